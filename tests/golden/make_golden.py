@@ -1,0 +1,312 @@
+"""Generate the golden fixtures under tests/golden/ from the reference (run in the build container only).
+
+The reference package (/root/reference) is imported here -- and only here -- to produce input/output
+VECTORS (numpy arrays).  No reference source travels: the fixtures are data.  Re-run with
+
+    python tests/golden/make_golden.py
+
+What is produced:
+  mat_*.npz      construct_A / construct_L / construct_M outputs           (bayes_drt/matrices.py)
+  ddt_*.npz      construct_A for the DDT kernels (Toeplitz path and general path)
+  dat_*.npz      Inverter._prep_matrices + _prep_stan_data output ("dat" dict) (bayes_drt/inversion.py:1684, :2127)
+  kat_*.npz      the 37 stored Stan `optimizing` results (code_EchemActa/map_results/obj_*.pkl):
+                 parameters + transformed parameters + the matrices they were computed from
+  csv_*.npz      reference data/result CSV files as arrays (data/simulated, map_results, bayes_results)
+  predict_*.npz  predict_distribution / predict_Z / predict_sigma outputs for given coefficients
+"""
+import glob
+import os
+import pickle
+import sys
+import types
+import warnings
+
+import numpy as np
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+warnings.filterwarnings('ignore')
+
+
+def _install_stubs():
+    # pystan / cvxopt are not installed; only the pre-Stan Python of the reference is executed.
+    cv = types.ModuleType('cvxopt')
+    cv.solvers = types.SimpleNamespace(options={})
+    cv.matrix = lambda *a, **k: None
+    sys.modules['cvxopt'] = cv
+    base = types.ModuleType('cvxopt.base')
+
+    class _Opaque(object):  # lets pickles that embed cvxopt matrices load; the content is never used
+        def __init__(self, *a, **k):
+            pass
+
+        def __setstate__(self, state):
+            pass
+
+    base.matrix = _Opaque
+    base.spmatrix = _Opaque
+    sys.modules['cvxopt.base'] = base
+    sys.modules['pystan'] = types.ModuleType('pystan')
+    sm = types.ModuleType('bayes_drt.stan_models')
+    sm.save_pickle = lambda *a, **k: None
+    sm.load_pickle = lambda *a, **k: None
+    sys.modules['bayes_drt.stan_models'] = sm
+    sm2 = types.ModuleType('stan_models')
+    sm2.save_pickle = sm.save_pickle
+    sm2.load_pickle = sm.load_pickle
+    sys.modules['stan_models'] = sm2
+
+
+_install_stubs()
+sys.path.insert(0, REF)
+from bayes_drt import matrices as rm  # noqa: E402
+from bayes_drt import inversion as ri  # noqa: E402
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print('%-58s %8.1f KB' % (name + '.npz', os.path.getsize(path) / 1024))
+
+
+def read_Z(path):
+    import pandas as pd
+    a = pd.read_csv(path)
+    return a['Freq'].values.astype(float), a['Zreal'].values + 1j * a['Zimag'].values
+
+
+# ---------------------------------------------------------------------------------------- matrices
+def gen_matrices():
+    cases = {
+        # name: (freq, basis_freq or None->tau=None)
+        '81x81': (np.logspace(6, -2, 81), None),
+        '81x161': (np.logspace(6, -2, 81), np.logspace(10, -6, 161)),
+        '41x51': (np.logspace(5, -3, 41)[::-1][::-1], 1 / (2 * np.pi * np.logspace(-2, 3, 51))),
+    }
+    for name, (f, bf) in cases.items():
+        if bf is None:
+            tau = None
+            tau_l = 1 / (2 * np.pi * f)
+        else:
+            tau = 1 / (2 * np.pi * bf)
+            tau_l = tau
+        eps = 1 / np.mean(np.diff(np.log(tau_l)))
+        out = dict(freq=f, tau=tau_l, epsilon=eps, tau_is_none=np.array(tau is None))
+        for part in ('real', 'imag'):
+            out['A_' + part[:2]] = rm.construct_A(f, part, tau=tau, epsilon=eps)
+        for o in (0, 1, 2):
+            out['L%d' % o] = rm.construct_L(1 / (2 * np.pi * tau_l), tau=tau_l, epsilon=eps, order=o)
+            out['M%d' % o] = rm.construct_M(1 / (2 * np.pi * tau_l), order=o, epsilon=eps)
+        save('mat_drt_' + name, **out)
+
+    # general (non log-uniform) path, small: irregular frequency grid and irregular tau grid
+    rs = np.random.RandomState(7)
+    f = np.sort(10 ** rs.uniform(-1, 4, 12))[::-1]
+    tau = np.sort(10 ** rs.uniform(-5, 1, 9))
+    eps = 1.7
+    out = dict(freq=f, tau=tau, epsilon=eps)
+    for part in ('real', 'imag'):
+        out['A_' + part[:2]] = rm.construct_A(f, part, tau=tau, epsilon=eps)
+    for o in (0, 1, 2):
+        out['L%d' % o] = rm.construct_L(1 / (2 * np.pi * tau), tau=tau, epsilon=eps, order=o)
+        out['M%d' % o] = rm.construct_M(1 / (2 * np.pi * tau), order=o, epsilon=eps)
+    # extra construct_L orders the reference supports (matrices.py:278-315)
+    out['L3'] = rm.construct_L(1 / (2 * np.pi * tau), tau=tau, epsilon=eps, order=3)
+    out['L0p5'] = rm.construct_L(1 / (2 * np.pi * tau), tau=tau, epsilon=eps, order=0.5)
+    out['L1p25'] = rm.construct_L(1 / (2 * np.pi * tau), tau=tau, epsilon=eps, order=1.25)
+    out['Lmix'] = rm.construct_L(1 / (2 * np.pi * tau), tau=tau, epsilon=eps, order=[0.2, 0.5, 0.3])
+    out['Mmix'] = rm.construct_M(1 / (2 * np.pi * tau), order=[0.2, 0.5, 0.3], epsilon=eps)
+    save('mat_drt_general_12x9', **out)
+
+
+def gen_ddt():
+    f = np.logspace(6, -2, 81)
+    tau = 1 / (2 * np.pi * np.logspace(10, -6, 161))
+    eps = 1 / np.mean(np.diff(np.log(tau)))
+    out = dict(freq=f, tau=tau, epsilon=eps)
+    for bc, sym, tag in (('transmissive', 'planar', 'tp'), ('blocking', 'planar', 'bp'), ('blocking', 'spherical', 'bs')):
+        for dt in ('parallel', 'series'):
+            for part in ('real', 'imag'):
+                A = rm.construct_A(f, part, tau=tau, epsilon=eps, kernel='DDT', dist_type=dt, symmetry=sym, bc=bc)
+                out['A_%s_%s_%s' % (part[:2], tag, dt)] = A
+    save('ddt_toeplitz_81x161', **out)
+
+    rs = np.random.RandomState(11)
+    f = np.sort(10 ** rs.uniform(-2, 5, 7))[::-1]
+    tau = np.sort(10 ** rs.uniform(-5, 2, 6))
+    eps = 2.3
+    out = dict(freq=f, tau=tau, epsilon=eps, k_ct=0.37)
+    for bc, sym, tag in (('transmissive', 'planar', 'tp'), ('blocking', 'planar', 'bp'), ('blocking', 'spherical', 'bs')):
+        for dt in ('parallel', 'series'):
+            for ct in (False, True):
+                for part in ('real', 'imag'):
+                    A = rm.construct_A(f, part, tau=tau, epsilon=eps, kernel='DDT', dist_type=dt, symmetry=sym,
+                                       bc=bc, ct=ct, k_ct=0.37 if ct else None)
+                    out['A_%s_%s_%s_ct%d' % (part[:2], tag, dt, int(ct))] = A
+    save('ddt_general_7x6', **out)
+
+
+# ---------------------------------------------------------------------------------------- dat dicts
+def _dat_arrays(dat):
+    out = {}
+    for k, v in dat.items():
+        if k.endswith('_tilde'):
+            continue  # duplicates of the fit inputs (inversion.py:1744-1746)
+        out[k] = np.asarray(v)
+    return out
+
+
+def gen_dat():
+    f, Z = read_Z(os.path.join(REF, 'data/simulated/Z_2ZARC_uniform_0.25.csv'))
+    for tag, bf in (('K101', None), ('K161', np.logspace(10, -6, 161)), ('K81', 'freq')):
+        inv = ri.Inverter(basis_freq=(f if isinstance(bf, str) else bf))
+        fs, Zs, WZ_re, WZ_im, W_re, W_im, dist_mat = inv._prep_matrices(f, Z, 'both', weights=None, dZ=False,
+                                                                        scale_Z=True, penalty='discrete',
+                                                                        fit_type='map')
+        for mode in ('optimize', 'sample'):
+            dat = inv._prep_stan_data(fs, Zs, 'both', 'Series', dist_mat, False, 0.002, mode=mode,
+                                      inductance_scale=1, outlier_lambda=None, fitY=False, SA=False, SASY=False)
+            arr = _dat_arrays(dat)
+            arr['Z_scale'] = np.array(inv._Z_scale)
+            arr['tau'] = inv.distributions['DRT']['tau']
+            arr['epsilon'] = np.array(inv.distributions['DRT']['epsilon'])
+            arr['freq_in'] = f
+            arr['Z_in'] = Z
+            save('dat_%s_2ZARC_uniform_0.25_%s' % (mode, tag), **arr)
+        if tag == 'K161':
+            # outlier variant (package "new" form, inversion.py:1873-1880; N overwritten at :1208-1211)
+            for mode in ('optimize', 'sample'):
+                dat = inv._prep_stan_data(fs, Zs, 'both', 'Series', dist_mat, True, 0.002, mode=mode,
+                                          inductance_scale=1, outlier_lambda=None, fitY=False, SA=False, SASY=False)
+                arr = {k: np.asarray(v) for k, v in dat.items() if k.startswith('sigma_out')}
+                save('dat_%s_outlier_scalars' % mode, **arr)
+
+    # series + parallel (config 5 family): DRT + TP-DDT, K=161 both
+    f, Z = read_Z(os.path.join(REF, 'data/simulated/Z_DRT-2-TpDDT_uniform_0.25.csv'))
+    bf = np.logspace(10, -6, 161)
+    dists = {'DRT': {'kernel': 'DRT'},
+             'TP-DDT': {'kernel': 'DDT', 'symmetry': 'planar', 'bc': 'transmissive', 'dist_type': 'parallel',
+                        'x_scale': 0.8}}
+    inv = ri.Inverter(basis_freq=bf, distributions=dists)
+    fs, Zs, WZ_re, WZ_im, W_re, W_im, dist_mat = inv._prep_matrices(f, Z, 'both', weights=None, dZ=False,
+                                                                    scale_Z=True, penalty='discrete', fit_type='map')
+    for mode in ('optimize', 'sample'):
+        for outl in (False, True):
+            dat = inv._prep_stan_data(fs, Zs, 'both', 'Series-Parallel', dist_mat, outl, 0.002, mode=mode,
+                                      inductance_scale=1, outlier_lambda=None, fitY=False, SA=False, SASY=False)
+            arr = _dat_arrays(dat)
+            if not (mode == 'sample' and not outl):
+                # keep only one full copy of the big matrices; the others keep scalars + Z
+                arr = {k: v for k, v in arr.items() if v.size < 2000}
+            arr['Z_scale'] = np.array(inv._Z_scale)
+            arr['freq_in'] = f
+            arr['Z_in'] = Z
+            save('dat_%s_DRT-TpDDT_%s' % (mode, 'outliers' if outl else 'plain'), **arr)
+
+
+# ---------------------------------------------------------------------------------------- KATs
+def gen_kats():
+    sys.path.insert(0, os.path.join(REF, 'code_EchemActa/bayes-drt_20201113'))
+    pk = sorted(glob.glob(os.path.join(REF, 'code_EchemActa/map_results/obj_*.pkl')))
+    for p in pk:
+        name = os.path.basename(p)[4:-4]
+        with open(p, 'rb') as fh:
+            obj = pickle.load(fh)
+        d = obj.__dict__
+        out = {}
+        res = d['_opt_result']
+        for k, v in res.items():
+            if k.endswith('_tilde'):
+                continue
+            out['opt__' + k] = np.asarray(v, dtype=float)
+        out['model_name'] = np.array(d['stan_model_name'])
+        out['Z_scale'] = np.array(float(d['_Z_scale']))
+        out['sigma_min'] = np.array(float(d.get('sigma_min', np.nan)))
+        out['f_train'] = np.asarray(d['f_train'], dtype=float)
+        dists = d['_distributions']
+        names = list(d['distribution_matrices'].keys())
+        out['dist_names'] = np.array(names)
+        for n in names:
+            m = d['distribution_matrices'][n]
+            info = dists.get(n, {}) if isinstance(dists, dict) else {}
+            for key in ('A_re', 'A_im', 'L0', 'L1', 'L2'):
+                if key in m:
+                    out['mat__%s__%s' % (n, key)] = np.asarray(m[key], dtype=float)
+            out['info__%s__dist_type' % n] = np.array(str(info.get('dist_type', 'series')))
+            out['info__%s__kernel' % n] = np.array(str(info.get('kernel', 'DRT')))
+            out['info__%s__x_scale' % n] = np.array(float(info.get('x_scale', 1.0)))
+            out['info__%s__bc' % n] = np.array(str(info.get('bc', '')))
+            out['info__%s__symmetry' % n] = np.array(str(info.get('symmetry', '')))
+        # measured data, when the simulated file of the same name exists
+        zf = os.path.join(REF, 'data/simulated/Z_%s.csv' % name)
+        if os.path.exists(zf):
+            f, Z = read_Z(zf)
+            idx = np.argsort(f)[::-1]
+            out['data_freq'] = f[idx]
+            out['data_Z'] = Z[idx]
+        save('kat_' + name, **out)
+
+
+# ---------------------------------------------------------------------------------------- CSVs + predict
+def gen_csv():
+    def csv(path):
+        import pandas as pd
+        a = pd.read_csv(path)
+        a = a[[c for c in a.columns if not c.startswith('Unnamed')]]
+        return a.values.astype(float), np.array(list(a.columns))
+
+    for stem in ('2ZARC_uniform_0.25', '2ZARC_noiseless', '2RC_uniform_0.25', 'RC-ZARC_uniform_0.25'):
+        out = {}
+        for key, rel in (('Z', 'data/simulated/Z_%s.csv'), ('Gout_map', 'code_EchemActa/map_results/Gout_%s.csv'),
+                         ('Zout_map', 'code_EchemActa/map_results/Zout_%s.csv'),
+                         ('Gout_bayes', 'code_EchemActa/bayes_results/Gout_%s.csv'),
+                         ('Zout_bayes', 'code_EchemActa/bayes_results/Zout_%s.csv')):
+            p = os.path.join(REF, rel % stem)
+            if os.path.exists(p):
+                out[key], out[key + '_cols'] = csv(p)
+        circ = stem.split('_')[0]
+        p = os.path.join(REF, 'data/simulated/gamma_%s.csv' % circ)
+        if os.path.exists(p):
+            out['gamma_true'], out['gamma_true_cols'] = csv(p)
+        save('csv_' + stem, **out)
+    p = os.path.join(REF, 'code_EchemActa/bayes_results/Gout_2RC_uniform_0.25_4x1000.csv')
+    g, c = csv(p)
+    save('csv_2RC_uniform_0.25_4x1000', Gout_bayes=g, Gout_bayes_cols=c)
+
+
+def gen_predict():
+    # predict_distribution / predict_Z / predict_sigma for a *given* coefficient vector (no Stan needed):
+    # inversion.py:3298-3311 (gamma = Phi @ coef), :2942-2959 (Z_hat), :3089-3139 (sigma)
+    f, Z = read_Z(os.path.join(REF, 'data/simulated/Z_2ZARC_uniform_0.25.csv'))
+    inv = ri.Inverter(basis_freq=np.logspace(10, -6, 161))
+    inv._prep_matrices(f, Z, 'both', weights=None, dZ=False, scale_Z=True, penalty='discrete', fit_type='map')
+    rs = np.random.RandomState(3)
+    K = 161
+    tau = inv.distributions['DRT']['tau']
+    coef = np.exp(-0.5 * ((np.log(tau) - np.log(1e-2)) / 1.5) ** 2) * (1 + 0.1 * rs.rand(K))
+    inv.distribution_fits = {'DRT': {'coef': coef}}
+    inv.R_inf = 0.93
+    inv.inductance = 2.2e-7
+    inv.fit_type = 'map'
+    inv.stan_model_name = 'Series_pos_StanModel.pkl'
+    inv.error_fit = {'sigma_min': 0.002 * inv._Z_scale, 'sigma_res': 0.004, 'alpha_prop': 0.003, 'alpha_re': 0.002,
+                     'alpha_im': 0.001}
+    tau_plot = np.logspace(-7, 2, 200)
+    g = inv.predict_distribution('DRT', eval_tau=tau_plot)
+    f = np.sort(f)[::-1]
+    f_alt = np.logspace(5, -1, 31)
+    Zp = inv.predict_Z(f)
+    inv.f_pred = None  # the reference's cache check cannot compare grids of different length
+    Zp_alt = inv.predict_Z(f_alt)
+    s_re, s_im = inv.predict_sigma(f_alt)
+    Rp = inv.predict_Rp()
+    save('predict_2ZARC_K161', freq=f, tau=tau, epsilon=np.array(inv.distributions['DRT']['epsilon']), coef=coef,
+         R_inf=np.array(inv.R_inf), inductance=np.array(inv.inductance), tau_plot=tau_plot, gamma=g, Z_pred=Zp,
+         f_alt=f_alt, Z_pred_alt=Zp_alt, sigma_re_alt=s_re, sigma_im_alt=s_im, Rp=np.array(Rp), Z_scale=np.array(inv._Z_scale),
+         **{'err_' + k: np.array(v) for k, v in inv.error_fit.items()})
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['matrices', 'ddt', 'dat', 'kats', 'csv', 'predict']
+    for w in which:
+        globals()['gen_' + w]()
