@@ -1,0 +1,232 @@
+"""ctypes front-end of the CPU ORACLE (oracle/bdrt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product (bayes_drt_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+MAXB = 3
+
+KERNEL_IDS = {
+    ('DRT', None, None): 0,
+    ('DDT', 'blocking', 'planar'): 1,
+    ('DDT', 'blocking', 'spherical'): 2,
+    ('DDT', 'transmissive', 'planar'): 3,
+}
+
+
+class _Model(C.Structure):
+    _fields_ = [('nf', C.c_int), ('nblocks', C.c_int),
+                ('K', C.c_int * MAXB), ('is_parallel', C.c_int * MAXB), ('nonneg', C.c_int * MAXB),
+                ('x_scale', C.c_double * MAXB),
+                ('A', C.c_void_p * MAXB), ('L0', C.c_void_p * MAXB), ('L1', C.c_void_p * MAXB),
+                ('L2', C.c_void_p * MAXB),
+                ('Z', C.c_void_p), ('freq', C.c_void_p),
+                ('sigma_min', C.c_double), ('ups_alpha', C.c_double), ('ups_beta', C.c_double),
+                ('induc_scale', C.c_double),
+                ('outlier_mode', C.c_int),
+                ('so_lambda', C.c_double), ('so_alpha', C.c_double), ('so_beta', C.c_double),
+                ('use_x_sum', C.c_int), ('x_sum_invscale', C.c_double)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, 'liboracle.so')
+    srcs = [os.path.join(_HERE, f) for f in ('bdrt_oracle.c', 'bdrt_oracle.h', 'nuts_oracle.c')]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(['make', '-s', '-C', _HERE, 'liboracle.so'])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_num_params.restype = C.c_int
+        _LIB.orc_logp_grad.restype = C.c_int
+        _LIB.orc_forward.restype = C.c_int
+        _LIB.orc_build_A.restype = C.c_int
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class OracleModel:
+    """A Stan model instance = blocks + data.  blocks: list of dicts with keys
+    A [2nf x K], L0, L1, L2 [K x K] (already mode-scaled), parallel (bool), nonneg (bool), x_scale."""
+
+    def __init__(self, blocks, Z, freq, sigma_min=0.002, ups_alpha=1.0, ups_beta=0.1, induc_scale=1.0,
+                 outlier_mode=0, so_lambda=10.0, so_alpha=5.0, so_beta=1.0, use_x_sum=None, x_sum_invscale=0.0):
+        self._keep = []
+        m = _Model()
+        m.nf = len(freq)
+        m.nblocks = len(blocks)
+        for b, blk in enumerate(blocks):
+            A = _f64(blk['A'])
+            assert A.shape[0] == 2 * m.nf
+            m.K[b] = A.shape[1]
+            m.is_parallel[b] = int(bool(blk.get('parallel', False)))
+            m.nonneg[b] = int(bool(blk.get('nonneg', False)))
+            m.x_scale[b] = float(blk.get('x_scale', 1.0))
+            arrs = [A] + [_f64(blk[k]) for k in ('L0', 'L1', 'L2')]
+            self._keep += arrs
+            m.A[b], m.L0[b], m.L1[b], m.L2[b] = [a.ctypes.data for a in arrs]
+        self.Z = _f64(Z)
+        self.freq = _f64(freq)
+        m.Z = self.Z.ctypes.data
+        m.freq = self.freq.ctypes.data
+        m.sigma_min, m.ups_alpha, m.ups_beta, m.induc_scale = sigma_min, ups_alpha, ups_beta, induc_scale
+        m.outlier_mode = outlier_mode
+        m.so_lambda, m.so_alpha, m.so_beta = so_lambda, so_alpha, so_beta
+        if use_x_sum is None:
+            use_x_sum = len(blocks) > 1
+        m.use_x_sum = int(use_x_sum)
+        m.x_sum_invscale = x_sum_invscale
+        self.m = m
+        self.D = lib().orc_num_params(C.byref(m))
+        self.Ks = [m.K[b] for b in range(m.nblocks)]
+
+    def layout(self):
+        o_x = (C.c_int * MAXB)(); o_u = (C.c_int * MAXB)(); o_d = (C.c_int * MAXB)()
+        o_err = C.c_int(); o_so = C.c_int()
+        pos = np.zeros(self.D, dtype=np.uint8)
+        lib().orc_layout(C.byref(self.m), o_x, C.byref(o_err), C.byref(o_so), o_u, o_d, _p(pos))
+        nb = self.m.nblocks
+        return dict(x=list(o_x)[:nb], err=o_err.value, so=o_so.value, ups=list(o_u)[:nb], d=list(o_d)[:nb],
+                    is_pos=pos.astype(bool))
+
+    def logp_grad(self, theta, jacobian=True):
+        theta = _f64(theta)
+        lp = C.c_double()
+        g = np.empty(self.D)
+        lib().orc_logp_grad(C.byref(self.m), _p(theta), int(jacobian), C.byref(lp), _p(g))
+        return lp.value, g
+
+    def logp(self, theta, jacobian=True):
+        theta = _f64(theta)
+        lp = C.c_double()
+        lib().orc_logp_grad(C.byref(self.m), _p(theta), int(jacobian), C.byref(lp), None)
+        return lp.value
+
+    def forward(self, theta):
+        theta = _f64(theta)
+        nf = self.m.nf
+        Kt = sum(self.Ks)
+        out = dict(Z_hat=np.empty(2 * nf), sigma_tot=np.empty(2 * nf), q=np.empty(Kt), ups=np.empty(Kt),
+                   dups=np.empty(Kt - 2 * len(self.Ks)))
+        xs = C.c_double()
+        lib().orc_forward(C.byref(self.m), _p(theta), _p(out['Z_hat']), _p(out['sigma_tot']), _p(out['q']),
+                          _p(out['ups']), _p(out['dups']), C.byref(xs))
+        out['x_sum'] = xs.value
+        return out
+
+    def constrain(self, theta):
+        out = np.empty(self.D)
+        lib().orc_constrain(C.byref(self.m), _p(_f64(theta)), _p(out))
+        return out
+
+    def unconstrain(self, params):
+        out = np.empty(self.D)
+        lib().orc_unconstrain(C.byref(self.m), _p(_f64(params)), _p(out))
+        return out
+
+
+# ------------------------------------------------------------------------------------------ matrices
+def _rel_round(x, precision):
+    """bayes_drt/utils.py:113-130 (relative rounding used for frequency matching)."""
+    x = np.asarray(x, dtype=float)
+    scale = np.floor(np.log10(x + 1e-30))
+    digits = (precision - scale).astype(int)
+    return np.array([round(float(v), int(d)) for v, d in zip(x, digits)])
+
+
+def is_loguniform(frequencies):
+    """bayes_drt/utils.py:133-139."""
+    fd = np.diff(np.log(frequencies))
+    return bool(np.std(fd) / np.mean(fd) <= 0.01)
+
+
+def a_is_toeplitz(frequencies, tau, ct=False):
+    """Toeplitz decision of construct_A (bayes_drt/matrices.py:145-205)."""
+    omega = np.asarray(frequencies, dtype=float) * 2 * np.pi
+    tau = np.asarray(tau, dtype=float)
+    inv_om = _rel_round(1 / omega, 10)
+    tau_r = _rel_round(tau, 10)
+    tau_eq_omega = len(tau) == len(omega) and bool(np.all(tau_r == inv_om))
+    subset = False
+    hit = np.where(tau_r == inv_om[0])[0]
+    if len(hit) > 1:
+        raise Exception('Repeated tau values')
+    if len(hit) == 1:
+        s = hit[0]
+        seg = tau_r[s:s + len(omega)]
+        subset = len(seg) == len(omega) and bool(np.all(seg == inv_om))
+    if not subset:
+        om_r = _rel_round(omega, 10)
+        hit = np.where(inv_om == tau_r[0])[0]
+        if len(hit) > 1:
+            raise Exception('Repeated omega values')
+        if len(hit) == 1:
+            s = hit[0]
+            seg = om_r[s:s + len(tau)]
+            subset = len(seg) == len(tau) and bool(np.all(seg == _rel_round(1 / tau, 10)))
+    if is_loguniform(frequencies) and not ct:
+        return bool(tau_eq_omega or (subset and is_loguniform(tau)))
+    return False
+
+
+def construct_A(frequencies, part, tau=None, epsilon=1.0, kernel='DRT', dist_type='series', symmetry='planar',
+                bc=None, ct=False, k_ct=None, toeplitz=None):
+    f = _f64(frequencies)
+    tau = _f64(1 / (2 * np.pi * f) if tau is None else tau)
+    if toeplitz is None:
+        toeplitz = a_is_toeplitz(f, tau, ct)
+    kid = KERNEL_IDS[('DRT', None, None)] if kernel == 'DRT' else KERNEL_IDS[('DDT', bc, symmetry)]
+    out = np.empty((len(f), len(tau)))
+    rc = lib().orc_build_A(_p(f), len(f), _p(tau), len(tau), C.c_double(epsilon), kid,
+                           0 if part == 'real' else 1, int(dist_type == 'series'), int(bool(ct)),
+                           C.c_double(k_ct if k_ct is not None else 0.0), int(toeplitz), _p(out))
+    if rc != 0:
+        raise Exception('First entries of first row and column are not equal')
+    return out
+
+
+def _order_coefs(order, n):
+    c = np.zeros(n)
+    if isinstance(order, (list, tuple)):
+        c[:3] = order
+    elif order in (0, 1, 2, 3) and order < n:
+        c[int(order)] = 1.0
+    elif 0 < order < 1:
+        c[0], c[1] = 1 - order, order
+    elif 1 < order < 2:
+        c[1], c[2] = 2 - order, order - 1
+    else:
+        raise ValueError('Order must be between 0 and 3')
+    return c
+
+
+def construct_L(tau, epsilon, order):
+    tau = _f64(tau)
+    out = np.empty((len(tau), len(tau)))
+    lib().orc_build_L(_p(tau), len(tau), C.c_double(epsilon), _p(_order_coefs(order, 4)), _p(out))
+    return out
+
+
+def construct_M(tau, epsilon, order):
+    tau = _f64(tau)
+    out = np.empty((len(tau), len(tau)))
+    toep = is_loguniform(1 / (2 * np.pi * tau))
+    lib().orc_build_M(_p(tau), len(tau), C.c_double(epsilon), _p(_order_coefs(order, 3)), int(toep), _p(out))
+    return out
