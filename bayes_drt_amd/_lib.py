@@ -1,0 +1,146 @@
+"""ctypes binding of libbdrt.so (C ABI: include/bdrt.h).
+
+This is the binding INTEGRATION.md shows for the reference side: plain pointers and sizes, no torch types.
+The library is loaded lazily and loudly: a missing libbdrt.so or a missing GPU is an error, never a fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+MAXB = 3
+
+
+class BdrtError(RuntimeError):
+    pass
+
+
+class Dat(C.Structure):
+    """bdrt_dat (include/bdrt.h) = the Stan data block assembled by Inverter._prep_stan_data."""
+    _fields_ = [('nf', C.c_int), ('nblocks', C.c_int),
+                ('K', C.c_int * MAXB), ('is_parallel', C.c_int * MAXB), ('nonneg', C.c_int * MAXB),
+                ('x_scale', C.c_double * MAXB),
+                ('A', C.c_void_p * MAXB), ('L0', C.c_void_p * MAXB), ('L1', C.c_void_p * MAXB),
+                ('L2', C.c_void_p * MAXB),
+                ('freq', C.c_void_p), ('n_spectra', C.c_int), ('Z', C.c_void_p),
+                ('sigma_min', C.c_double), ('ups_alpha', C.c_double), ('ups_beta', C.c_double),
+                ('induc_scale', C.c_double),
+                ('outlier_mode', C.c_int),
+                ('so_lambda', C.c_double), ('so_alpha', C.c_double), ('so_beta', C.c_double),
+                ('use_x_sum', C.c_int), ('x_sum_invscale', C.c_double)]
+
+
+class OptOptions(C.Structure):
+    _fields_ = [('max_iter', C.c_int), ('history', C.c_int), ('init_alpha', C.c_double), ('tol_obj', C.c_double),
+                ('tol_rel_obj', C.c_double), ('tol_grad', C.c_double), ('tol_rel_grad', C.c_double),
+                ('tol_param', C.c_double)]
+
+
+class OptReport(C.Structure):
+    _fields_ = [('iterations', C.c_int), ('n_evals', C.c_int), ('return_code', C.c_int), ('lp', C.c_double),
+                ('grad_norm', C.c_double)]
+
+
+class NutsControl(C.Structure):
+    _fields_ = [('adapt_delta', C.c_double), ('adapt_t0', C.c_double), ('adapt_gamma', C.c_double),
+                ('adapt_kappa', C.c_double), ('max_treedepth', C.c_int), ('init_buffer', C.c_int),
+                ('term_buffer', C.c_int), ('base_window', C.c_int), ('init_radius', C.c_double),
+                ('max_deltaH', C.c_double), ('stepsize0', C.c_double)]
+
+
+class ChainDiag(C.Structure):
+    _fields_ = [('n_leapfrog', C.c_int64), ('n_divergent', C.c_int), ('n_max_treedepth', C.c_int),
+                ('stepsize', C.c_double), ('mean_accept', C.c_double)]
+
+
+# every symbol include/bdrt.h declares (tests/test_abi.py checks the library exports each of them)
+SYMBOLS = [
+    'bdrt_build_A', 'bdrt_build_L', 'bdrt_build_M',
+    'bdrt_problem_create', 'bdrt_problem_destroy', 'bdrt_num_params', 'bdrt_param_is_pos', 'bdrt_problem_set_Z',
+    'bdrt_logp_grad', 'bdrt_logp_grad_dev', 'bdrt_transformed',
+    'bdrt_opt_defaults', 'bdrt_optimize',
+    'bdrt_nuts_defaults', 'bdrt_sampler_create', 'bdrt_sampler_destroy', 'bdrt_sampler_advance', 'bdrt_sampler_sync',
+    'bdrt_sampler_run', 'bdrt_sampler_results', 'bdrt_sampler_total_leapfrogs', 'bdrt_sampler_kernel_time',
+    'bdrt_sample',
+    'bdrt_gram', 'bdrt_qp_box',
+    'bdrt_last_error', 'bdrt_device_count', 'bdrt_set_device', 'bdrt_version',
+]
+
+
+def library_path():
+    return os.path.join(_HERE, 'libbdrt.so')
+
+
+def load_library():
+    """Load libbdrt.so.  Raises BdrtError when it has not been built (no silent fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise BdrtError('libbdrt.so not found at %s: build it with `python -c "import __graft_entry__ as g; '
+                        'g.build()"` or `make -C bayes_drt_amd/csrc`' % path)
+    lib = C.CDLL(path)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.c_void_p
+    lib.bdrt_last_error.restype = C.c_char_p
+    lib.bdrt_version.restype = C.c_char_p
+    lib.bdrt_problem_create.restype = vp
+    lib.bdrt_problem_create.argtypes = [C.POINTER(Dat)]
+    lib.bdrt_problem_destroy.argtypes = [vp]
+    lib.bdrt_problem_destroy.restype = None
+    lib.bdrt_num_params.argtypes = [vp]
+    lib.bdrt_param_is_pos.argtypes = [vp, vp]
+    lib.bdrt_problem_set_Z.argtypes = [vp, vp, C.c_int]
+    lib.bdrt_logp_grad.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.bdrt_logp_grad_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    lib.bdrt_transformed.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
+    lib.bdrt_build_A.argtypes = [vp, C.c_int, vp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                 C.c_int, vp]
+    lib.bdrt_build_L.argtypes = [vp, C.c_int, C.c_double, vp, vp]
+    lib.bdrt_build_M.argtypes = [vp, C.c_int, C.c_double, vp, C.c_int, vp]
+    lib.bdrt_opt_defaults.argtypes = [C.POINTER(OptOptions)]
+    lib.bdrt_opt_defaults.restype = None
+    lib.bdrt_optimize.argtypes = [vp, vp, vp, C.c_int, C.POINTER(OptOptions), vp, vp]
+    lib.bdrt_nuts_defaults.argtypes = [C.POINTER(NutsControl)]
+    lib.bdrt_nuts_defaults.restype = None
+    lib.bdrt_sampler_create.restype = vp
+    lib.bdrt_sampler_create.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_uint64, vp, C.POINTER(NutsControl)]
+    lib.bdrt_sampler_destroy.argtypes = [vp]
+    lib.bdrt_sampler_destroy.restype = None
+    lib.bdrt_sampler_advance.argtypes = [vp, C.c_int, vp]
+    lib.bdrt_sampler_sync.argtypes = [vp]
+    lib.bdrt_sampler_run.argtypes = [vp]
+    lib.bdrt_sampler_results.argtypes = [vp, vp, vp, vp]
+    lib.bdrt_sampler_total_leapfrogs.argtypes = [vp]
+    lib.bdrt_sampler_total_leapfrogs.restype = C.c_int64
+    lib.bdrt_sampler_kernel_time.argtypes = [vp, vp, vp, C.c_int]
+    lib.bdrt_sample.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_uint64, vp, C.POINTER(NutsControl), vp, vp,
+                                vp]
+    lib.bdrt_gram.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.bdrt_qp_box.argtypes = [vp, vp, vp, C.c_int, vp, vp]
+    lib.bdrt_set_device.argtypes = [C.c_int]
+    _LIB = lib
+    return lib
+
+
+def check(rc, what):
+    if rc is None or (isinstance(rc, int) and rc < 0):
+        raise BdrtError('%s failed (%s): %s' % (what, rc, load_library().bdrt_last_error().decode()))
+    return rc
+
+
+def require_gpu():
+    lib = load_library()
+    if lib.bdrt_device_count() < 1:
+        raise BdrtError('no HIP device visible: bayes_drt_amd has no CPU fallback')
+    return lib
+
+
+def f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

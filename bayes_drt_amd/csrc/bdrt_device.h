@@ -1,0 +1,458 @@
+// bdrt_device.h -- device-side model description and the tile evaluator of the log-posterior + gradient.
+//
+// One workgroup (512 threads = 8 wave64) evaluates NC = 16 points ("chains") at once so that every dense
+// contraction of the Stan model is an fp64 MFMA GEMM with N = 16:
+//     forward   Y[R x 16]  = M[R x K] . X[K x 16]        (A x, L0 x, L1 x, L2 x)
+//     backward  G[K x 16]  = M^T[K x R] . Rm[R x 16]     (A^T g_Zhat - sum_i d_i L_i^T (v_i / ups^2))
+// with v_mfma_f64_16x16x4_f64.  The matrices are pre-packed into MFMA fragment order (bdrt_model.hip) so a
+// wave's operand load is one contiguous 1 KiB global_load_dwordx4; they stay L2-resident (0.83 MB for the
+// 81 x 161 benchmark shape).  X / Y / Rm live in LDS as [row][16 chains] so that every MFMA B-operand read is a
+// conflict-free ds_read_b64 and the element-wise model code in between (likelihood, priors, chain rule) is a
+// (row, chain) map over the workgroup with wave-shuffle + LDS reductions for the per-chain scalars.
+//
+// Model being evaluated: bayes_drt/stan_model_files/*_modelcode.txt (reference), all families written as
+// "blocks" (see include/bdrt.h).  Gradient: hand-derived reverse pass.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bdrt {
+
+constexpr int NC = 16;        // chains per workgroup = MFMA N
+constexpr int NT = 512;       // threads per workgroup
+constexpr int NW = NT / 64;   // waves per workgroup
+constexpr int NG = NT / NC;   // row groups in the element-wise phases
+constexpr int MAXB = 3;
+constexpr int NRED = 8;       // max quantities per block reduction
+constexpr double LOG_015 = -1.8971199848858813;   // log(0.15): ups = 0.15*ups_raw
+
+struct DevBlock {
+    int K;            // basis functions
+    int is_parallel, is_pos;
+    int tilesA;       // ceil(2nf/16)
+    int tilesL;       // ceil(3K/16)
+    int tilesK;       // ceil(K/16)
+    int kpairs;       // ceil(K/8): forward reduction in pairs of k-steps (8 columns per pair)
+    int rpairsA;      // ceil(2nf/8)
+    int rpairsL;      // ceil(3K/8)
+    int o_x, o_ups, o_d;
+    int yp_slot;      // index of the Y_hat buffer for parallel blocks
+    double x_scale;
+    const double *Af; // [tilesA][kpairs][64][2]   A rows x K cols, fragment order
+    const double *Lf; // [tilesL][kpairs][64][2]   (L0;L1;L2) rows x K cols
+    const double *Bk; // [tilesK][rpairsA+rpairsL][64][2]  transposed: K rows x (2nf pad | 3K pad) reduction
+};
+
+struct DevProblem {
+    int nf, nblocks, D;
+    int o_err, o_so;
+    int outlier_mode, use_x_sum;
+    int n_spectra;
+    int XR, ZR, LR, npar;     // LDS row counts
+    double sigma_min, ups_alpha, ups_beta, induc_scale;
+    double so_lambda, so_alpha, so_beta, x_sum_invscale;
+    const double *Z;          // [n_spectra][2nf]
+    const double *w;          // [nf] 2*pi*f
+    DevBlock blk[MAXB];
+};
+
+__host__ __device__ inline size_t lds_doubles(const DevProblem &P)
+{
+    return (size_t)NC * ((size_t)P.XR + (size_t)P.ZR * (1 + P.npar) + (size_t)P.LR + NW * NRED + 32);
+}
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// Y[(16 t + i)][c] = sum_k M[16 t + i][k] X[k][c] for the tiles of this wave.
+// Fragment order (host packing in bdrt_model.hip::pack_forward): element (tile t, pair p, lane l, h) =
+// M[16 t + (l & 15)][8 p + 4 h + (l >> 4)].
+__device__ __forceinline__ void gemm_forward(const double *__restrict__ Mp, int ntiles, int kpairs,
+                                             const double *Xs, double *Ys, int wave, int lane)
+{
+    const int col = lane & 15, kq = lane >> 4;
+    for (int t = wave; t < ntiles; t += NW) {
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const double2 *mp = reinterpret_cast<const double2 *>(Mp) + ((size_t)t * kpairs) * 64 + lane;
+        const double *xb = Xs + kq * NC + col;
+#pragma unroll 4
+        for (int p = 0; p < kpairs; ++p) {
+            const double2 a = mp[(size_t)p * 64];
+            const double b0 = xb[(8 * p) * NC];
+            const double b1 = xb[(8 * p + 4) * NC];
+            acc0 = mfma_f64(a.x, b0, acc0);
+            acc1 = mfma_f64(a.y, b1, acc1);
+        }
+        // C/D layout of v_mfma_f64_16x16x4_f64: row = (lane >> 4) + 4 r, col = lane & 15
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ys[(16 * t + kq + 4 * r) * NC + col] = acc0[r] + acc1[r];
+    }
+}
+
+// G[(16 t + i)][c] = sum_r M[r][16 t + i] Rm[r][c]; reduction rows = [A part (Ra) | L part (Rl)].
+// Fragment order (pack_backward): element (tile t, pair p, lane l, h) = Mt[16 t + (l & 15)][8 p + 4 h + (l >> 4)],
+// Mt = transposed stacked matrix with the A part padded to 8*rpairsA rows.
+__device__ __forceinline__ void gemm_backward(const double *__restrict__ Mp, int ntiles, int rpairsA, int rpairsL,
+                                              const double *Ra, const double *Rl, double *Gs, int wave, int lane)
+{
+    const int col = lane & 15, kq = lane >> 4;
+    const int rp = rpairsA + rpairsL;
+    for (int t = wave; t < ntiles; t += NW) {
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const double2 *mp = reinterpret_cast<const double2 *>(Mp) + ((size_t)t * rp) * 64 + lane;
+        const double *ra = Ra + kq * NC + col;
+        const double *rl = Rl + kq * NC + col;
+#pragma unroll 4
+        for (int p = 0; p < rpairsA; ++p) {
+            const double2 a = mp[(size_t)p * 64];
+            acc0 = mfma_f64(a.x, ra[(8 * p) * NC], acc0);
+            acc1 = mfma_f64(a.y, ra[(8 * p + 4) * NC], acc1);
+        }
+        mp += (size_t)rpairsA * 64;
+#pragma unroll 4
+        for (int p = 0; p < rpairsL; ++p) {
+            const double2 a = mp[(size_t)p * 64];
+            acc0 = mfma_f64(a.x, rl[(8 * p) * NC], acc0);
+            acc1 = mfma_f64(a.y, rl[(8 * p + 4) * NC], acc1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Gs[(16 * t + kq + 4 * r) * NC + col] = acc0[r] + acc1[r];
+    }
+}
+
+// Sum NQ per-thread partials over the row groups of each chain.  Deterministic order:
+// lanes (c, c+16, c+32, c+48) by xor-shuffle, then the 8 waves in index order.  Result in out[q*NC + c].
+template <int NQ>
+__device__ __forceinline__ void chain_reduce(double (&v)[NQ], double *red, double *out, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double x = v[q];
+        x += __shfl_xor(x, 16);
+        x += __shfl_xor(x, 32);
+        if (lane < NC) red[(wave * NRED + q) * NC + lane] = x;
+    }
+    __syncthreads();
+    if (tid < NQ * NC) {
+        const int q = tid / NC, c = tid % NC;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[(w * NRED + q) * NC + c];
+        out[q * NC + c] = s;
+    }
+    __syncthreads();
+}
+
+// per-chain scalar slots in LDS
+enum { S_RINF = 0, S_INDUC, S_SRES, S_AP, S_AR, S_AI, S_D0 /* 9 slots */, S_XSUM = 15, S_LP = 16, S_TMP = 17 /* 8 slots */,
+       S_REJ = 25, S_NSLOT = 32 };
+
+struct TileIO {
+    const double *theta;   // unconstrained parameters
+    long t_sc, t_sj;       // strides: chain, parameter
+    double *grad;          // may be nullptr
+    long g_sc, g_sj;
+    double *lp;            // [16] (global or LDS), stride 1; may be nullptr
+    const int *spec;       // spectrum index per chain (nullptr: 0)
+    int nvalid;            // chains in this tile that exist
+    int jacobian;
+    double *Z_hat;         // optional [chain][2nf] outputs (transformed parameters)
+    double *sigma_tot;
+    double *params;        // optional [chain][D] constrained parameters
+};
+
+// Evaluate lp and gradient for the 16 chains of this workgroup.  smem: lds_doubles(P) doubles.
+// All threads of the workgroup must call.  Ends with a __syncthreads().
+__device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, double *smem)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = tid & (NC - 1), g = tid >> 4;          // chain column, row group
+    const int nf = P.nf, N2 = 2 * nf;
+    const bool valid = c < io.nvalid;
+    const int cc = valid ? c : 0;                         // padded columns replay chain 0 (never written back)
+    const double jac = io.jacobian ? 1.0 : 0.0;
+
+    double *Xs = smem;
+    double *Zh = Xs + (size_t)P.XR * NC;
+    double *Yp = Zh + (size_t)P.ZR * NC;
+    double *Lr = Yp + (size_t)P.ZR * NC * P.npar;
+    double *red = Lr + (size_t)P.LR * NC;
+    double *sc = red + NW * NRED * NC;
+
+    const double *th = io.theta + (long)cc * io.t_sc;
+    auto TH = [&](int j) -> double { return th[(long)j * io.t_sj]; };
+    double *gr = io.grad ? io.grad + (long)cc * io.g_sc : nullptr;
+    auto GW = [&](int j, double v) { if (gr && valid) gr[(long)j * io.g_sj] = v; };
+    double *pr = io.params ? io.params + (size_t)cc * P.D : nullptr;
+    auto PW = [&](int j, double v) { if (pr && valid) pr[j] = v; };
+
+    // ---- phase 0: per-chain scalars -------------------------------------------------------------
+    if (tid < NC) {
+        const double rinf_raw = exp(TH(0)), induc_raw = exp(TH(1));
+        sc[S_RINF * NC + c] = 100.0 * rinf_raw;
+        sc[S_INDUC * NC + c] = induc_raw * P.induc_scale;
+        for (int j = 0; j < 4; ++j) sc[(S_SRES + j) * NC + c] = 0.05 * exp(TH(P.o_err + j));
+        for (int b = 0; b < P.nblocks; ++b)
+            for (int i = 0; i < 3; ++i) sc[(S_D0 + 3 * b + i) * NC + c] = exp(TH(P.blk[b].o_d + i));
+        sc[S_LP * NC + c] = 0.0;
+        sc[S_XSUM * NC + c] = 0.0;
+        sc[S_REJ * NC + c] = 0.0;
+    }
+    for (int i = tid; i < P.ZR * NC; i += NT) Zh[i] = 0.0;
+    __syncthreads();
+
+    // ---- phase 1: Z_hat = sum_b (A_b x_b  or  1/(A_b x_b)) + offsets --------------------------------
+    for (int b = 0; b < P.nblocks; ++b) {
+        const DevBlock &B = P.blk[b];
+        double xsum[1] = {0.0};
+        for (int k = g; k < 8 * B.kpairs; k += NG) {
+            double x = 0.0;
+            if (k < B.K) {
+                const double t = TH(B.o_x + k);
+                const double xr = B.is_pos ? exp(t) : t;
+                xsum[0] += xr;
+                x = xr * B.x_scale;                       // xp = xp_raw * xp_scale (1 for series blocks)
+                PW(B.o_x + k, xr);
+            }
+            Xs[k * NC + c] = x;
+        }
+        if (P.use_x_sum) {
+            chain_reduce<1>(xsum, red, sc + S_TMP * NC, tid);
+            if (tid < NC) sc[S_XSUM * NC + c] += sc[S_TMP * NC + c];
+        }
+        __syncthreads();
+        gemm_forward(B.Af, B.tilesA, B.kpairs, Xs, Lr, wave, lane);     // T = A_b x_b  (in the Lr buffer)
+        __syncthreads();
+        for (int n = g; n < nf; n += NG) {
+            const double yr = Lr[n * NC + c], yi = Lr[(nf + n) * NC + c];
+            if (!B.is_parallel) {
+                Zh[n * NC + c] += yr;
+                Zh[(nf + n) * NC + c] += yi;
+            } else {
+                double *Y = Yp + (size_t)B.yp_slot * P.ZR * NC;
+                Y[n * NC + c] = yr;
+                Y[(nf + n) * NC + c] = yi;
+                const double dn = yr * yr + yi * yi;
+                Zh[n * NC + c] += yr / dn;                // Z_hat_p (Parallel_modelcode.txt:47)
+                Zh[(nf + n) * NC + c] += -yi / dn;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 2: likelihood Z ~ normal(Z_hat, sigma_tot); g_Zhat in place --------------------------
+    {
+        const double Rinf = sc[S_RINF * NC + c], induc = sc[S_INDUC * NC + c];
+        const double s_res = sc[S_SRES * NC + c], a_p = sc[S_AP * NC + c], a_r = sc[S_AR * NC + c],
+                     a_i = sc[S_AI * NC + c];
+        const double c0 = P.sigma_min * P.sigma_min + s_res * s_res;
+        const double ap2 = a_p * a_p, ar2 = a_r * a_r, ai2 = a_i * a_i;
+        const int sp = io.spec ? io.spec[cc] : 0;
+        const double *Zm = P.Z + (size_t)sp * N2;
+        double acc[7] = {0, 0, 0, 0, 0, 0, 0};   // lp, S_R, S_L, S_h, S_hz2, S_hzr2, S_hzi2
+        for (int n = g; n < nf; n += NG) {
+            const double wn = P.w[n];
+            const double zr = Zh[n * NC + c] + Rinf;
+            const double zi = Zh[(nf + n) * NC + c] + induc * wn;
+            double so_re = 0.0, so_im = 0.0, r0 = 0.0, r1 = 0.0;
+            if (P.outlier_mode) {
+                r0 = exp(TH(P.o_so + n));
+                r1 = exp(TH(P.o_so + nf + n));
+                PW(P.o_so + n, r0); PW(P.o_so + nf + n, r1);
+                if (P.outlier_mode == 1) so_re = so_im = 0.05 * r0 * r1;
+                else { so_re = 0.05 * r0; so_im = 0.05 * r1; }
+            }
+            const double common = ar2 * zr * zr + ai2 * zi * zi;
+            const double s2_re = c0 + ap2 * zr * zr + common + so_re * so_re;
+            const double s2_im = c0 + ap2 * zi * zi + common + so_im * so_im;
+            const double e_re = Zm[n] - zr, e_im = Zm[nf + n] - zi;
+            const double w_re = 1.0 / s2_re, w_im = 1.0 / s2_im;
+            acc[0] += -0.5 * log(s2_re) - 0.5 * e_re * e_re * w_re - 0.5 * log(s2_im) - 0.5 * e_im * e_im * w_im;
+            const double h_re = -0.5 * w_re + 0.5 * e_re * e_re * w_re * w_re;
+            const double h_im = -0.5 * w_im + 0.5 * e_im * e_im * w_im * w_im;
+            const double gzr = e_re * w_re + 2.0 * zr * (h_re * (ap2 + ar2) + h_im * ar2);
+            const double gzi = e_im * w_im + 2.0 * zi * (h_im * (ap2 + ai2) + h_re * ai2);
+            Zh[n * NC + c] = gzr;
+            Zh[(nf + n) * NC + c] = gzi;
+            acc[1] += gzr;
+            acc[2] += gzi * wn;
+            acc[3] += h_re + h_im;
+            acc[4] += h_re * zr * zr + h_im * zi * zi;
+            acc[5] += (h_re + h_im) * zr * zr;
+            acc[6] += (h_re + h_im) * zi * zi;
+            if (io.Z_hat && valid) { io.Z_hat[(size_t)c * N2 + n] = zr; io.Z_hat[(size_t)c * N2 + nf + n] = zi; }
+            if (io.sigma_tot && valid) {
+                io.sigma_tot[(size_t)c * N2 + n] = sqrt(s2_re);
+                io.sigma_tot[(size_t)c * N2 + nf + n] = sqrt(s2_im);
+            }
+            if (P.outlier_mode == 1) {
+                // sigma_out = raw .* scale * 0.05 ; raw ~ exponential(lambda) ; scale ~ inv_gamma(alpha, beta)
+                const double dso = 2.0 * so_re * (h_re + h_im);
+                GW(P.o_so + n, r0 * (0.05 * r1 * dso - P.so_lambda) + jac);
+                GW(P.o_so + nf + n, 0.05 * r0 * r1 * dso - (P.so_alpha + 1.0) + P.so_beta / r1 + jac);
+                acc[0] += -P.so_lambda * r0 - (P.so_alpha + 1.0) * TH(P.o_so + nf + n) - P.so_beta / r1 +
+                          jac * (TH(P.o_so + n) + TH(P.o_so + nf + n));
+            } else if (P.outlier_mode == 2) {
+                GW(P.o_so + n, r0 * (0.05 * 2.0 * so_re * h_re - P.so_lambda) + jac);
+                GW(P.o_so + nf + n, r1 * (0.05 * 2.0 * so_im * h_im - P.so_lambda) + jac);
+                acc[0] += -P.so_lambda * (r0 + r1) + jac * (TH(P.o_so + n) + TH(P.o_so + nf + n));
+            }
+        }
+        chain_reduce<7>(acc, red, sc + S_TMP * NC, tid);
+        if (tid < NC) {
+            const double *S = sc + S_TMP * NC;
+            const double t0 = TH(0), t1 = TH(1);
+            const double rinf_raw = exp(t0), induc_raw = exp(t1);
+            double lp = S[0 * NC + c];
+            // Rinf_raw, induc_raw ~ std_normal(); lower=0 -> log transform
+            GW(0, rinf_raw * (100.0 * S[1 * NC + c] - rinf_raw) + jac);
+            GW(1, induc_raw * (P.induc_scale * S[2 * NC + c] - induc_raw) + jac);
+            lp += -0.5 * rinf_raw * rinf_raw - 0.5 * induc_raw * induc_raw + jac * (t0 + t1);
+            PW(0, rinf_raw); PW(1, induc_raw);
+            const double sums[4] = {S[3 * NC + c], S[4 * NC + c], S[5 * NC + c], S[6 * NC + c]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double t = TH(P.o_err + j);
+                const double raw = exp(t);
+                const double val = 0.05 * raw;            // sigma_res, alpha_prop, alpha_re, alpha_im
+                GW(P.o_err + j, raw * (0.05 * 2.0 * val * sums[j] - raw) + jac);
+                lp += -0.5 * raw * raw + jac * t;
+                PW(P.o_err + j, raw);
+            }
+            if (P.use_x_sum) {
+                const double xs_raw = sc[S_XSUM * NC + c];
+                const double xs = xs_raw * P.x_sum_invscale;
+                lp += -0.5 * xs * xs;                     // x_sum ~ std_normal()
+                if (xs_raw < 0.0) sc[S_REJ * NC + c] = 1.0;   // real<lower=0> x_sum_raw
+            }
+            sc[S_LP * NC + c] += lp;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 3: per block: q-prior, ups prior, back-propagation ------------------------------------
+    for (int b = 0; b < P.nblocks; ++b) {
+        const DevBlock &B = P.blk[b];
+        const int K = B.K;
+        for (int k = g; k < 8 * B.kpairs; k += NG) {
+            double x = 0.0;
+            if (k < K) { const double t = TH(B.o_x + k); x = B.is_pos ? exp(t) : t; }
+            Xs[k * NC + c] = x;                           // raw x: q uses L * x_raw (Series-Parallel_modelcode.txt:55)
+        }
+        __syncthreads();
+        gemm_forward(B.Lf, B.tilesL, B.kpairs, Xs, Lr, wave, lane);     // v = [L0 x; L1 x; L2 x]
+        __syncthreads();
+        for (int k = g; k < K; k += NG) Xs[k * NC + c] = 0.15 * exp(TH(B.o_ups + k));   // ups = ups_raw*0.15
+        __syncthreads();
+        {
+            const double d0 = sc[(S_D0 + 3 * b + 0) * NC + c], d1 = sc[(S_D0 + 3 * b + 1) * NC + c],
+                         d2 = sc[(S_D0 + 3 * b + 2) * NC + c];
+            double acc[4] = {0, 0, 0, 0};                 // lp, Sv0, Sv1, Sv2
+            for (int k = g; k < K; k += NG) {
+                const double u = Xs[k * NC + c];
+                const double iu2 = 1.0 / (u * u);
+                const double v0 = Lr[k * NC + c], v1 = Lr[(K + k) * NC + c], v2 = Lr[(2 * K + k) * NC + c];
+                const double q2 = d0 * v0 * v0 + d1 * v1 * v1 + d2 * v2 * v2;
+                const double t = TH(B.o_ups + k);
+                const double r = u / 0.15;
+                // q ~ normal(0, ups) evaluated on q^2; ups_raw ~ inv_gamma(alpha, beta); log transform
+                acc[0] += -(t + LOG_015) - 0.5 * q2 * iu2 - (P.ups_alpha + 1.0) * t - P.ups_beta / r + jac * t;
+                acc[1] += v0 * v0 * iu2; acc[2] += v1 * v1 * iu2; acc[3] += v2 * v2 * iu2;
+                double gu = -1.0 / u + q2 * iu2 / u;
+                // dups[k] = 0.5*(ups[k+1] - 0.5*(ups[k]+ups[k+2]))/ups[k+1] ~ std_normal()
+                if (k >= 1 && k + 1 < K) {
+                    const double um = Xs[(k - 1) * NC + c], up = Xs[(k + 1) * NC + c];
+                    const double du = 0.5 * (u - 0.5 * (um + up)) / u;
+                    acc[0] += -0.5 * du * du;
+                    gu += -du * 0.25 * (um + up) * iu2;
+                }
+                if (k >= 2) {                             // k is the right neighbour of centre k-1
+                    const double u0 = Xs[(k - 1) * NC + c], um = Xs[(k - 2) * NC + c];
+                    const double du = 0.5 * (u0 - 0.5 * (um + u)) / u0;
+                    gu += du * 0.25 / u0;
+                }
+                if (k + 2 < K) {                          // k is the left neighbour of centre k+1
+                    const double u0 = Xs[(k + 1) * NC + c], up = Xs[(k + 2) * NC + c];
+                    const double du = 0.5 * (u0 - 0.5 * (u + up)) / u0;
+                    gu += du * 0.25 / u0;
+                }
+                GW(B.o_ups + k, u * gu - (P.ups_alpha + 1.0) + P.ups_beta / r + jac);
+                PW(B.o_ups + k, r);
+                Lr[k * NC + c] = -d0 * v0 * iu2;
+                Lr[(K + k) * NC + c] = -d1 * v1 * iu2;
+                Lr[(2 * K + k) * NC + c] = -d2 * v2 * iu2;
+            }
+            // rows 3K .. 8*rpairsL of the reduction must be exactly zero
+            for (int r = 3 * K + g; r < 8 * B.rpairsL; r += NG) Lr[r * NC + c] = 0.0;
+            if (B.is_parallel) {
+                // chain through Z_hat_p = conj(Y)/|Y|^2 : g_Y = J^T g_Z
+                double *Y = Yp + (size_t)B.yp_slot * P.ZR * NC;
+                for (int n = g; n < nf; n += NG) {
+                    const double yr = Y[n * NC + c], yi = Y[(nf + n) * NC + c];
+                    const double dn = yr * yr + yi * yi, id2 = 1.0 / (dn * dn);
+                    const double dd = (yi * yi - yr * yr) * id2, doff = 2.0 * yr * yi * id2;
+                    const double gzr = Zh[n * NC + c], gzi = Zh[(nf + n) * NC + c];
+                    Y[n * NC + c] = (gzr * dd + gzi * doff) * B.x_scale;      // xp = xp_raw * xp_scale
+                    Y[(nf + n) * NC + c] = (-gzr * doff + gzi * dd) * B.x_scale;
+                }
+                for (int r = N2 + g; r < P.ZR; r += NG) Y[r * NC + c] = 0.0;
+            }
+            chain_reduce<4>(acc, red, sc + S_TMP * NC, tid);
+            if (tid < NC) {
+                const double *S = sc + S_TMP * NC;
+                double lp = S[0 * NC + c];
+                const double dd[3] = {d0, d1, d2};
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {             // d ~ inv_gamma(5,5), log transform
+                    const double t = TH(B.o_d + i);
+                    GW(B.o_d + i, -0.5 * dd[i] * S[(1 + i) * NC + c] - 6.0 + 5.0 / dd[i] + jac);
+                    lp += -6.0 * t - 5.0 / dd[i] + jac * t;
+                    PW(B.o_d + i, dd[i]);
+                }
+                sc[S_LP * NC + c] += lp;
+            }
+        }
+        __syncthreads();
+        const double *Ra = B.is_parallel ? Yp + (size_t)B.yp_slot * P.ZR * NC : Zh;
+        gemm_backward(B.Bk, B.tilesK, B.rpairsA, B.rpairsL, Ra, Lr, Xs, wave, lane);
+        __syncthreads();
+        if (gr) {
+            const double xs_term = P.use_x_sum ? -sc[S_XSUM * NC + c] * P.x_sum_invscale * P.x_sum_invscale : 0.0;
+            double lpj[1] = {0.0};
+            for (int k = g; k < K; k += NG) {
+                const double graw = Xs[k * NC + c] + xs_term;
+                if (B.is_pos) {
+                    const double t = TH(B.o_x + k);
+                    GW(B.o_x + k, exp(t) * graw + jac);
+                    lpj[0] += jac * t;
+                } else {
+                    GW(B.o_x + k, graw);
+                }
+            }
+            if (io.jacobian && B.is_pos) {
+                chain_reduce<1>(lpj, red, sc + S_TMP * NC, tid);
+                if (tid < NC) sc[S_LP * NC + c] += sc[S_TMP * NC + c];
+            }
+        } else if (io.jacobian && B.is_pos) {
+            double lpj[1] = {0.0};
+            for (int k = g; k < K; k += NG) lpj[0] += TH(B.o_x + k);
+            chain_reduce<1>(lpj, red, sc + S_TMP * NC, tid);
+            if (tid < NC) sc[S_LP * NC + c] += sc[S_TMP * NC + c];
+        }
+        __syncthreads();
+    }
+
+    if (tid < NC && io.lp && valid) {
+        double lp = sc[S_LP * NC + c];
+        if (sc[S_REJ * NC + c] != 0.0) lp = -INFINITY;
+        io.lp[c] = lp;
+    }
+    __syncthreads();
+}
+
+}  // namespace bdrt

@@ -1,0 +1,52 @@
+// bdrt_host.h -- host-side objects shared by the translation units of libbdrt.so
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/bdrt.h"
+#include "bdrt_device.h"
+
+namespace bdrt {
+
+void set_error(const char *fmt, ...);
+
+#define BDRT_HIP(call)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            bdrt::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -10;                                                                             \
+        }                                                                                           \
+    } while (0)
+
+struct Problem {
+    DevProblem dev;                 // device view (pointers are device pointers)
+    std::vector<void *> allocs;     // owned device allocations
+    std::vector<unsigned char> is_pos;
+    hipStream_t stream = nullptr;
+    size_t lds_bytes = 0;
+    int device = 0;
+    double *d_Z = nullptr;
+    size_t z_capacity = 0;          // doubles
+    // host copies of the layout
+    int o_x[MAXB], o_ups[MAXB], o_d[MAXB];
+    // scratch buffers for host-pointer entry points (grown on demand)
+    double *d_theta = nullptr, *d_grad = nullptr, *d_lp = nullptr;
+    int *d_spec = nullptr;
+    size_t scratch_rows = 0;
+    int ensure_scratch(size_t rows);
+};
+
+// launch the batched evaluator on device buffers (theta/grad [B x D] row-major)
+int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
+                     double *d_grad, double *d_params, double *d_Zhat, double *d_sig, hipStream_t stream);
+
+}  // namespace bdrt
+
+struct bdrt_problem {
+    bdrt::Problem impl;
+};

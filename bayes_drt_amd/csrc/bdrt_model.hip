@@ -1,0 +1,339 @@
+// bdrt_model.hip -- problem object (Stan `data` block in HBM, matrices packed into MFMA fragment order),
+// the batched log-posterior + gradient kernel, and their C ABI (include/bdrt.h section (2)).
+//
+// Replaces: pystan's log_prob/grad_log_prob evaluation of bayes_drt/stan_model_files/*_modelcode.txt
+// (reference bayes_drt/inversion.py:1216-1221).
+#include <cmath>
+#include <cstring>
+
+#include "bdrt_host.h"
+
+namespace bdrt {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// element (tile t, pair p, lane l, h) = M[16 t + (l & 15)][8 p + 4 h + (l >> 4)], zero outside [R x C]
+template <class F>
+static std::vector<double> pack_fragments(int tiles, int pairs, F elem)
+{
+    std::vector<double> out((size_t)tiles * pairs * 128, 0.0);
+    for (int t = 0; t < tiles; ++t)
+        for (int p = 0; p < pairs; ++p)
+            for (int l = 0; l < 64; ++l)
+                for (int h = 0; h < 2; ++h)
+                    out[(((size_t)t * pairs + p) * 64 + l) * 2 + h] = elem(16 * t + (l & 15), 8 * p + 4 * h + (l >> 4));
+    return out;
+}
+
+template <class T>
+static int upload(Problem &P, const std::vector<T> &h, const T **dptr)
+{
+    void *d = nullptr;
+    BDRT_HIP(hipMalloc(&d, h.size() * sizeof(T) + 16));
+    BDRT_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    P.allocs.push_back(d);
+    *dptr = (const T *)d;
+    return 0;
+}
+
+int Problem::ensure_scratch(size_t rows)
+{
+    if (rows <= scratch_rows) return 0;
+    size_t n = rows < 64 ? 64 : rows;
+    if (d_theta) { hipFree(d_theta); hipFree(d_grad); hipFree(d_lp); hipFree(d_spec); }
+    BDRT_HIP(hipMalloc((void **)&d_theta, n * dev.D * sizeof(double)));
+    BDRT_HIP(hipMalloc((void **)&d_grad, n * dev.D * sizeof(double)));
+    BDRT_HIP(hipMalloc((void **)&d_lp, n * sizeof(double)));
+    BDRT_HIP(hipMalloc((void **)&d_spec, n * sizeof(int)));
+    scratch_rows = n;
+    return 0;
+}
+
+static int build_problem(Problem &P, const bdrt_dat *dat)
+{
+    if (!dat || dat->nf <= 0 || dat->nblocks < 1 || dat->nblocks > MAXB) {
+        set_error("bdrt_problem_create: invalid nf/nblocks");
+        return -1;
+    }
+    if (dat->n_spectra < 1 || !dat->Z || !dat->freq) {
+        set_error("bdrt_problem_create: Z/freq missing or n_spectra < 1");
+        return -1;
+    }
+    BDRT_HIP(hipGetDevice(&P.device));
+    DevProblem &D = P.dev;
+    memset(&D, 0, sizeof(D));
+    const int nf = dat->nf, N2 = 2 * nf;
+    D.nf = nf;
+    D.nblocks = dat->nblocks;
+    D.outlier_mode = dat->outlier_mode;
+    D.use_x_sum = dat->use_x_sum;
+    D.sigma_min = dat->sigma_min;
+    D.ups_alpha = dat->ups_alpha;
+    D.ups_beta = dat->ups_beta;
+    D.induc_scale = dat->induc_scale;
+    D.so_lambda = dat->so_lambda;
+    D.so_alpha = dat->so_alpha;
+    D.so_beta = dat->so_beta;
+    D.x_sum_invscale = dat->x_sum_invscale;
+
+    // parameter layout = Stan declaration order (see include/bdrt.h)
+    int o = 2;
+    for (int b = 0; b < dat->nblocks; ++b) { P.o_x[b] = o; o += dat->K[b]; }
+    D.o_err = o; o += 4;
+    D.o_so = o;
+    if (dat->outlier_mode) o += 2 * nf;
+    for (int b = 0; b < dat->nblocks; ++b) { P.o_ups[b] = o; o += dat->K[b]; }
+    for (int b = 0; b < dat->nblocks; ++b) { P.o_d[b] = o; o += 3; }
+    D.D = o;
+    P.is_pos.assign((size_t)o, 1);
+    for (int b = 0; b < dat->nblocks; ++b)
+        if (!dat->is_parallel[b] && !dat->nonneg[b])
+            for (int k = 0; k < dat->K[b]; ++k) P.is_pos[P.o_x[b] + k] = 0;
+
+    int XR = 0, LR = 0, npar = 0;
+    const int rpairsA = cdiv(N2, 8), tilesA = cdiv(N2, 16);
+    for (int b = 0; b < dat->nblocks; ++b) {
+        const int K = dat->K[b];
+        if (K < 3 || !dat->A[b] || !dat->L0[b] || !dat->L1[b] || !dat->L2[b]) {
+            set_error("bdrt_problem_create: block %d: K < 3 or missing matrix", b);
+            return -1;
+        }
+        DevBlock &B = D.blk[b];
+        B.K = K;
+        B.is_parallel = dat->is_parallel[b] ? 1 : 0;
+        B.is_pos = (dat->is_parallel[b] || dat->nonneg[b]) ? 1 : 0;
+        B.x_scale = dat->is_parallel[b] ? dat->x_scale[b] : 1.0;
+        B.tilesA = tilesA;
+        B.tilesL = cdiv(3 * K, 16);
+        B.tilesK = cdiv(K, 16);
+        B.kpairs = cdiv(K, 8);
+        B.rpairsA = rpairsA;
+        B.rpairsL = cdiv(3 * K, 8);
+        B.o_x = P.o_x[b]; B.o_ups = P.o_ups[b]; B.o_d = P.o_d[b];
+        B.yp_slot = B.is_parallel ? npar++ : 0;
+        const double *A = dat->A[b];
+        const double *Ls[3] = {dat->L0[b], dat->L1[b], dat->L2[b]};
+        auto Aelem = [&](int r, int k) -> double { return (r < N2 && k < K) ? A[(size_t)r * K + k] : 0.0; };
+        auto Lelem = [&](int r, int k) -> double {
+            return (r < 3 * K && k < K) ? Ls[r / K][(size_t)(r % K) * K + k] : 0.0;
+        };
+        const int ra8 = 8 * rpairsA;
+        auto Telem = [&](int k, int r) -> double { return r < ra8 ? Aelem(r, k) : Lelem(r - ra8, k); };
+        int rc;
+        if ((rc = upload(P, pack_fragments(B.tilesA, B.kpairs, Aelem), &B.Af))) return rc;
+        if ((rc = upload(P, pack_fragments(B.tilesL, B.kpairs, Lelem), &B.Lf))) return rc;
+        if ((rc = upload(P, pack_fragments(B.tilesK, B.rpairsA + B.rpairsL, Telem), &B.Bk))) return rc;
+        XR = std::max(XR, std::max(8 * B.kpairs, 16 * B.tilesK));
+        LR = std::max(LR, std::max(16 * B.tilesL, 16 * B.tilesA));
+    }
+    D.XR = XR;
+    D.ZR = 8 * rpairsA;
+    D.LR = LR;
+    D.npar = npar;
+    P.lds_bytes = lds_doubles(D) * sizeof(double);
+    if (P.lds_bytes > 160 * 1024) {
+        set_error("bdrt_problem_create: problem needs %zu B of LDS per workgroup (> 160 KiB): nf=%d, K too large",
+                  P.lds_bytes, nf);
+        return -2;
+    }
+    std::vector<double> w(nf);
+    for (int n = 0; n < nf; ++n) w[n] = 2.0 * M_PI * dat->freq[n];
+    int rc;
+    if ((rc = upload(P, w, &D.w))) return rc;
+    BDRT_HIP(hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
+    D.n_spectra = 0;
+    return 0;
+}
+
+static int set_Z(Problem &P, const double *Z, int n_spectra)
+{
+    const size_t need = (size_t)n_spectra * 2 * P.dev.nf;
+    if (need > P.z_capacity) {
+        if (P.d_Z) hipFree(P.d_Z);
+        BDRT_HIP(hipMalloc((void **)&P.d_Z, need * sizeof(double)));
+        P.z_capacity = need;
+    }
+    BDRT_HIP(hipMemcpy(P.d_Z, Z, need * sizeof(double), hipMemcpyHostToDevice));
+    P.dev.Z = P.d_Z;
+    P.dev.n_spectra = n_spectra;
+    return 0;
+}
+
+__global__ __launch_bounds__(NT) void logp_grad_kernel(DevProblem P, const double *theta, const int *spec, int B,
+                                                       int jacobian, double *lp, double *grad, double *params,
+                                                       double *Zhat, double *sig)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int c0 = blockIdx.x * NC;
+    TileIO io;
+    io.theta = theta + (size_t)c0 * P.D;
+    io.t_sc = P.D; io.t_sj = 1;
+    io.grad = grad ? grad + (size_t)c0 * P.D : nullptr;
+    io.g_sc = P.D; io.g_sj = 1;
+    io.lp = lp ? lp + c0 : nullptr;
+    io.spec = spec ? spec + c0 : nullptr;
+    io.nvalid = min(NC, B - c0);
+    io.jacobian = jacobian;
+    io.Z_hat = Zhat ? Zhat + (size_t)c0 * 2 * P.nf : nullptr;
+    io.sigma_tot = sig ? sig + (size_t)c0 * 2 * P.nf : nullptr;
+    io.params = params ? params + (size_t)c0 * P.D : nullptr;
+    logp_grad_tile(P, io, smem);
+}
+
+int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
+                     double *d_grad, double *d_params, double *d_Zhat, double *d_sig, hipStream_t stream)
+{
+    if (B <= 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+        attr_set = true;
+    }
+    const int grid = cdiv(B, NC);
+    hipLaunchKernelGGL(logp_grad_kernel, dim3(grid), dim3(NT), p->lds_bytes, stream, p->dev, d_theta, d_spec, B,
+                       jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
+    BDRT_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace bdrt
+
+using namespace bdrt;
+
+extern "C" {
+
+const char *bdrt_last_error(void) { return g_last_error.c_str(); }
+const char *bdrt_version(void) { return "bdrt-mi355x 0.1 (gfx950)"; }
+
+int bdrt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bdrt_set_device(int dev)
+{
+    BDRT_HIP(hipSetDevice(dev));
+    return 0;
+}
+
+bdrt_problem *bdrt_problem_create(const bdrt_dat *dat)
+{
+    bdrt_problem *p = new bdrt_problem();
+    int rc = build_problem(p->impl, dat);
+    if (rc == 0) rc = set_Z(p->impl, dat->Z, dat->n_spectra);
+    if (rc != 0) {
+        bdrt_problem_destroy(p);
+        return nullptr;
+    }
+    return p;
+}
+
+void bdrt_problem_destroy(bdrt_problem *p)
+{
+    if (!p) return;
+    Problem &P = p->impl;
+    for (void *d : P.allocs) hipFree(d);
+    if (P.d_Z) hipFree(P.d_Z);
+    if (P.d_theta) { hipFree(P.d_theta); hipFree(P.d_grad); hipFree(P.d_lp); hipFree(P.d_spec); }
+    if (P.stream) hipStreamDestroy(P.stream);
+    delete p;
+}
+
+int bdrt_num_params(const bdrt_problem *p) { return p ? p->impl.dev.D : -1; }
+
+int bdrt_param_is_pos(const bdrt_problem *p, unsigned char *is_pos)
+{
+    if (!p || !is_pos) return -1;
+    memcpy(is_pos, p->impl.is_pos.data(), p->impl.is_pos.size());
+    return 0;
+}
+
+int bdrt_problem_set_Z(bdrt_problem *p, const double *Z, int n_spectra)
+{
+    if (!p || !Z || n_spectra < 1) { set_error("bdrt_problem_set_Z: bad arguments"); return -1; }
+    BDRT_HIP(hipStreamSynchronize(p->impl.stream));
+    return set_Z(p->impl, Z, n_spectra);
+}
+
+static int check_spec(Problem &P, const int *spec, int B)
+{
+    if (!spec) return 0;
+    for (int i = 0; i < B; ++i)
+        if (spec[i] < 0 || spec[i] >= P.dev.n_spectra) {
+            set_error("spectrum index %d out of range [0,%d) at row %d", spec[i], P.dev.n_spectra, i);
+            return -1;
+        }
+    return 0;
+}
+
+int bdrt_logp_grad_dev(bdrt_problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
+                       double *d_grad, void *stream)
+{
+    if (!p || !d_theta) { set_error("bdrt_logp_grad_dev: null argument"); return -1; }
+    return launch_logp_grad(&p->impl, d_theta, d_spec, B, jacobian, d_lp, d_grad, nullptr, nullptr, nullptr,
+                            stream ? (hipStream_t)stream : p->impl.stream);
+}
+
+int bdrt_logp_grad(bdrt_problem *p, const double *theta, const int *spec, int B, int jacobian, double *lp, double *grad)
+{
+    if (!p || !theta || B < 0) { set_error("bdrt_logp_grad: bad arguments"); return -1; }
+    if (B == 0) return 0;
+    Problem &P = p->impl;
+    int rc;
+    if ((rc = check_spec(P, spec, B))) return rc;
+    if ((rc = P.ensure_scratch((size_t)B))) return rc;
+    const size_t nb = (size_t)B * P.dev.D * sizeof(double);
+    BDRT_HIP(hipMemcpyAsync(P.d_theta, theta, nb, hipMemcpyHostToDevice, P.stream));
+    if (spec) BDRT_HIP(hipMemcpyAsync(P.d_spec, spec, (size_t)B * sizeof(int), hipMemcpyHostToDevice, P.stream));
+    if ((rc = launch_logp_grad(&P, P.d_theta, spec ? P.d_spec : nullptr, B, jacobian, P.d_lp, grad ? P.d_grad : nullptr,
+                               nullptr, nullptr, nullptr, P.stream)))
+        return rc;
+    if (lp) BDRT_HIP(hipMemcpyAsync(lp, P.d_lp, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, P.stream));
+    if (grad) BDRT_HIP(hipMemcpyAsync(grad, P.d_grad, nb, hipMemcpyDeviceToHost, P.stream));
+    BDRT_HIP(hipStreamSynchronize(P.stream));
+    return 0;
+}
+
+int bdrt_transformed(bdrt_problem *p, const double *theta, const int *spec, int B, double *params, double *Z_hat,
+                     double *sigma_tot)
+{
+    if (!p || !theta || B < 0) { set_error("bdrt_transformed: bad arguments"); return -1; }
+    if (B == 0) return 0;
+    Problem &P = p->impl;
+    int rc;
+    if ((rc = check_spec(P, spec, B))) return rc;
+    if ((rc = P.ensure_scratch((size_t)B))) return rc;
+    const size_t nb = (size_t)B * P.dev.D * sizeof(double), nz = (size_t)B * 2 * P.dev.nf * sizeof(double);
+    double *d_par = nullptr, *d_zh = nullptr, *d_sg = nullptr;
+    BDRT_HIP(hipMalloc((void **)&d_par, nb));
+    BDRT_HIP(hipMalloc((void **)&d_zh, nz));
+    BDRT_HIP(hipMalloc((void **)&d_sg, nz));
+    BDRT_HIP(hipMemcpyAsync(P.d_theta, theta, nb, hipMemcpyHostToDevice, P.stream));
+    if (spec) BDRT_HIP(hipMemcpyAsync(P.d_spec, spec, (size_t)B * sizeof(int), hipMemcpyHostToDevice, P.stream));
+    rc = launch_logp_grad(&P, P.d_theta, spec ? P.d_spec : nullptr, B, 0, P.d_lp, nullptr, d_par, d_zh, d_sg, P.stream);
+    if (rc == 0) {
+        if (params) hipMemcpyAsync(params, d_par, nb, hipMemcpyDeviceToHost, P.stream);
+        if (Z_hat) hipMemcpyAsync(Z_hat, d_zh, nz, hipMemcpyDeviceToHost, P.stream);
+        if (sigma_tot) hipMemcpyAsync(sigma_tot, d_sg, nz, hipMemcpyDeviceToHost, P.stream);
+        if (hipStreamSynchronize(P.stream) != hipSuccess) { set_error("bdrt_transformed: sync failed"); rc = -10; }
+    }
+    hipFree(d_par); hipFree(d_zh); hipFree(d_sg);
+    return rc;
+}
+
+}  // extern "C"

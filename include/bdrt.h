@@ -1,0 +1,194 @@
+/*
+ * bdrt.h -- C ABI of libbdrt.so, the MI355X (gfx950) hot path of bayes-drt.
+ *
+ * The reference (jdhuang-csm/bayes-drt) has no FFI: its hot path is reached from Python through three
+ * internal seams of bayes_drt.inversion.Inverter:
+ *   (1) construct_A / construct_L / construct_M          bayes_drt/matrices.py:120, :268, :366
+ *   (2) StanModel.optimizing / StanModel.sampling        bayes_drt/inversion.py:1216, :1218-1221 (pystan 2.19.1.1)
+ *   (3) cvxopt.solvers.qp via Inverter._convex_opt       bayes_drt/inversion.py:1043-1067
+ * Each entry point below replaces one of those calls; the ctypes binding a maintainer would add is shown
+ * in INTEGRATION.md and implemented in bayes_drt_amd/_lib.py.
+ *
+ * Conventions: all arrays are C-contiguous fp64 unless stated; the caller owns every buffer passed in;
+ * the library copies inputs to HBM at bdrt_problem_create and owns device memory until bdrt_problem_destroy.
+ * Functions return 0 on success, a negative code on error (text via bdrt_last_error()).  A non-finite or
+ * rejected log-density is NOT an error: lp = -inf for that row.
+ * Host-pointer entry points move data over PCIe; the *_dev entry points take device pointers (HBM-resident
+ * inputs) and a hipStream_t (passed as void*).
+ */
+#ifndef BDRT_H
+#define BDRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDRT_MAX_BLOCKS 3
+
+/* integrand ids: bayes_drt/matrices.py:27-117 get_A_func */
+enum {
+    BDRT_KERNEL_DRT = 0,              /* matrices.py:45-52 */
+    BDRT_KERNEL_DDT_BLOCK_PLANAR = 1, /* matrices.py:59-70 */
+    BDRT_KERNEL_DDT_BLOCK_SPHER = 2,  /* matrices.py:72-80 */
+    BDRT_KERNEL_DDT_TRANS_PLANAR = 3  /* matrices.py:83-92 */
+};
+
+/* ---- (1) matrix construction ------------------------------------------------------------------ */
+
+/* replaces construct_A (matrices.py:120-265).  out: [nf x k] row-major.  part 0=real 1=imag.
+ * dist_series: 1 integrate Z_D, 0 integrate 1/Z_D (DDT).  toeplitz=1: first column + first row only
+ * (matrices.py:213-242), returns -2 if r[0]!=c[0] (matrices.py:239-241). */
+int bdrt_build_A(const double *freq, int nf, const double *tau, int k, double eps, int kernel_id, int part,
+                 int dist_series, int use_ct, double k_ct, int toeplitz, double *out);
+/* replaces construct_L (matrices.py:268-325); coef4 weights derivative orders 0..3.  out: [k x k] */
+int bdrt_build_L(const double *tau, int k, double eps, const double *coef4, double *out);
+/* replaces construct_M (matrices.py:366-411); coef3 weights orders 0..2.  out: [k x k] */
+int bdrt_build_M(const double *tau, int k, double eps, const double *coef3, int toeplitz, double *out);
+
+/* ---- (2) the Stan model: data block, log-posterior + gradient, optimizing, sampling -------------- */
+
+/* The Stan `data` block of the model families in bayes_drt/stan_model_files/ (SURVEY.md 8(a) S1-S6),
+ * as assembled by Inverter._prep_stan_data (inversion.py:1684-2122), written as "blocks":
+ *   Series(_pos)            1 series block                         Series_modelcode.txt
+ *   Parallel                1 parallel block, use_x_sum=0          Parallel_modelcode.txt
+ *   Series-Parallel(_pos)   series + 1 parallel, use_x_sum=1       Series-Parallel_modelcode.txt
+ *   Series-2Parallel(_pos)  series + 2 parallel, use_x_sum=1       Series-2Parallel_modelcode.txt
+ *   *_outliers              outlier_mode 1 (Series: raw[nf],scale[nf]) or 2 (stacked raw[2nf])
+ * Parameter order = Stan declaration order: Rinf_raw, induc_raw, x blocks, sigma_res_raw, alpha_prop_raw,
+ * alpha_re_raw, alpha_im_raw, [sigma_out_raw(, sigma_out_scale)], ups blocks, (d0,d1,d2) blocks. */
+typedef struct {
+    int nf;                                /* measured frequencies (Stan N/2)                          */
+    int nblocks;
+    int K[BDRT_MAX_BLOCKS];
+    int is_parallel[BDRT_MAX_BLOCKS];
+    int nonneg[BDRT_MAX_BLOCKS];           /* vector<lower=0> x (parallel blocks are always lower=0)   */
+    double x_scale[BDRT_MAX_BLOCKS];       /* xp_scale                                                 */
+    const double *A[BDRT_MAX_BLOCKS];      /* [2nf x K] stacked [A_re ; A_im]                          */
+    const double *L0[BDRT_MAX_BLOCKS];     /* [K x K], mode-scaled as in inversion.py:1725-1737        */
+    const double *L1[BDRT_MAX_BLOCKS];
+    const double *L2[BDRT_MAX_BLOCKS];
+    const double *freq;                    /* [nf]                                                     */
+    int n_spectra;                         /* spectra sharing the grids (multi-spectrum batch)         */
+    const double *Z;                       /* [n_spectra x 2nf] stacked [Z' ; Z''] per spectrum        */
+    double sigma_min, ups_alpha, ups_beta, induc_scale;
+    int outlier_mode;
+    double so_lambda, so_alpha, so_beta;
+    int use_x_sum;
+    double x_sum_invscale;
+} bdrt_dat;
+
+typedef struct bdrt_problem bdrt_problem;
+
+bdrt_problem *bdrt_problem_create(const bdrt_dat *dat);   /* NULL on error */
+void bdrt_problem_destroy(bdrt_problem *p);
+int bdrt_num_params(const bdrt_problem *p);               /* D: length of the unconstrained vector */
+/* is_pos[D]: 1 where the Stan parameter is declared <lower=0> (log transform) */
+int bdrt_param_is_pos(const bdrt_problem *p, unsigned char *is_pos);
+/* replace the measured spectra of an existing problem (same grids): Z [n_spectra x 2nf] */
+int bdrt_problem_set_Z(bdrt_problem *p, const double *Z, int n_spectra);
+
+/* log_prob + gradient on the unconstrained scale for B points (Stan's log_prob_grad, evaluated by pystan
+ * inside optimizing/sampling: inversion.py:1216-1221).  theta [B x D]; spec[B] selects the spectrum of each
+ * row (NULL: all 0); jacobian 1 = sampling, 0 = optimizing; lp [B]; grad [B x D]. */
+int bdrt_logp_grad(bdrt_problem *p, const double *theta, const int *spec, int B, int jacobian, double *lp,
+                   double *grad);
+/* same with device pointers (inputs already in HBM); stream = hipStream_t */
+int bdrt_logp_grad_dev(bdrt_problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
+                       double *d_grad, void *stream);
+/* constrained parameters + transformed parameters (Stan `transformed parameters` block) for B points:
+ * params [B x D] (constrained), Z_hat [B x 2nf], sigma_tot [B x 2nf]; any output may be NULL */
+int bdrt_transformed(bdrt_problem *p, const double *theta, const int *spec, int B, double *params, double *Z_hat,
+                     double *sigma_tot);
+
+/* replaces StanModel.optimizing (inversion.py:1216): L-BFGS on the unconstrained scale, no Jacobian.
+ * One optimisation per row of init (n_fits rows, spectrum spec[i]); every log_prob+grad is evaluated on the GPU. */
+typedef struct {
+    int max_iter;           /* Stan `iter` (inversion.py:1077: 50000)   */
+    int history;            /* 5                                         */
+    double init_alpha;      /* 1e-3                                      */
+    double tol_obj;         /* 1e-12                                     */
+    double tol_rel_obj;     /* 1e4  (x machine eps)                      */
+    double tol_grad;        /* 1e-8                                      */
+    double tol_rel_grad;    /* 1e7  (x machine eps)                      */
+    double tol_param;       /* 1e-8                                      */
+} bdrt_opt_options;
+typedef struct {
+    int iterations;
+    int n_evals;
+    int return_code;        /* 0 converged, 1 max_iter, <0 failure       */
+    double lp;
+    double grad_norm;
+} bdrt_opt_report;
+void bdrt_opt_defaults(bdrt_opt_options *o);
+int bdrt_optimize(bdrt_problem *p, const double *init_theta, const int *spec, int n_fits, const bdrt_opt_options *opts,
+                  double *theta_out, bdrt_opt_report *reports);
+
+/* replaces StanModel.sampling (inversion.py:1218-1221): NUTS, diagonal metric, Stan-2.19 style adaptation.
+ * The whole transition loop runs on the GPU (one workgroup per 16 chains); the host only relaunches. */
+typedef struct {
+    double adapt_delta;     /* 0.9  (inversion.py:1221)                  */
+    double adapt_t0;        /* 10   (inversion.py:1221)                  */
+    double adapt_gamma;     /* 0.05                                      */
+    double adapt_kappa;     /* 0.75                                      */
+    int max_treedepth;      /* 10                                        */
+    int init_buffer;        /* 75                                        */
+    int term_buffer;        /* 50                                        */
+    int base_window;        /* 25                                        */
+    double init_radius;     /* 2: U(-2,2) on the unconstrained scale     */
+    double max_deltaH;      /* 1000                                      */
+    double stepsize0;       /* 1                                         */
+} bdrt_nuts_control;
+typedef struct {
+    int64_t n_leapfrog;     /* log_prob+grad evaluations (leapfrogs)     */
+    int n_divergent;        /* post-warm-up                              */
+    int n_max_treedepth;    /* post-warm-up iterations that hit the cap  */
+    double stepsize;        /* adapted step size                         */
+    double mean_accept;     /* mean accept_stat post-warm-up             */
+} bdrt_chain_diag;
+void bdrt_nuts_defaults(bdrt_nuts_control *c);
+
+typedef struct bdrt_sampler bdrt_sampler;
+/* n_units chains; unit u samples spectrum spec[u] (NULL: 0) with RNG stream (seed, chain_id[u]) (NULL: u);
+ * init_theta [n_units x D] or NULL (random U(-r,r), retried until finite).  */
+bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec, const int *chain_id, int warmup,
+                                  int n_draws, uint64_t seed, const double *init_theta, const bdrt_nuts_control *ctrl);
+void bdrt_sampler_destroy(bdrt_sampler *s);
+/* advance every unfinished chain by at most `rounds` leapfrogs (one launch, asynchronous on `stream`);
+ * *all_done is set when every chain has produced warmup+n_draws iterations (requires a sync: pass NULL to skip) */
+int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done);
+int bdrt_sampler_sync(bdrt_sampler *s);
+/* run to completion */
+int bdrt_sampler_run(bdrt_sampler *s);
+/* draws [n_units x n_draws x D] unconstrained; diag [n_units]; either may be NULL */
+int bdrt_sampler_results(bdrt_sampler *s, double *draws_unconstrained, double *lp, bdrt_chain_diag *diag);
+/* total leapfrogs executed so far, summed over chains (device counter) */
+int64_t bdrt_sampler_total_leapfrogs(bdrt_sampler *s);
+/* HIP-event time (ms) and launch count of the NUTS kernel accumulated since creation / last reset */
+int bdrt_sampler_kernel_time(bdrt_sampler *s, double *ms_total, int64_t *n_launches, int reset);
+/* convenience: create + run + results.  draws [n_units x n_draws x D] */
+int bdrt_sample(bdrt_problem *p, int n_units, const int *spec, const int *chain_id, int warmup, int n_draws,
+                uint64_t seed, const double *init_theta, const bdrt_nuts_control *ctrl, double *draws, double *lp,
+                bdrt_chain_diag *diag);
+
+/* ---- (3) ridge: Gram matrices and the box-constrained QP (replaces _convex_opt, inversion.py:1043-1067) -- */
+/* P = WA_re^T WA_re + WA_im^T WA_im + L2mat ; q = -(WA_re^T WZ_re + WA_im^T WZ_im) + L1vec  (inversion.py:1045-1052)
+ * WA [2nf x n] stacked; WZ [2nf]; P [n x n]; q [n]  */
+int bdrt_gram(const double *WA, const double *WZ, int nrows, int n, const double *L2mat, const double *L1vec, double *P,
+              double *q);
+/* min 1/2 x^T P x + q^T x  s.t. x >= lo (lo[i] = -inf allowed): primal-dual interior point with cvxopt-like
+ * tolerances (abstol 1e-7, reltol 1e-6, feastol 1e-7).  Returns iterations (>=0) or <0. */
+int bdrt_qp_box(const double *P, const double *q, const double *lo, int n, double *x, double *primal_objective);
+
+/* ---- misc ----------------------------------------------------------------------------------------- */
+const char *bdrt_last_error(void);
+int bdrt_device_count(void);
+int bdrt_set_device(int dev);
+const char *bdrt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,143 @@
+"""GPU parity (-m gpu): HIP log-posterior + gradient (libbdrt.so via the C ABI) vs the CPU oracle.
+
+fp64 tolerance: the two sides sum the same products in different orders (MFMA k-blocked vs sequential), so
+lp agrees to ~1e-13 relative; asserted: |lp - lp_ref| <= 1e-10 * max(1, |lp_ref|) and
+max|g - g_ref| <= 1e-10 * max(1, max|g_ref|).
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import kat_names, kat_to_model, load
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from bayes_drt_amd.model import Problem
+    from oracle import oracle as orc
+    return Problem, orc
+
+
+def _compare(prob, om, thetas, jac, spec=None, oms=None):
+    lp, g = prob.logp_grad(thetas, jacobian=jac, spec=spec)
+    for i, th in enumerate(thetas):
+        m = om if oms is None else oms[spec[i]]
+        lp_ref, g_ref = m.logp_grad(th, jacobian=jac)
+        if not np.isfinite(lp_ref):
+            assert lp[i] == lp_ref
+            continue
+        assert abs(lp[i] - lp_ref) <= 1e-10 * max(1.0, abs(lp_ref)), (i, lp[i], lp_ref)
+        err = np.max(np.abs(g[i] - g_ref))
+        assert err <= 1e-10 * max(1.0, np.max(np.abs(g_ref))), (i, err, int(np.argmax(np.abs(g[i] - g_ref))))
+
+
+def _bench_blocks(mode='sample', tag='K161'):
+    d = load('dat_%s_2ZARC_uniform_0.25_%s' % (mode, tag))
+    blk = dict(A=d['A'], L0=d['L0'], L1=d['L1'], L2=d['L2'], nonneg=True)
+    kw = dict(sigma_min=float(d['sigma_min']), ups_alpha=float(d['ups_alpha']), ups_beta=float(d['ups_beta']),
+              induc_scale=float(d['induc_scale']))
+    return d, blk, kw
+
+
+@pytest.mark.parametrize('mode', ['sample', 'optimize'])
+@pytest.mark.parametrize('B', [1, 5, 16, 33])
+def test_benchmark_shape_vs_oracle(mode, B):
+    Problem, orc = _mods()
+    d, blk, kw = _bench_blocks(mode)
+    prob = Problem([blk], d['Z'], d['freq'], **kw)
+    om = orc.OracleModel([blk], d['Z'], d['freq'], **kw)
+    assert prob.D == om.D == 331
+    rng = np.random.default_rng(B)
+    thetas = rng.uniform(-2, 2, (B, prob.D))
+    _compare(prob, om, thetas, mode == 'sample')
+    _compare(prob, om, thetas, mode != 'sample')
+
+
+def test_signed_x_series():
+    Problem, orc = _mods()
+    d, blk, kw = _bench_blocks('sample', 'K81')
+    blk = dict(blk, nonneg=False)
+    prob = Problem([blk], d['Z'], d['freq'], **kw)
+    om = orc.OracleModel([blk], d['Z'], d['freq'], **kw)
+    rng = np.random.default_rng(3)
+    _compare(prob, om, rng.uniform(-2, 2, (7, prob.D)), True)
+
+
+def test_multi_spectrum_batch():
+    Problem, orc = _mods()
+    d, blk, kw = _bench_blocks('sample')
+    rng = np.random.default_rng(11)
+    Zs = np.stack([d['Z'] * (1 + 0.05 * s) + 0.01 * rng.standard_normal(len(d['Z'])) for s in range(5)])
+    prob = Problem([blk], Zs, d['freq'], **kw)
+    oms = [orc.OracleModel([blk], Zs[s], d['freq'], **kw) for s in range(5)]
+    spec = rng.integers(0, 5, 40).astype(np.int32)
+    thetas = rng.uniform(-2, 2, (40, prob.D))
+    _compare(prob, None, thetas, True, spec=spec, oms=oms)
+    with pytest.raises(Exception):
+        prob.logp_grad(thetas[:2], spec=np.array([0, 5], dtype=np.int32))
+
+
+@pytest.mark.parametrize('name', ['RC-ZARC_uniform_0.25', 'trunc_uniform_0.25', 'LIB_data', 'PDAC_outliers',
+                                  'DRT-2-TpDDT_uniform_0.25', 'PDAC_DRT-TpDDT_outliers',
+                                  'DRT-TpDDT-BpDDT_uniform_0.25'])
+def test_model_families_vs_oracle(name):
+    """Series, Series_pos, old Series_outliers (stacked), Series-Parallel_pos (+outliers), Series-2Parallel_pos at the
+    reference's stored MAP points and at perturbed points."""
+    Problem, orc = _mods()
+    k = kat_to_model(name)
+    assert k is not None
+    kw = dict(k['kw'])
+    rng = np.random.default_rng(5)
+    if not k['has_Z']:
+        kw['Z'] = np.asarray(k['opt']['Z_hat']).ravel() + 0.01 * rng.standard_normal(len(kw['Z']))
+    if kw['use_x_sum']:
+        kw['x_sum_invscale'] = 0.3
+    prob = Problem(**kw)
+    om = orc.OracleModel(**kw)
+    assert prob.D == om.D
+    th0 = om.unconstrain(k['params'])
+    thetas = np.stack([th0] + [th0 + 0.1 * rng.standard_normal(om.D) for _ in range(4)])
+    for jac in (False, True):
+        _compare(prob, om, thetas, jac)
+    # transformed parameters vs the stored Stan outputs (KAT through the GPU path)
+    params, Zh, sg = prob.transformed(th0[None])
+    np.testing.assert_allclose(params[0], k['params'], rtol=1e-12)
+    ref = np.asarray(k['opt']['Z_hat']).ravel()
+    assert np.max(np.abs(Zh[0] - ref)) <= 1e-11 * np.max(np.abs(ref))
+    ref = np.asarray(k['opt']['sigma_tot']).ravel()
+    assert np.max(np.abs(sg[0] - ref)) <= 1e-11 * np.max(np.abs(ref))
+
+
+def test_outlier_mode1_and_parallel_only():
+    Problem, orc = _mods()
+    d, blk, kw = _bench_blocks('sample', 'K81')
+    so = load('dat_sample_outlier_scalars')
+    kw1 = dict(kw, outlier_mode=1, so_lambda=float(so['sigma_out_lambda']), so_alpha=float(so['sigma_out_alpha']),
+               so_beta=float(so['sigma_out_beta']))
+    prob = Problem([blk], d['Z'], d['freq'], **kw1)
+    om = orc.OracleModel([blk], d['Z'], d['freq'], **kw1)
+    rng = np.random.default_rng(8)
+    _compare(prob, om, rng.uniform(-1, 1, (9, prob.D)), True)
+    # Parallel model (Parallel_modelcode.txt): a single parallel block built from the DDT golden matrices
+    dd = load('ddt_toeplitz_81x161')
+    A = np.vstack([dd['A_re_tp_parallel'], dd['A_im_tp_parallel']])
+    m161 = load('mat_drt_81x161')
+    blkp = dict(A=A, L0=m161['L0'], L1=m161['L1'], L2=0.75 * m161['L2'], parallel=True, x_scale=1.0)
+    Zy = 1.0 / (d['Z'][:81] + 1j * d['Z'][81:])
+    Zp = np.concatenate([Zy.real, Zy.imag]) * 0 + d['Z']
+    prob = Problem([blkp], Zp, d['freq'], use_x_sum=False, **kw)
+    om = orc.OracleModel([blkp], Zp, d['freq'], use_x_sum=False, **kw)
+    _compare(prob, om, rng.uniform(-2, 0, (6, prob.D)), True)
+
+
+def test_x_sum_rejection_flag():
+    Problem, orc = _mods()
+    k = kat_to_model('DRT-2-TpDDT_uniform_0.25')
+    kw = dict(k['kw']); kw['blocks'] = [dict(b) for b in kw['blocks']]
+    kw['blocks'][0]['nonneg'] = False
+    prob = Problem(**kw)
+    p = k['params'].copy()
+    lay = prob.layout()
+    p[lay['x'][0]:lay['x'][0] + prob.Ks[0]] = -10.0
+    lp, g = prob.logp_grad(prob.unconstrain(p)[None], jacobian=True)
+    assert lp[0] == -np.inf
