@@ -48,7 +48,9 @@ def test_ddt_toeplitz_vs_golden(tag, dt):
     f, tau, eps = d['freq'], d['tau'], float(d['epsilon'])
     bc, sym = DDT[tag]
     A = [gm.construct_A(f, p, tau=tau, epsilon=eps, kernel='DDT', dist_type=dt, symmetry=sym, bc=bc) for p in ('real', 'imag')]
-    _cmp_complex(A[0], A[1], d['A_re_%s_%s' % (tag, dt)], d['A_im_%s_%s' % (tag, dt)])
+    # blocking-spherical: tanh x/(x - tanh x) cancels catastrophically for |x| << 1 in the reference itself
+    # (x - tanh x ~ x^3/3): two correct fp64 evaluations differ by ~eps/|x|^2, hence the looser bound
+    _cmp_complex(A[0], A[1], d['A_re_%s_%s' % (tag, dt)], d['A_im_%s_%s' % (tag, dt)], tol=1e-6 if tag == 'bs' else 1e-11)
 
 
 @pytest.mark.parametrize('tag', ['tp', 'bp', 'bs'])
@@ -61,7 +63,8 @@ def test_ddt_general_vs_golden(tag, ct):
     for dt in ('parallel', 'series'):
         A = [gm.construct_A(f, p, tau=tau, epsilon=eps, kernel='DDT', dist_type=dt, symmetry=sym, bc=bc, ct=bool(ct),
                             k_ct=float(d['k_ct']) if ct else None) for p in ('real', 'imag')]
-        _cmp_complex(A[0], A[1], d['A_re_%s_%s_ct%d' % (tag, dt, ct)], d['A_im_%s_%s_ct%d' % (tag, dt, ct)])
+        _cmp_complex(A[0], A[1], d['A_re_%s_%s_ct%d' % (tag, dt, ct)], d['A_im_%s_%s_ct%d' % (tag, dt, ct)],
+                     tol=1e-6 if tag == 'bs' else 1e-11)
 
 
 def test_full_size_general_path_vs_toeplitz():

@@ -18,7 +18,7 @@ def _mods():
     return Problem, orc
 
 
-def _compare(prob, om, thetas, jac, spec=None, oms=None):
+def _compare(prob, om, thetas, jac, spec=None, oms=None, gtol=1e-10):
     lp, g = prob.logp_grad(thetas, jacobian=jac, spec=spec)
     for i, th in enumerate(thetas):
         m = om if oms is None else oms[spec[i]]
@@ -28,7 +28,7 @@ def _compare(prob, om, thetas, jac, spec=None, oms=None):
             continue
         assert abs(lp[i] - lp_ref) <= 1e-10 * max(1.0, abs(lp_ref)), (i, lp[i], lp_ref)
         err = np.max(np.abs(g[i] - g_ref))
-        assert err <= 1e-10 * max(1.0, np.max(np.abs(g_ref))), (i, err, int(np.argmax(np.abs(g[i] - g_ref))))
+        assert err <= gtol * max(1.0, np.max(np.abs(g_ref))), (i, err, int(np.argmax(np.abs(g[i] - g_ref))))
 
 
 def _bench_blocks(mode='sample', tag='K161'):
@@ -98,7 +98,9 @@ def test_model_families_vs_oracle(name):
     th0 = om.unconstrain(k['params'])
     thetas = np.stack([th0] + [th0 + 0.1 * rng.standard_normal(om.D) for _ in range(4)])
     for jac in (False, True):
-        _compare(prob, om, thetas, jac)
+        # at the stored MAPs the gradient is a near-total cancellation of O(1e4) terms (e.g. 100*sum(g_Zhat) for
+        # Rinf_raw): the summation-order noise floor is ~1e-9 absolute, hence the looser bound here
+        _compare(prob, om, thetas, jac, gtol=1e-8)
     # transformed parameters vs the stored Stan outputs (KAT through the GPU path)
     params, Zh, sg = prob.transformed(th0[None])
     np.testing.assert_allclose(params[0], k['params'], rtol=1e-12)
