@@ -3,6 +3,7 @@
 //
 // Replaces: pystan's log_prob/grad_log_prob evaluation of bayes_drt/stan_model_files/*_modelcode.txt
 // (reference bayes_drt/inversion.py:1216-1221).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -140,7 +141,7 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
     }
     D.XR = XR;
     D.ZR = 8 * rpairsA;
-    D.LR = LR;
+    D.LR = std::max(LR, MIN_LR);
     D.npar = npar;
     P.lds_bytes = lds_doubles(D) * sizeof(double);
     if (P.lds_bytes > 160 * 1024) {

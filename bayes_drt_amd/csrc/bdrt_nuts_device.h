@@ -1,2 +1,155 @@
-// placeholder (NUTS device code follows)
+// bdrt_nuts_device.h -- counter-based RNG and the per-chain NUTS bookkeeping shared by the NUTS kernel.
+//
+// The sampler being replaced is Stan 2.19.1's adapt_diag_e_nuts as driven by pystan's `sampling`
+// (reference call site bayes_drt/inversion.py:1218-1221; behaviour: SURVEY.md Appendix A).  Stan's own RNG
+// stream cannot be reproduced (boost::ecuyer1988 inside the absent pystan), so randomness is a counter-based
+// Philox4x32-10 keyed by (seed, chain id) and indexed by (iteration, tree depth, leaf, purpose): every draw is
+// a pure function of those, which makes results independent of how chains are packed into workgroups / GPUs.
 #pragma once
+#include <stdint.h>
+
+namespace bdrt {
+
+// purposes (counter word 1, low byte)
+enum { RNG_INIT = 1, RNG_MOMENTUM = 2, RNG_DIRECTION = 3, RNG_LEAF = 4, RNG_TOP = 5, RNG_EPS_MOMENTUM = 6 };
+
+struct Philox {
+    uint32_t k0, k1, chain;
+};
+
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4])
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// two uniforms in (0,1) from one Philox block; counter = (index, purpose | depth<<8 | trial<<16, iteration, chain)
+__host__ __device__ inline void rng_uniform2(const Philox &g, uint32_t index, uint32_t purpose, uint32_t depth,
+                                             uint32_t trial, uint32_t iter, double &u0, double &u1)
+{
+    uint32_t o[4];
+    philox4x32_10(index, purpose | (depth << 8) | (trial << 16), iter, g.chain, g.k0, g.k1, o);
+    const uint64_t a = ((uint64_t)o[0] << 32) | o[1], b = ((uint64_t)o[2] << 32) | o[3];
+    u0 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    u1 = ((double)(b >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+__host__ __device__ inline double rng_uniform(const Philox &g, uint32_t index, uint32_t purpose, uint32_t depth,
+                                              uint32_t trial, uint32_t iter)
+{
+    double u0, u1;
+    rng_uniform2(g, index, purpose, depth, trial, iter, u0, u1);
+    return u0;
+}
+
+// standard normal number `j` of a stream: Box-Muller on block j/2, cosine branch for even j, sine for odd j
+__host__ __device__ inline double rng_normal(const Philox &g, uint32_t j, uint32_t purpose, uint32_t trial,
+                                             uint32_t iter)
+{
+    double u0, u1;
+    rng_uniform2(g, j >> 1, purpose, 0, trial, iter, u0, u1);
+    const double r = sqrt(-2.0 * log(u0));
+    const double a = 6.283185307179586476925286766559 * u1;
+    return (j & 1) ? r * sin(a) : r * cos(a);
+}
+
+__host__ __device__ inline double log_sum_exp2(double a, double b)
+{
+    if (a == -INFINITY) return b;
+    if (b == -INFINITY) return a;
+    return a > b ? a + log1p(exp(b - a)) : b + log1p(exp(a - b));
+}
+
+// chain phases
+enum { PH_INIT = 0, PH_EPS = 1, PH_TREE = 2, PH_DONE = 3, PH_FAILED = 4 };
+
+// per-chain scalar state, one struct per chain in global memory (host reads it back for diagnostics)
+struct ChainState {
+    int phase;
+    int iter;             // completed iterations (warm-up + sampling)
+    int depth;            // current tree depth (doublings completed)
+    int leaf, nleaves;    // position inside the subtree being built
+    int dir;              // +1 / -1
+    int init_attempt;
+    int eps_dir, eps_trials;
+    int n_leap_iter;      // leapfrogs in the current iteration
+    int da_counter;
+    int win_counter, win_size, next_window, win_n;
+    int init_buffer, term_buffer, base_window;
+    int n_div, n_maxdepth, n_post;
+    int spec, chain_id;
+    int pad_;
+    double eps;           // nominal step size
+    double H0, lsw, lsw_sub, lps, lpq, sum_metro;
+    double da_sbar, da_xbar, da_mu;
+    double sum_accept;
+    long long n_leap_total;
+};
+
+struct NutsParams {
+    int warmup, n_draws, max_depth;
+    double delta, gamma, t0, kappa, init_radius, max_deltaH, stepsize0;
+    uint32_t seed_lo, seed_hi;
+    int has_init;
+};
+
+// Stan's windowed_adaptation schedule (stan/mcmc/windowed_adaptation.hpp)
+__host__ __device__ inline void window_init(ChainState &s, int warmup, int init_buffer, int term_buffer, int base_window)
+{
+    if (warmup < 20) {                       // no metric adaptation at all
+        init_buffer = warmup; term_buffer = 0; base_window = 0;
+    } else if (init_buffer + base_window + term_buffer > warmup) {
+        init_buffer = (int)(0.15 * warmup);
+        term_buffer = (int)(0.1 * warmup);
+        base_window = warmup - (init_buffer + term_buffer);
+    }
+    s.init_buffer = init_buffer; s.term_buffer = term_buffer; s.base_window = base_window;
+    s.win_counter = 0;
+    s.win_size = base_window;
+    s.next_window = init_buffer + base_window - 1;
+    s.win_n = 0;
+}
+__host__ __device__ inline bool window_active(const ChainState &s, int warmup)
+{
+    return s.win_counter >= s.init_buffer && s.win_counter < warmup - s.term_buffer && s.win_counter != warmup;
+}
+__host__ __device__ inline bool window_end(const ChainState &s, int warmup)
+{
+    return s.win_counter == s.next_window && s.win_counter != warmup;
+}
+__host__ __device__ inline void window_next(ChainState &s, int warmup)
+{
+    if (s.next_window == warmup - s.term_buffer - 1) return;
+    s.win_size *= 2;
+    s.next_window = s.win_counter + s.win_size;
+    if (s.next_window == warmup - s.term_buffer - 1) return;
+    const int boundary = s.next_window + 2 * s.win_size;
+    if (boundary >= warmup - s.term_buffer) s.next_window = warmup - s.term_buffer - 1;
+}
+
+// Stan's stepsize_adaptation::learn_stepsize (dual averaging)
+__host__ __device__ inline void da_restart(ChainState &s) { s.da_counter = 0; s.da_sbar = 0.0; s.da_xbar = 0.0; }
+__host__ __device__ inline void da_learn(ChainState &s, const NutsParams &np, double accept)
+{
+    s.da_counter += 1;
+    accept = accept > 1.0 ? 1.0 : accept;
+    const double eta = 1.0 / (s.da_counter + np.t0);
+    s.da_sbar = (1.0 - eta) * s.da_sbar + eta * (np.delta - accept);
+    const double x = s.da_mu - s.da_sbar * sqrt((double)s.da_counter) / np.gamma;
+    const double x_eta = pow((double)s.da_counter, -np.kappa);
+    s.da_xbar = (1.0 - x_eta) * s.da_xbar + x_eta * x;
+    s.eps = exp(x);
+}
+
+}  // namespace bdrt

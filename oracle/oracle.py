@@ -230,3 +230,65 @@ def construct_M(tau, epsilon, order):
     toep = is_loguniform(1 / (2 * np.pi * tau))
     lib().orc_build_M(_p(tau), len(tau), C.c_double(epsilon), _p(_order_coefs(order, 3)), int(toep), _p(out))
     return out
+
+
+# ------------------------------------------------------------------------------------------ NUTS oracle
+class NutsControl(C.Structure):
+    _fields_ = [('adapt_delta', C.c_double), ('adapt_t0', C.c_double), ('adapt_gamma', C.c_double),
+                ('adapt_kappa', C.c_double), ('max_treedepth', C.c_int), ('init_buffer', C.c_int),
+                ('term_buffer', C.c_int), ('base_window', C.c_int), ('init_radius', C.c_double),
+                ('max_deltaH', C.c_double), ('stepsize0', C.c_double)]
+
+
+class ChainDiag(C.Structure):
+    _fields_ = [('n_leapfrog', C.c_longlong), ('n_divergent', C.c_int), ('n_max_treedepth', C.c_int),
+                ('stepsize', C.c_double), ('mean_accept', C.c_double)]
+
+
+def nuts_control(**kw):
+    c = NutsControl()
+    lib().orc_nuts_defaults(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _diag_dict(d):
+    return dict(n_leapfrog=d.n_leapfrog, n_divergent=d.n_divergent, n_max_treedepth=d.n_max_treedepth,
+                stepsize=d.stepsize, mean_accept=d.mean_accept)
+
+
+def nuts_sample(model, chain_id, seed, warmup, n_draws, init_theta=None, control=None):
+    """One chain of the recursive CPU NUTS on an OracleModel.  Returns (draws [n_draws x D], lp, diag)."""
+    ctrl = control if control is not None else nuts_control()
+    draws = np.empty((n_draws, model.D)); lp = np.empty(n_draws)
+    diag = ChainDiag()
+    init = _f64(init_theta) if init_theta is not None else None
+    fn = lib().orc_nuts_sample
+    fn.restype = C.c_int
+    rc = fn(C.byref(model.m), int(chain_id), C.c_uint64(seed), int(warmup), int(n_draws),
+            _p(init) if init is not None else None, C.byref(ctrl), _p(draws), _p(lp), C.byref(diag))
+    if rc != 0:
+        raise RuntimeError('orc_nuts_sample failed (no finite initial point)')
+    return draws, lp, _diag_dict(diag)
+
+
+def nuts_sample_gauss(mu, sd, chain_id, seed, warmup, n_draws, control=None):
+    """Known-answer target N(mu, diag(sd^2)) through the same sampler."""
+    mu = _f64(mu); sd = _f64(sd)
+    desc = np.concatenate([[float(len(mu))], mu, sd])
+    ctrl = control if control is not None else nuts_control()
+    draws = np.empty((n_draws, len(mu)))
+    diag = ChainDiag()
+    fn = lib().orc_nuts_sample_gauss
+    fn.restype = C.c_int
+    rc = fn(_p(desc), int(chain_id), C.c_uint64(seed), int(warmup), int(n_draws), C.byref(ctrl), _p(draws),
+            C.byref(diag))
+    assert rc == 0
+    return draws, _diag_dict(diag)
+
+
+def eval_loop(model, theta0, n, jacobian=True):
+    fn = lib().orc_eval_loop
+    fn.restype = C.c_double
+    return fn(C.byref(model.m), _p(_f64(theta0)), int(n), int(jacobian))
