@@ -35,12 +35,13 @@ class Dat(C.Structure):
 class OptOptions(C.Structure):
     _fields_ = [('max_iter', C.c_int), ('history', C.c_int), ('init_alpha', C.c_double), ('tol_obj', C.c_double),
                 ('tol_rel_obj', C.c_double), ('tol_grad', C.c_double), ('tol_rel_grad', C.c_double),
-                ('tol_param', C.c_double)]
+                ('tol_param', C.c_double), ('newton_max_iter', C.c_int), ('lbfgs_before_newton', C.c_int),
+                ('newton_tol', C.c_double)]
 
 
 class OptReport(C.Structure):
     _fields_ = [('iterations', C.c_int), ('n_evals', C.c_int), ('return_code', C.c_int), ('lp', C.c_double),
-                ('grad_norm', C.c_double)]
+                ('grad_norm', C.c_double), ('newton_iterations', C.c_int), ('grad_inf', C.c_double)]
 
 
 class NutsControl(C.Structure):

@@ -16,8 +16,21 @@
 
 #include "bdrt_host.h"
 #include "bdrt_lbfgs.h"
+#include "bdrt_newton.h"
 
 using namespace bdrt;
+
+namespace bdrt {
+
+struct FitDriver {
+    LbfgsFit L;
+    NewtonFit N;
+    int stage = 0;     // 0 L-BFGS, 1 Newton, 2 done
+    int nreq() const { return stage == 0 ? 1 : (stage == 1 ? N.n_requests() : 0); }
+    const double *req(int i) const { return stage == 0 ? L.trial() : N.request(i); }
+};
+
+}  // namespace bdrt
 
 extern "C" {
 
@@ -25,6 +38,7 @@ void bdrt_opt_defaults(bdrt_opt_options *o)
 {
     o->max_iter = 50000; o->history = 5; o->init_alpha = 1e-3; o->tol_obj = 1e-12; o->tol_rel_obj = 1e4;
     o->tol_grad = 1e-8; o->tol_rel_grad = 1e7; o->tol_param = 1e-8;
+    o->newton_max_iter = 400; o->lbfgs_before_newton = 1000; o->newton_tol = 1e-8;
 }
 
 int bdrt_optimize(bdrt_problem *p, const double *init_theta, const int *spec, int n_fits, const bdrt_opt_options *opts,
@@ -37,45 +51,90 @@ int bdrt_optimize(bdrt_problem *p, const double *init_theta, const int *spec, in
     const int D = P.dev.D;
     for (int i = 0; i < n_fits; ++i)
         if (spec && (spec[i] < 0 || spec[i] >= P.dev.n_spectra)) { set_error("bdrt_optimize: spectrum index out of range"); return -1; }
-    std::vector<LbfgsFit> fits((size_t)n_fits);
-    for (int i = 0; i < n_fits; ++i) fits[i].init(D, init_theta + (size_t)i * D, &o);
-    int rc;
-    if ((rc = P.ensure_scratch((size_t)n_fits))) return rc;
-    std::vector<double> h_theta((size_t)n_fits * D), h_grad((size_t)n_fits * D), h_lp((size_t)n_fits);
-    std::vector<int> h_spec((size_t)n_fits), active;
-    const long long max_rounds = (long long)o.max_iter * 70 + 100;
-    for (long long round = 0; round < max_rounds; ++round) {
-        active.clear();
-        for (int i = 0; i < n_fits; ++i)
-            if (fits[i].phase != LbfgsFit::DONE) active.push_back(i);
-        if (active.empty()) break;
-        const int B = (int)active.size();
-        for (int k = 0; k < B; ++k) {
-            memcpy(&h_theta[(size_t)k * D], fits[active[k]].trial(), D * sizeof(double));
-            h_spec[k] = spec ? spec[active[k]] : 0;
+    bdrt_opt_options ol = o;                          // L-BFGS phase
+    if (o.newton_max_iter > 0) ol.max_iter = std::min(o.max_iter, std::max(o.lbfgs_before_newton, 0));
+    std::vector<FitDriver> fits((size_t)n_fits);
+    for (int i = 0; i < n_fits; ++i) {
+        fits[i].L.init(D, init_theta + (size_t)i * D, &ol);
+        if (ol.max_iter <= 0) { fits[i].L.phase = LbfgsFit::DONE; }
+    }
+    auto advance_stage = [&](FitDriver &F) {
+        if (F.stage == 0 && F.L.phase == LbfgsFit::DONE) {
+            if (o.newton_max_iter > 0 && F.L.rc >= 0) { F.N.init(D, F.L.x.data(), o.newton_max_iter, o.newton_tol); F.stage = 1; }
+            else F.stage = 2;
         }
-        BDRT_HIP(hipMemcpyAsync(P.d_theta, h_theta.data(), (size_t)B * D * sizeof(double), hipMemcpyHostToDevice, P.stream));
-        BDRT_HIP(hipMemcpyAsync(P.d_spec, h_spec.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, P.stream));
-        if ((rc = launch_logp_grad(&P, P.d_theta, P.d_spec, B, /*jacobian=*/0, P.d_lp, P.d_grad, nullptr, nullptr,
-                                   nullptr, P.stream)))
-            return rc;
-        BDRT_HIP(hipMemcpyAsync(h_lp.data(), P.d_lp, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, P.stream));
-        BDRT_HIP(hipMemcpyAsync(h_grad.data(), P.d_grad, (size_t)B * D * sizeof(double), hipMemcpyDeviceToHost, P.stream));
-        BDRT_HIP(hipStreamSynchronize(P.stream));
-        for (int k = 0; k < B; ++k) {
-            LbfgsFit &F = fits[active[k]];
-            F.feed_any(h_lp[k], &h_grad[(size_t)k * D]);
+        if (F.stage == 1 && F.N.phase == NewtonFit::DONE) F.stage = 2;
+    };
+    for (auto &F : fits) advance_stage(F);
+
+    const size_t MAXCOLS = 16384;                      // columns per launch (PCIe staging bounded to ~45 MB each way)
+    int rc;
+    if ((rc = P.ensure_scratch(MAXCOLS))) return rc;
+    std::vector<double> h_theta(MAXCOLS * D), h_grad(MAXCOLS * D), h_lp(MAXCOLS);
+    std::vector<int> h_spec(MAXCOLS);
+    std::vector<double> fit_lp, fit_grad;             // per-fit assembly buffers for multi-request phases
+    const long long max_rounds = (long long)o.max_iter * 70 + (long long)o.newton_max_iter * 60 + 1000;
+    for (long long round = 0; round < max_rounds; ++round) {
+        // gather the requests of this round: list of (fit, request index)
+        std::vector<std::pair<int, int>> reqs;
+        for (int i = 0; i < n_fits; ++i) {
+            const int n = fits[i].nreq();
+            for (int k = 0; k < n; ++k) reqs.emplace_back(i, k);
+        }
+        if (reqs.empty()) break;
+        // results per fit (request order)
+        std::vector<size_t> off((size_t)n_fits + 1, 0);
+        for (int i = 0; i < n_fits; ++i) off[i + 1] = off[i] + (size_t)fits[i].nreq();
+        fit_lp.resize(reqs.size());
+        fit_grad.resize(reqs.size() * (size_t)D);
+        for (size_t base = 0; base < reqs.size(); base += MAXCOLS) {
+            const int B = (int)std::min(MAXCOLS, reqs.size() - base);
+            for (int k = 0; k < B; ++k) {
+                const auto &rq = reqs[base + k];
+                memcpy(&h_theta[(size_t)k * D], fits[rq.first].req(rq.second), D * sizeof(double));
+                h_spec[k] = spec ? spec[rq.first] : 0;
+            }
+            BDRT_HIP(hipMemcpyAsync(P.d_theta, h_theta.data(), (size_t)B * D * sizeof(double), hipMemcpyHostToDevice, P.stream));
+            BDRT_HIP(hipMemcpyAsync(P.d_spec, h_spec.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, P.stream));
+            if ((rc = launch_logp_grad(&P, P.d_theta, P.d_spec, B, /*jacobian=*/0, P.d_lp, P.d_grad, nullptr, nullptr,
+                                       nullptr, P.stream)))
+                return rc;
+            BDRT_HIP(hipMemcpyAsync(&fit_lp[base], P.d_lp, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, P.stream));
+            BDRT_HIP(hipMemcpyAsync(&fit_grad[base * D], P.d_grad, (size_t)B * D * sizeof(double), hipMemcpyDeviceToHost, P.stream));
+            BDRT_HIP(hipStreamSynchronize(P.stream));
+        }
+        for (int i = 0; i < n_fits; ++i) {
+            FitDriver &F = fits[i];
+            if (F.stage == 2) continue;
+            const double *lps = &fit_lp[off[i]];
+            const double *grs = &fit_grad[off[i] * D];
+            if (F.stage == 0) F.L.feed_any(lps[0], grs);
+            else F.N.consume(lps, grs);
+            advance_stage(F);
         }
     }
     for (int i = 0; i < n_fits; ++i) {
-        LbfgsFit &F = fits[i];
-        memcpy(theta_out + (size_t)i * D, F.x.data(), D * sizeof(double));
+        FitDriver &F = fits[i];
+        const bool newton = o.newton_max_iter > 0 && F.N.D == D;
+        const std::vector<double> &x = newton ? F.N.x : F.L.x;
+        memcpy(theta_out + (size_t)i * D, x.data(), D * sizeof(double));
         if (reports) {
-            reports[i].iterations = F.iters;
-            reports[i].n_evals = F.n_evals;
-            reports[i].return_code = F.phase == LbfgsFit::DONE ? F.rc : 1;
-            reports[i].lp = -F.f;
-            reports[i].grad_norm = std::sqrt(LbfgsFit::dot(F.g, F.g));
+            bdrt_opt_report &R = reports[i];
+            R.iterations = F.L.iters;
+            R.n_evals = F.L.n_evals + (newton ? F.N.n_evals : 0);
+            R.newton_iterations = newton ? F.N.iters : 0;
+            if (newton) {
+                R.return_code = F.N.phase == NewtonFit::DONE ? F.N.rc : 1;
+                R.lp = F.N.lp;
+                R.grad_norm = std::sqrt(LbfgsFit::dot(F.N.g, F.N.g));
+                R.grad_inf = F.N.grad_inf();
+            } else {
+                R.return_code = F.L.phase == LbfgsFit::DONE ? F.L.rc : 1;
+                R.lp = -F.L.f;
+                R.grad_norm = std::sqrt(LbfgsFit::dot(F.L.g, F.L.g));
+                double m = 0; for (double v : F.L.g) m = std::max(m, std::fabs(v));
+                R.grad_inf = m;
+            }
         }
     }
     return 0;

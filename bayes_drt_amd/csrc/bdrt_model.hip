@@ -197,11 +197,11 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
                      double *d_grad, double *d_params, double *d_Zhat, double *d_sig, hipStream_t stream)
 {
     if (B <= 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static size_t attr_bytes = 0;
+    if (p->lds_bytes > attr_bytes) {
         BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
-        attr_set = true;
+                                     (int)p->lds_bytes));
+        attr_bytes = p->lds_bytes;
     }
     const int grid = cdiv(B, NC);
     hipLaunchKernelGGL(logp_grad_kernel, dim3(grid), dim3(NT), p->lds_bytes, stream, p->dev, d_theta, d_spec, B,

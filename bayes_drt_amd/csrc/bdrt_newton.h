@@ -1,0 +1,177 @@
+// bdrt_newton.h -- second-order MAP polish (host-side state machine, no HIP dependency).
+//
+// Why it exists: the reference's MAP is an early-terminated L-BFGS(5) iterate of an extremely ill-conditioned
+// posterior: two fp64 evaluations of the same gradient that differ in the 13th digit send
+// L-BFGS down different paths within ~100 iterations and leave gamma(ln tau) 3-10 % apart after 50 000.  On the
+// GPU a full Hessian costs ONE launch (2 D central-difference gradient evaluations = 2 D columns of the batched MFMA
+// kernel), so the MAP can be driven to a true stationary point (|g|_inf ~ 1e-9) by a damped Newton iteration
+// (Levenberg-Marquardt on the unconstrained scale).  Measured: +39 nats over 50 000 L-BFGS iterations on the 2-ZARC
+// benchmark, and gamma reproducible to 1e-11 rel-L2 from different starts.
+//
+// The state machine asks its driver for batches of log_prob+grad evaluations:
+//   n_requests() / request(i)  -> points to evaluate (1 trial point, or 2 D Hessian probes)
+//   consume(lp[], grad[][])    -> results, in request order
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace bdrt {
+
+// in-place lower Cholesky of the symmetric n x n matrix a (row-major); false if not positive definite
+inline bool cholesky_lower(std::vector<double> &a, int n)
+{
+    for (int j = 0; j < n; ++j) {
+        double d = a[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= a[(size_t)j * n + k] * a[(size_t)j * n + k];
+        if (!(d > 0.0) || !std::isfinite(d)) return false;
+        d = std::sqrt(d);
+        a[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = a[(size_t)i * n + j];
+            const double *ri = &a[(size_t)i * n], *rj = &a[(size_t)j * n];
+            for (int k = 0; k < j; ++k) s -= ri[k] * rj[k];
+            a[(size_t)i * n + j] = s / d;
+        }
+    }
+    return true;
+}
+inline void cholesky_solve(const std::vector<double> &L, int n, std::vector<double> &b)
+{
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[(size_t)i * n + k] * b[k];
+        b[i] = s / L[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < n; ++k) s -= L[(size_t)k * n + i] * b[k];
+        b[i] = s / L[(size_t)i * n + i];
+    }
+}
+
+struct NewtonFit {
+    enum Phase { NEED_POINT, NEED_HESS, NEED_TRIAL, DONE };
+    int D = 0, max_iter = 300;
+    double tol = 1e-8;
+    Phase phase = NEED_POINT;
+    int iters = 0, n_evals = 0, rc = 1;       // rc: 0 converged, 1 iteration cap, 2 damping exhausted, -1 non-finite start
+    double lam = 1e-3, lp = 0.0;
+    std::vector<double> x, g, H, s, xt, hstep, probes, M;
+
+    void init(int D_, const double *x0, int max_iter_, double tol_)
+    {
+        D = D_; max_iter = max_iter_; tol = tol_;
+        x.assign(x0, x0 + D); g.assign(D, 0.0); s.assign(D, 0.0); xt = x; hstep.assign(D, 0.0);
+        H.assign((size_t)D * D, 0.0); M = H;
+        probes.assign((size_t)2 * D * D, 0.0);
+        phase = max_iter > 0 ? NEED_POINT : DONE;
+        if (max_iter <= 0) rc = 1;
+    }
+    double grad_inf() const
+    {
+        double m = 0;
+        for (double v : g) m = std::max(m, std::fabs(v));
+        return m;
+    }
+    int n_requests() const { return phase == NEED_HESS ? 2 * D : (phase == DONE ? 0 : 1); }
+    const double *request(int i) const
+    {
+        if (phase == NEED_POINT) return x.data();
+        if (phase == NEED_TRIAL) return xt.data();
+        return &probes[(size_t)i * D];
+    }
+    void make_probes()
+    {
+        for (int j = 0; j < D; ++j) {
+            hstep[j] = 1e-5 * std::max(1.0, std::fabs(x[j]));
+            double *pp = &probes[(size_t)(2 * j) * D], *pm = &probes[(size_t)(2 * j + 1) * D];
+            memcpy(pp, x.data(), sizeof(double) * D);
+            memcpy(pm, x.data(), sizeof(double) * D);
+            pp[j] += hstep[j];
+            pm[j] -= hstep[j];
+        }
+        phase = NEED_HESS;
+    }
+    // solve (-H + lam I) s = g, enlarging lam until positive definite; sets the trial point
+    bool make_trial()
+    {
+        while (lam <= 1e12) {
+            for (int i = 0; i < D; ++i)
+                for (int k = 0; k <= i; ++k) M[(size_t)i * D + k] = -H[(size_t)i * D + k] + (i == k ? lam : 0.0);
+            if (cholesky_lower(M, D)) {
+                s = g;
+                cholesky_solve(M, D, s);
+                bool fin = true;
+                for (int j = 0; j < D; ++j) { xt[j] = x[j] + s[j]; fin = fin && std::isfinite(xt[j]); }
+                if (fin) { phase = NEED_TRIAL; return true; }
+            }
+            lam *= 4.0;
+        }
+        rc = 2; phase = DONE;
+        return false;
+    }
+    // lp[i], grad[i*D..] in request order
+    void consume(const double *lps, const double *grads)
+    {
+        if (phase == NEED_POINT) {
+            n_evals += 1;
+            lp = lps[0];
+            memcpy(g.data(), grads, sizeof(double) * D);
+            bool fin = std::isfinite(lp);
+            for (int j = 0; j < D; ++j) fin = fin && std::isfinite(g[j]);
+            if (!fin) { rc = -1; phase = DONE; return; }
+            if (grad_inf() < tol) { rc = 0; phase = DONE; return; }
+            make_probes();
+            return;
+        }
+        if (phase == NEED_HESS) {
+            n_evals += 2 * D;
+            bool fin = true;
+            for (int j = 0; j < D; ++j) {
+                const double *gp = grads + (size_t)(2 * j) * D, *gm = grads + (size_t)(2 * j + 1) * D;
+                for (int k = 0; k < D; ++k) {
+                    const double v = (gp[k] - gm[k]) / (2.0 * hstep[j]);
+                    H[(size_t)j * D + k] = v;
+                    fin = fin && std::isfinite(v);
+                }
+            }
+            if (!fin) { rc = 2; phase = DONE; return; }
+            for (int j = 0; j < D; ++j)
+                for (int k = 0; k < j; ++k) {
+                    const double v = 0.5 * (H[(size_t)j * D + k] + H[(size_t)k * D + j]);
+                    H[(size_t)j * D + k] = v; H[(size_t)k * D + j] = v;
+                }
+            make_trial();
+            return;
+        }
+        // NEED_TRIAL
+        n_evals += 1;
+        const double lpn = lps[0];
+        double pred = 0.0;                                   // model increase g.s + 1/2 s^T H s
+        for (int j = 0; j < D; ++j) {
+            double hs = 0.0;
+            for (int k = 0; k < D; ++k) hs += H[(size_t)j * D + k] * s[k];
+            pred += s[j] * (g[j] + 0.5 * hs);
+        }
+        bool fin = std::isfinite(lpn);
+        for (int j = 0; j < D && fin; ++j) fin = std::isfinite(grads[j]);
+        if (fin && lpn - lp >= 1e-4 * pred && lpn >= lp - 1e-12 * std::fabs(lp)) {
+            const double rho = pred > 0.0 ? (lpn - lp) / pred : 0.0;
+            x = xt; lp = lpn;
+            memcpy(g.data(), grads, sizeof(double) * D);
+            if (rho > 0.75) lam = std::max(lam / 5.0, 1e-12);
+            else if (rho < 0.25) lam *= 2.0;
+            iters += 1;
+            if (grad_inf() < tol) { rc = 0; phase = DONE; return; }
+            if (iters >= max_iter) { rc = 1; phase = DONE; return; }
+            make_probes();
+            return;
+        }
+        lam *= 4.0;
+        make_trial();
+    }
+};
+
+}  // namespace bdrt

@@ -609,11 +609,16 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     S.args.done_counter = S.d_done;
     S.args.n_units = n_units;
     if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)nuts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return fail("hipFuncSetAttribute failed");
-        attr_set = true;
+    static size_t attr_bytes = 0;
+    if (S.lds_bytes > attr_bytes) {
+        hipError_t e = hipFuncSetAttribute((const void *)nuts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)S.lds_bytes);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(nuts_kernel, %zu B dynamic LDS) failed: %s", S.lds_bytes, hipGetErrorString(e));
+            bdrt_sampler_destroy(s);
+            return nullptr;
+        }
+        attr_bytes = S.lds_bytes;
     }
     return s;
 }

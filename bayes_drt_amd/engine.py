@@ -80,6 +80,11 @@ def blocks_from_dat(model_name, dat):
     return blocks, kw, names
 
 
+def _report(r):
+    return dict(iterations=r.iterations, n_evals=r.n_evals, return_code=r.return_code, lp=r.lp, grad_norm=r.grad_norm,
+                newton_iterations=r.newton_iterations, grad_inf=r.grad_inf)
+
+
 class StanFit:
     """What `fit[name]` needs (reference inversion.py:2514-2519, :2560, :2702, :3096): post-warm-up draws of all
     chains merged, shape [chains*draws, ...]."""
@@ -231,22 +236,29 @@ class StanModel:
         return theta
 
     # ------------------------------------------------------------------ optimizing / sampling
-    def optimizing(self, data, iter=50000, seed=1234, init='random', **opts):
-        """MAP by L-BFGS without Jacobian (Stan `optimizing`).  Returns OrderedDict name -> ndarray with the
-        parameters and transformed parameters `Inverter._extract_parameter` reads."""
+    def optimizing(self, data, iter=50000, seed=1234, init='random', algorithm='LBFGS+Newton', **opts):
+        """MAP without Jacobian (Stan `optimizing`).  Returns OrderedDict name -> ndarray with the parameters and
+        transformed parameters `Inverter._extract_parameter` reads.
+
+        algorithm='LBFGS' is the Stan-style L-BFGS(5) with Stan's termination tests (an early-terminated iterate,
+        SURVEY fact 4); the default 'LBFGS+Newton' continues with the GPU full-Hessian Newton polish to a true
+        stationary point (bdrt_newton.h)."""
         P = self._prepare(data)
         lib = P._lib
         theta0 = self._init_theta(init, 1, seed)
         o = OptOptions()
         lib.bdrt_opt_defaults(C.byref(o))
         o.max_iter = int(iter)
+        if algorithm == 'LBFGS':
+            o.newton_max_iter = 0
+        elif algorithm != 'LBFGS+Newton':
+            raise ValueError("algorithm must be 'LBFGS' or 'LBFGS+Newton'")
         for k, v in opts.items():
             setattr(o, k, v)
         out = np.empty((1, P.D))
         rep = (OptReport * 1)()
         check(lib.bdrt_optimize(P.handle, ptr(theta0), None, 1, C.byref(o), ptr(out), rep), 'bdrt_optimize')
-        self.last_report = dict(iterations=rep[0].iterations, n_evals=rep[0].n_evals, return_code=rep[0].return_code,
-                                lp=rep[0].lp, grad_norm=rep[0].grad_norm)
+        self.last_report = _report(rep[0])
         return self.result_dict(out[0])
 
     def result_dict(self, theta):
@@ -340,6 +352,5 @@ def optimize_batch(problem, theta0, spec=None, max_iter=50000, **opts):
     out = np.empty((n, problem.D))
     rep = (OptReport * n)()
     check(lib.bdrt_optimize(problem.handle, ptr(theta0), ptr(sp), n, C.byref(o), ptr(out), rep), 'bdrt_optimize')
-    reports = [dict(iterations=r.iterations, n_evals=r.n_evals, return_code=r.return_code, lp=r.lp,
-                    grad_norm=r.grad_norm) for r in rep]
+    reports = [_report(r) for r in rep]
     return out, reports

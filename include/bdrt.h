@@ -106,21 +106,29 @@ int bdrt_transformed(bdrt_problem *p, const double *theta, const int *spec, int 
 /* replaces StanModel.optimizing (inversion.py:1216): L-BFGS on the unconstrained scale, no Jacobian.
  * One optimisation per row of init (n_fits rows, spectrum spec[i]); every log_prob+grad is evaluated on the GPU. */
 typedef struct {
-    int max_iter;           /* Stan `iter` (inversion.py:1077: 50000)   */
-    int history;            /* 5                                         */
-    double init_alpha;      /* 1e-3                                      */
-    double tol_obj;         /* 1e-12                                     */
-    double tol_rel_obj;     /* 1e4  (x machine eps)                      */
-    double tol_grad;        /* 1e-8                                      */
-    double tol_rel_grad;    /* 1e7  (x machine eps)                      */
-    double tol_param;       /* 1e-8                                      */
+    int max_iter;           /* Stan `iter` (inversion.py:1077: 50000): cap on L-BFGS iterations          */
+    int history;            /* 5                                                                         */
+    double init_alpha;      /* 1e-3                                                                      */
+    double tol_obj;         /* 1e-12                                                                     */
+    double tol_rel_obj;     /* 1e4  (x machine eps)                                                      */
+    double tol_grad;        /* 1e-8                                                                      */
+    double tol_rel_grad;    /* 1e7  (x machine eps)                                                      */
+    double tol_param;       /* 1e-8                                                                      */
+    /* second-order polish (not in Stan; bdrt_newton.h): after at most lbfgs_before_newton L-BFGS iterations a
+     * damped Newton iteration with the full Hessian (2D batched gradient evaluations per step) runs until
+     * |grad|_inf < newton_tol.  newton_max_iter = 0 gives the plain Stan-style L-BFGS.                   */
+    int newton_max_iter;    /* 400                                                                       */
+    int lbfgs_before_newton;/* 1000                                                                      */
+    double newton_tol;      /* 1e-8                                                                      */
 } bdrt_opt_options;
 typedef struct {
-    int iterations;
-    int n_evals;
-    int return_code;        /* 0 converged, 1 max_iter, <0 failure       */
+    int iterations;         /* L-BFGS iterations                                                         */
+    int n_evals;            /* log_prob+grad evaluations, all phases                                     */
+    int return_code;        /* 0 converged, 1 iteration cap, 2 damping exhausted, <0 failure             */
     double lp;
-    double grad_norm;
+    double grad_norm;       /* 2-norm                                                                    */
+    int newton_iterations;
+    double grad_inf;        /* max-norm at the returned point                                            */
 } bdrt_opt_report;
 void bdrt_opt_defaults(bdrt_opt_options *o);
 int bdrt_optimize(bdrt_problem *p, const double *init_theta, const int *spec, int n_fits, const bdrt_opt_options *opts,
