@@ -117,7 +117,7 @@ typedef struct {
     /* second-order polish (not in Stan; bdrt_newton.h): after at most lbfgs_before_newton L-BFGS iterations a
      * damped Newton iteration with the full Hessian (2D batched gradient evaluations per step) runs until
      * |grad|_inf < newton_tol.  newton_max_iter = 0 gives the plain Stan-style L-BFGS.                   */
-    int newton_max_iter;    /* 400                                                                       */
+    int newton_max_iter;    /* 2000                                                                      */
     int lbfgs_before_newton;/* 1000                                                                      */
     double newton_tol;      /* 1e-8                                                                      */
 } bdrt_opt_options;
