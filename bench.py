@@ -149,8 +149,8 @@ def main():
     ctrl = NutsControl()
     lib.bdrt_nuts_defaults(C.byref(ctrl))
     ctrl.adapt_delta, ctrl.adapt_t0 = 0.9, 10.0                          # inversion.py:1221
-    # long enough that no chain finishes inside the benchmark
-    h = lib.bdrt_sampler_create(prob.handle, n_units, ptr(spec), ptr(chain_id), 1000, 100000, C.c_uint64(1234), None,
+    # warm-up long enough that no chain finishes inside the benchmark (adaptation windows at 100, 150, 250, ...)
+    h = lib.bdrt_sampler_create(prob.handle, n_units, ptr(spec), ptr(chain_id), 1000000, 1, C.c_uint64(1234), None,
                                 C.byref(ctrl))
     if not h:
         raise SystemExit('bdrt_sampler_create: ' + lib.bdrt_last_error().decode())
