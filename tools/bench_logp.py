@@ -15,7 +15,8 @@ bf = np.logspace(10, -6, K); tau = 1 / (2 * np.pi * bf); eps = 1 / np.mean(np.di
 A = np.vstack([gm.construct_A(f, 'real', tau=tau, epsilon=eps), gm.construct_A(f, 'imag', tau=tau, epsilon=eps)])
 L = [gm.construct_L(bf, tau=tau, epsilon=eps, order=o) for o in (0, 1, 2)]
 prob = Problem([dict(A=A, L0=L[0], L1=L[1], L2=0.75 * L[2], nonneg=True)], Z, f, ups_alpha=1.0, ups_beta=0.1)
-stream = torch.cuda.current_stream().cuda_stream
+ts = torch.cuda.Stream()           # a real (non-null) stream: the events below are recorded on it too
+stream = ts.cuda_stream
 for B in (16, 256, 2048, 4096, 16384, 65536):
     th = torch.empty(B, prob.D, dtype=torch.float64, device='cuda').uniform_(-2, 2)
     g = torch.empty_like(th); lp = torch.empty(B, dtype=torch.float64, device='cuda')
@@ -23,13 +24,15 @@ for B in (16, 256, 2048, 4096, 16384, 65536):
     def run():
         rc = lib.bdrt_logp_grad_dev(prob.handle, th.data_ptr(), spec.data_ptr(), B, 1, lp.data_ptr(), g.data_ptr(), stream)
         assert rc == 0
-    for _ in range(3): run()
     torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    n = 20
-    e0.record()
-    for _ in range(n): run()
-    e1.record(); torch.cuda.synchronize()
+    with torch.cuda.stream(ts):
+        for _ in range(3): run()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record(ts)
+        for _ in range(n): run()
+        e1.record(ts)
+    torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     print(json.dumps(dict(B=B, ms=ms, evals_per_s=B / ms * 1e3, tflops=B * FLOP_PER_EVAL / ms * 1e-9,
                           frac_mfma=B * FLOP_PER_EVAL / ms * 1e-9 / 78.6)))
