@@ -64,6 +64,7 @@ SYMBOLS = [
     'bdrt_opt_defaults', 'bdrt_optimize',
     'bdrt_nuts_defaults', 'bdrt_sampler_create', 'bdrt_sampler_destroy', 'bdrt_sampler_advance', 'bdrt_sampler_sync',
     'bdrt_sampler_run', 'bdrt_sampler_results', 'bdrt_sampler_total_leapfrogs', 'bdrt_sampler_kernel_time',
+    'bdrt_sampler_phase_profile',
     'bdrt_sample',
     'bdrt_gram', 'bdrt_qp_box',
     'bdrt_last_error', 'bdrt_device_count', 'bdrt_set_device', 'bdrt_version',
@@ -117,6 +118,7 @@ def load_library():
     lib.bdrt_sampler_total_leapfrogs.argtypes = [vp]
     lib.bdrt_sampler_total_leapfrogs.restype = C.c_int64
     lib.bdrt_sampler_kernel_time.argtypes = [vp, vp, vp, C.c_int]
+    lib.bdrt_sampler_phase_profile.argtypes = [vp, C.c_int, vp]
     lib.bdrt_sample.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_uint64, vp, C.POINTER(NutsControl), vp, vp,
                                 vp]
     lib.bdrt_gram.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]

@@ -50,6 +50,7 @@ struct DevProblem {
     int outlier_mode, use_x_sum;
     int n_spectra;
     int XR, ZR, LR, npar;     // LDS row counts
+    int dbg;                  // timing ablation only (env BDRT_DEBUG_SKIP): 1 skip forward GEMMs, 2 skip backward GEMM
     double sigma_min, ups_alpha, ups_beta, induc_scale;
     double so_lambda, so_alpha, so_beta, x_sum_invscale;
     const double *Z;          // [n_spectra][2nf]
@@ -72,6 +73,48 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
 // Y[(16 t + i)][c] = sum_k M[16 t + i][k] X[k][c] for the tiles of this wave.
 // Fragment order (host packing in bdrt_model.hip::pack_forward): element (tile t, pair p, lane l, h) =
 // M[16 t + (l & 15)][8 p + 4 h + (l >> 4)].
+constexpr int PF = 4;   // operand pairs prefetched ahead of the MFMAs (register double buffer)
+
+// one chunk of PF operand pairs: 2*PF MFMAs fed from registers (a) and LDS (xb rows 8p, 8p+4)
+__device__ __forceinline__ void mfma_chunk(const double2 (&a)[PF], const double *xb, int p0, d4 &acc0, d4 &acc1)
+{
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        acc0 = mfma_f64(a[i].x, xb[(8 * (p0 + i)) * NC], acc0);
+        acc1 = mfma_f64(a[i].y, xb[(8 * (p0 + i) + 4) * NC], acc1);
+    }
+}
+
+// acc += sum over `pairs` operand pairs of M-fragments (global/L2, stride 64 double2 per pair) times LDS rows.
+// Software pipelined: the loads of chunk i+1 are in flight while the MFMAs of chunk i issue.
+__device__ __forceinline__ void mfma_stream(const double2 *__restrict__ mp, int pairs, const double *xb, d4 &acc0,
+                                            d4 &acc1)
+{
+    const int nchunk = pairs / PF;
+    double2 a[PF], b[PF];
+    if (nchunk > 0) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) a[i] = mp[(size_t)i * 64];
+    }
+    int c = 0;
+    for (; c + 1 < nchunk; c += 2) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) b[i] = mp[(size_t)((c + 1) * PF + i) * 64];
+        mfma_chunk(a, xb, c * PF, acc0, acc1);
+        if (c + 2 < nchunk) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) a[i] = mp[(size_t)((c + 2) * PF + i) * 64];
+        }
+        mfma_chunk(b, xb, (c + 1) * PF, acc0, acc1);
+    }
+    if (c < nchunk) mfma_chunk(a, xb, c * PF, acc0, acc1);
+    for (int p = nchunk * PF; p < pairs; ++p) {
+        const double2 v = mp[(size_t)p * 64];
+        acc0 = mfma_f64(v.x, xb[(8 * p) * NC], acc0);
+        acc1 = mfma_f64(v.y, xb[(8 * p + 4) * NC], acc1);
+    }
+}
+
 __device__ __forceinline__ void gemm_forward(const double *__restrict__ Mp, int ntiles, int kpairs,
                                              const double *Xs, double *Ys, int wave, int lane)
 {
@@ -79,15 +122,7 @@ __device__ __forceinline__ void gemm_forward(const double *__restrict__ Mp, int 
     for (int t = wave; t < ntiles; t += NW) {
         d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
         const double2 *mp = reinterpret_cast<const double2 *>(Mp) + ((size_t)t * kpairs) * 64 + lane;
-        const double *xb = Xs + kq * NC + col;
-#pragma unroll 4
-        for (int p = 0; p < kpairs; ++p) {
-            const double2 a = mp[(size_t)p * 64];
-            const double b0 = xb[(8 * p) * NC];
-            const double b1 = xb[(8 * p + 4) * NC];
-            acc0 = mfma_f64(a.x, b0, acc0);
-            acc1 = mfma_f64(a.y, b1, acc1);
-        }
+        mfma_stream(mp, kpairs, Xs + kq * NC + col, acc0, acc1);
         // C/D layout of v_mfma_f64_16x16x4_f64: row = (lane >> 4) + 4 r, col = lane & 15
 #pragma unroll
         for (int r = 0; r < 4; ++r) Ys[(16 * t + kq + 4 * r) * NC + col] = acc0[r] + acc1[r];
@@ -105,21 +140,8 @@ __device__ __forceinline__ void gemm_backward(const double *__restrict__ Mp, int
     for (int t = wave; t < ntiles; t += NW) {
         d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
         const double2 *mp = reinterpret_cast<const double2 *>(Mp) + ((size_t)t * rp) * 64 + lane;
-        const double *ra = Ra + kq * NC + col;
-        const double *rl = Rl + kq * NC + col;
-#pragma unroll 4
-        for (int p = 0; p < rpairsA; ++p) {
-            const double2 a = mp[(size_t)p * 64];
-            acc0 = mfma_f64(a.x, ra[(8 * p) * NC], acc0);
-            acc1 = mfma_f64(a.y, ra[(8 * p + 4) * NC], acc1);
-        }
-        mp += (size_t)rpairsA * 64;
-#pragma unroll 4
-        for (int p = 0; p < rpairsL; ++p) {
-            const double2 a = mp[(size_t)p * 64];
-            acc0 = mfma_f64(a.x, rl[(8 * p) * NC], acc0);
-            acc1 = mfma_f64(a.y, rl[(8 * p + 4) * NC], acc1);
-        }
+        mfma_stream(mp, rpairsA, Ra + kq * NC + col, acc0, acc1);
+        mfma_stream(mp + (size_t)rpairsA * 64, rpairsL, Rl + kq * NC + col, acc0, acc1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Gs[(16 * t + kq + 4 * r) * NC + col] = acc0[r] + acc1[r];
     }
@@ -165,6 +187,7 @@ struct TileIO {
     double *Z_hat;         // optional [chain][2nf] outputs (transformed parameters)
     double *sigma_tot;
     double *params;        // optional [chain][D] constrained parameters
+    long long *prof;       // optional cycle counters per phase (thread 0 of the workgroup), slots 0..9
 };
 
 // Evaluate lp and gradient for the 16 chains of this workgroup.  smem: lds_doubles(P) doubles.
@@ -192,6 +215,8 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
     double *pr = io.params ? io.params + (size_t)cc * P.D : nullptr;
     auto PW = [&](int j, double v) { if (pr && valid) pr[j] = v; };
 
+    long long tprev = (io.prof && tid == 0) ? clock64() : 0;
+#define BDRT_TILE_PROF(slot) do { if (io.prof && tid == 0) { const long long t_ = clock64(); io.prof[slot] += t_ - tprev; tprev = t_; } } while (0)
     // ---- phase 0: per-chain scalars -------------------------------------------------------------
     if (tid < NC) {
         const double rinf_raw = exp(TH(0)), induc_raw = exp(TH(1));
@@ -206,6 +231,7 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
     }
     for (int i = tid; i < P.ZR * NC; i += NT) Zh[i] = 0.0;
     __syncthreads();
+    BDRT_TILE_PROF(0);
 
     // ---- phase 1: Z_hat = sum_b (A_b x_b  or  1/(A_b x_b)) + offsets --------------------------------
     for (int b = 0; b < P.nblocks; ++b) {
@@ -227,8 +253,10 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
             if (tid < NC) sc[S_XSUM * NC + c] += sc[S_TMP * NC + c];
         }
         __syncthreads();
-        gemm_forward(B.Af, B.tilesA, B.kpairs, Xs, Lr, wave, lane);     // T = A_b x_b  (in the Lr buffer)
+        BDRT_TILE_PROF(1);
+        if (!(P.dbg & 1)) gemm_forward(B.Af, B.tilesA, B.kpairs, Xs, Lr, wave, lane);     // T = A_b x_b  (in the Lr buffer)
         __syncthreads();
+        BDRT_TILE_PROF(2);
         for (int n = g; n < nf; n += NG) {
             const double yr = Lr[n * NC + c], yi = Lr[(nf + n) * NC + c];
             if (!B.is_parallel) {
@@ -244,6 +272,7 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
             }
         }
         __syncthreads();
+        BDRT_TILE_PROF(3);
     }
 
     // ---- phase 2: likelihood Z ~ normal(Z_hat, sigma_tot); g_Zhat in place --------------------------
@@ -334,6 +363,7 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
             sc[S_LP * NC + c] += lp;
         }
         __syncthreads();
+        BDRT_TILE_PROF(4);
     }
 
     // ---- phase 3: per block: q-prior, ups prior, back-propagation ------------------------------------
@@ -346,8 +376,10 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
             Xs[k * NC + c] = x;                           // raw x: q uses L * x_raw (Series-Parallel_modelcode.txt:55)
         }
         __syncthreads();
-        gemm_forward(B.Lf, B.tilesL, B.kpairs, Xs, Lr, wave, lane);     // v = [L0 x; L1 x; L2 x]
+        BDRT_TILE_PROF(5);
+        if (!(P.dbg & 1)) gemm_forward(B.Lf, B.tilesL, B.kpairs, Xs, Lr, wave, lane);     // v = [L0 x; L1 x; L2 x]
         __syncthreads();
+        BDRT_TILE_PROF(6);
         for (int k = g; k < K; k += NG) Xs[k * NC + c] = 0.15 * exp(TH(B.o_ups + k));   // ups = ups_raw*0.15
         __syncthreads();
         {
@@ -420,8 +452,10 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
         }
         __syncthreads();
         const double *Ra = B.is_parallel ? Yp + (size_t)B.yp_slot * P.ZR * NC : Zh;
-        gemm_backward(B.Bk, B.tilesK, B.rpairsA, B.rpairsL, Ra, Lr, Xs, wave, lane);
+        BDRT_TILE_PROF(7);
+        if (!(P.dbg & 2)) gemm_backward(B.Bk, B.tilesK, B.rpairsA, B.rpairsL, Ra, Lr, Xs, wave, lane);
         __syncthreads();
+        BDRT_TILE_PROF(8);
         if (gr) {
             const double xs_term = P.use_x_sum ? -sc[S_XSUM * NC + c] * P.x_sum_invscale * P.x_sum_invscale : 0.0;
             double lpj[1] = {0.0};
@@ -448,6 +482,7 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
         __syncthreads();
     }
 
+    BDRT_TILE_PROF(9);
     if (tid < NC && io.lp && valid) {
         double lp = sc[S_LP * NC + c];
         if (sc[S_REJ * NC + c] != 0.0) lp = -INFINITY;

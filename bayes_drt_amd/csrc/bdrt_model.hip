@@ -5,6 +5,7 @@
 // (reference bayes_drt/inversion.py:1216-1221).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "bdrt_host.h"
@@ -143,6 +144,7 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
     D.ZR = 8 * rpairsA;
     D.LR = std::max(LR, MIN_LR);
     D.npar = npar;
+    if (const char *e = getenv("BDRT_DEBUG_SKIP")) D.dbg = atoi(e);
     P.lds_bytes = lds_doubles(D) * sizeof(double);
     if (P.lds_bytes > 160 * 1024) {
         set_error("bdrt_problem_create: problem needs %zu B of LDS per workgroup (> 160 KiB): nf=%d, K too large",
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(NT) void logp_grad_kernel(DevProblem P, const doubl
     io.Z_hat = Zhat ? Zhat + (size_t)c0 * 2 * P.nf : nullptr;
     io.sigma_tot = sig ? sig + (size_t)c0 * 2 * P.nf : nullptr;
     io.params = params ? params + (size_t)c0 * P.D : nullptr;
+    io.prof = nullptr;
     logp_grad_tile(P, io, smem);
 }
 

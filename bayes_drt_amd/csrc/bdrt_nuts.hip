@@ -34,36 +34,19 @@ static_assert(NW * NQ_CHK * NC <= MIN_LR * NC, "Lr buffer too small for the NUTS
 enum { V_TH = 0, V_P, V_G, V_THM, V_PM, V_GM, V_THP, V_PP, V_GP, V_THS, V_GS, V_THQ, V_GQ, V_RHO, V_RHOC, V_MINV,
        V_WMEAN, V_WM2, V_CKC /* MAXD */, V_CKP = V_CKC + MAXD /* MAXD */, V_COUNT = V_CKP + MAXD };
 
-// flag / value slots broadcast through LDS: [slot][16]
-enum { F_EPS = 0, F_ACT, F_LPN, F_KIN, F_NONFIN, F_COPYQ, F_CUR2S, F_TREE, F_EVEN, F_CKIDX, F_NM, F_LAST, F_DIR,
-       F_UPDS, F_ENDT, F_WELF, F_WN, F_WEND, F_DRAW, F_NEXT, F_ITER, F_TRIAL, F_ATT, F_KIN0, F_RED /* NQ_CHK */,
-       F_COUNT = F_RED + NQ_CHK };
-
-template <int NQ>
-__device__ __forceinline__ void chain_reduce_big(double (&v)[NQ], double *red, double *out, int tid)
+// sum over the 32 lanes of a half-wave (one chain), fixed order => deterministic; every lane gets the result
+__device__ __forceinline__ double half_sum(double x)
 {
-    // same as chain_reduce but with a caller-provided scratch of NW*NQ*NC doubles
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        double x = v[q];
-        x += __shfl_xor(x, 16);
-        x += __shfl_xor(x, 32);
-        if (lane < NC) red[(wave * NQ + q) * NC + lane] = x;
-    }
-    __syncthreads();
-    for (int i = tid; i < NQ * NC; i += NT) {
-        const int q = i / NC, c = i % NC;
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) s += red[(w * NQ + q) * NC + c];
-        out[q * NC + c] = s;
-    }
-    __syncthreads();
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 8);
+    x += __shfl_xor(x, 4);
+    x += __shfl_xor(x, 2);
+    x += __shfl_xor(x, 1);
+    return x;
 }
 
 struct NutsArgs {
-    double *vecs;          // [n_wg][V_COUNT][D][16]
+    double *vecs;          // [n_wg][V_COUNT][16 chains][ds]  (one contiguous row per chain and vector)
     ChainState *states;    // [n_units]
     double *draws;         // [n_units][n_draws][D]
     double *lp_draws;      // [n_units][n_draws]
@@ -71,413 +54,396 @@ struct NutsArgs {
     int *done_counter;     // workgroups whose chains are all finished
     int n_units;
     int rounds;
+    int ds;                // row stride of the state vectors (D rounded up to 32)
+    long long *prof;       // optional [n_wg][32] cycle counters (phase profile)
 };
 
+// Thread mapping of the bookkeeping stages: chain c of the workgroup lives in ONE half-wave (wave c/2, lanes
+// 32*(c%2)..+31); its D-vectors are contiguous rows, lane l handles elements l, l+32, ...  Per-chain dot products are
+// 5-step xor-shuffle reductions, the per-chain scalar logic runs redundantly in the 32 lanes of the half-wave (state
+// in LDS), and no stage between two tile evaluations needs a workgroup barrier.
 __global__ __launch_bounds__(NT) void nuts_kernel(DevProblem P, NutsParams np, NutsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x;
-    const int c = tid & (NC - 1), g = tid >> 4;
-    const int D = P.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = 2 * wave + (lane >> 5);
+    const int l32 = lane & 31;
+    const int D = P.D, DS = a.ds;
     const int wg = blockIdx.x;
     const int c0 = wg * NC;
     const int nvalid = min(NC, a.n_units - c0);
     const bool valid = c < nvalid;
 
-    // LDS carve-up: [tile region | flags | chain states | spec]
+    // LDS carve-up: [tile region | lp of the 16 chains | chain states | spectrum ids]
     const size_t tile_doubles = lds_doubles(P);
-    double *fl = smem + tile_doubles;
-    ChainState *sts = reinterpret_cast<ChainState *>(fl + F_COUNT * NC);
+    double *lpn = smem + tile_doubles;
+    ChainState *sts = reinterpret_cast<ChainState *>(lpn + NC);
     int *spec = reinterpret_cast<int *>(sts + NC);
-    // scratch for the big reduction: the tile's Lr buffer is free outside logp_grad_tile
-    double *bigred = smem + (size_t)P.XR * NC + (size_t)P.ZR * NC * (1 + P.npar);
 
-    double *V = a.vecs + (size_t)wg * V_COUNT * D * NC;
-    auto vec = [&](int v) -> double * { return V + (size_t)v * D * NC; };
+    double *V = a.vecs + (size_t)wg * V_COUNT * NC * DS;
+    auto row = [&](int v) -> double * { return V + ((size_t)v * NC + c) * DS; };   // this chain's row of vector v
 
     if (tid < NC) {
-        if (valid) sts[c] = a.states[c0 + c];
-        else { memset(&sts[c], 0, sizeof(ChainState)); sts[c].phase = PH_DONE; }
-        spec[c] = valid ? sts[c].spec : 0;
+        if (tid < nvalid) sts[tid] = a.states[c0 + tid];
+        else { memset(&sts[tid], 0, sizeof(ChainState)); sts[tid].phase = PH_DONE; }
+        spec[tid] = tid < nvalid ? sts[tid].spec : 0;
     }
     __syncthreads();
-    // (re)derive the leapfrog inputs of the first round from the stored state
-    if (tid < NC) {
-        ChainState &s = sts[c];
-        const bool act = s.phase == PH_INIT || s.phase == PH_EPS || s.phase == PH_TREE;
-        fl[F_ACT * NC + c] = act ? 1.0 : 0.0;
-        double e = 0.0;
-        if (s.phase == PH_EPS) e = s.eps;
-        else if (s.phase == PH_TREE) e = s.dir * s.eps;
-        fl[F_EPS * NC + c] = e;
-    }
-    __syncthreads();
+    ChainState &s = sts[c];
+    const Philox rng = {np.seed_lo, np.seed_hi, (uint32_t)s.chain_id};
 
     TileIO io;
-    io.theta = vec(V_TH); io.t_sc = 1; io.t_sj = NC;
-    io.grad = vec(V_G); io.g_sc = 1; io.g_sj = NC;
-    io.lp = fl + F_LPN * NC;
+    io.theta = V + (size_t)V_TH * NC * DS; io.t_sc = DS; io.t_sj = 1;
+    io.grad = V + (size_t)V_G * NC * DS; io.g_sc = DS; io.g_sj = 1;
+    io.lp = lpn;
     io.spec = spec;
     io.nvalid = NC;            // padded columns carry a DONE state and finite vectors
     io.jacobian = 1;
     io.Z_hat = nullptr; io.sigma_tot = nullptr; io.params = nullptr;
+    io.prof = a.prof ? a.prof + (size_t)wg * 32 : nullptr;
+    long long tnp = 0;
+#define BDRT_NUTS_PROF(slot) do { if (io.prof && tid == 0) { const long long t_ = clock64(); io.prof[slot] += t_ - tnp; tnp = t_; } } while (0)
 
     unsigned long long my_leaps = 0;
+    double *TH = row(V_TH), *Pm = row(V_P), *G = row(V_G), *MI = row(V_MINV);
 
     for (int round = 0; round < a.rounds; ++round) {
-        // ---- any chain still working? ---------------------------------------------------------------
-        {
-            const double act = fl[F_ACT * NC + c];
-            if (!__syncthreads_or(act != 0.0)) break;
-        }
-        const double e = fl[F_EPS * NC + c];
-        const bool act = fl[F_ACT * NC + c] != 0.0;
+        const int ph0 = s.phase;
+        const bool act = ph0 == PH_INIT || ph0 == PH_EPS || ph0 == PH_TREE;
+        if (!__syncthreads_or(act)) break;
+        const double e = ph0 == PH_EPS ? s.eps : (ph0 == PH_TREE ? s.dir * s.eps : 0.0);
+        if (io.prof && tid == 0) tnp = clock64();
 
         // ---- A: half kick + drift --------------------------------------------------------------------
         if (act) {
-            double *TH = vec(V_TH), *Pm = vec(V_P);
-            const double *G = vec(V_G), *MI = vec(V_MINV);
-            for (int j = g; j < D; j += NG) {
-                const int i = j * NC + c;
-                const double p = Pm[i] + 0.5 * e * G[i];
-                Pm[i] = p;
-                TH[i] += e * MI[i] * p;
+            for (int j = l32; j < D; j += 32) {
+                const double p = Pm[j] + 0.5 * e * G[j];
+                Pm[j] = p;
+                TH[j] += e * MI[j] * p;
             }
         }
         __syncthreads();
+        BDRT_NUTS_PROF(10);
 
         // ---- B: log-posterior + gradient at the new point (MFMA tile) ------------------------------------
         logp_grad_tile(P, io, smem);
+        if (io.prof && tid == 0) tnp = clock64();
 
         // ---- C: second half kick, kinetic energy, finiteness of the gradient -----------------------------
-        {
-            double acc[2] = {0.0, 0.0};
-            if (act) {
-                double *Pm = vec(V_P);
-                const double *G = vec(V_G), *MI = vec(V_MINV);
-                for (int j = g; j < D; j += NG) {
-                    const int i = j * NC + c;
-                    const double gj = G[i];
-                    const double p = Pm[i] + 0.5 * e * gj;
-                    Pm[i] = p;
-                    acc[0] += MI[i] * p * p;
-                    acc[1] += isfinite(gj) ? 0.0 : 1.0;
-                }
+        double kin = 0.0, nonfin = 0.0;
+        if (act) {
+            for (int j = l32; j < D; j += 32) {
+                const double gj = G[j];
+                const double p = Pm[j] + 0.5 * e * gj;
+                Pm[j] = p;
+                kin += MI[j] * p * p;
+                nonfin += isfinite(gj) ? 0.0 : 1.0;
             }
-            chain_reduce<2>(acc, smem + (size_t)P.XR * NC + (size_t)P.ZR * NC * (1 + P.npar) + (size_t)P.LR * NC,
-                            fl + F_KIN * NC, tid);   // F_KIN, F_NONFIN are consecutive slots
         }
+        kin = 0.5 * half_sum(kin);
+        nonfin = half_sum(nonfin);
+        BDRT_NUTS_PROF(11);
 
-        // ---- S1: per-chain scalar logic after the evaluation -----------------------------------------------
-        if (tid < NC) {
-            ChainState &s = sts[c];
-            const Philox rng = {np.seed_lo, np.seed_hi, (uint32_t)s.chain_id};
-            fl[F_COPYQ * NC + c] = 0; fl[F_CUR2S * NC + c] = 0; fl[F_TREE * NC + c] = 0; fl[F_NM * NC + c] = 0;
-            fl[F_LAST * NC + c] = 0; fl[F_UPDS * NC + c] = 0; fl[F_ENDT * NC + c] = 0; fl[F_WELF * NC + c] = 0;
-            fl[F_WEND * NC + c] = 0; fl[F_DRAW * NC + c] = -1; fl[F_NEXT * NC + c] = 0; fl[F_EVEN * NC + c] = 0;
-            fl[F_DIR * NC + c] = s.dir;
-            if (act) {
-                const double lp = fl[F_LPN * NC + c];
-                const double kin = 0.5 * fl[F_KIN * NC + c];
-                const bool finite_pt = isfinite(lp) && fl[F_NONFIN * NC + c] == 0.0;
-                if (s.phase == PH_INIT) {
-                    if (finite_pt) {
-                        s.lps = lp;
-                        fl[F_CUR2S * NC + c] = 1;
-                        s.phase = PH_EPS; s.eps_dir = 0; s.eps_trials = 0;
-                        fl[F_NEXT * NC + c] = 3;
-                    } else {
-                        s.init_attempt += 1;
-                        if (s.init_attempt >= 100) { s.phase = PH_FAILED; }
-                        else fl[F_NEXT * NC + c] = 4;
-                    }
-                } else if (s.phase == PH_EPS) {
-                    // Stan base_hmc::init_stepsize
-                    my_leaps += 1;
-                    double h = -lp + kin;
-                    if (isnan(h)) h = INFINITY;
-                    const double dH = s.H0 - h;
-                    const double thr = -0.2231435513142097557662950903;   // log(0.8)
-                    bool finished = false;
-                    if (s.eps_trials == 0) {
-                        s.eps_dir = dH > thr ? 1 : -1;
-                    } else {
-                        if (s.eps_dir == 1 && !(dH > thr)) finished = true;
-                        else if (s.eps_dir == -1 && !(dH < thr)) finished = true;
-                        else s.eps = s.eps_dir == 1 ? 2.0 * s.eps : 0.5 * s.eps;
-                        if (!(s.eps > 1e-300) || s.eps > 1e7) finished = true;   // Stan throws here; we stop adapting
-                    }
-                    s.eps_trials += 1;
-                    if (finished) {
-                        // services::sample::hmc_nuts_diag_e_adapt sets mu = log(10*stepsize) from the CONFIGURED step
-                        // size before the first init_stepsize; after a metric update mu = log(10*eps) (adapt_diag_e_nuts)
-                        s.da_mu = s.iter == 0 ? log(10.0 * np.stepsize0) : log(10.0 * s.eps);
-                        da_restart(s);
-                        s.phase = PH_TREE;
-                        fl[F_NEXT * NC + c] = 1;
-                    } else {
-                        fl[F_NEXT * NC + c] = 3;
-                    }
-                } else {   // PH_TREE: one new leaf
-                    my_leaps += 1;
-                    s.n_leap_iter += 1;
-                    double h = -lp + kin;
-                    if (isnan(h)) h = INFINITY;
-                    const bool divergent = (h - s.H0) > np.max_deltaH;
-                    const double w = s.H0 - h;
-                    s.sum_metro += w > 0.0 ? 1.0 : exp(w);
-                    if (divergent) {
-                        fl[F_ENDT * NC + c] = 2;               // transition ends, subtree discarded, divergent
-                    } else {
-                        const double lsw_new = log_sum_exp2(s.lsw_sub, w);
-                        // uniform sampling inside the new subtree: keep leaf i with probability w_i / W_i
-                        const double u = rng_uniform(rng, (uint32_t)s.leaf, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
-                        if (s.leaf == 0 || u < exp(w - lsw_new)) { fl[F_COPYQ * NC + c] = 1; s.lpq = lp; }
-                        s.lsw_sub = lsw_new;
-                        fl[F_TREE * NC + c] = 1;
-                        const int i = s.leaf;
-                        if ((i & 1) == 0) {
-                            fl[F_EVEN * NC + c] = 1;
-                            fl[F_CKIDX * NC + c] = __popc((unsigned)(i >> 1));
-                        } else {
-                            int t = 0;
-                            while ((i >> t) & 1) ++t;          // trailing ones = completed sub-subtrees ending here
-                            fl[F_NM * NC + c] = t;
-                            fl[F_CKIDX * NC + c] = __popc((unsigned)(i >> 1));
-                        }
-                        if (i == s.nleaves - 1) fl[F_LAST * NC + c] = 1;
-                    }
+        // ---- S1: per-chain scalar logic after the evaluation (redundant in the 32 lanes of the chain) --------
+        bool copyq = false, cur2s = false, tree = false, even = false, last = false;
+        bool upds = false, welf = false, wend = false;
+        int nm = 0, ck = 0, endt = 0, next = 0, draw = -1;
+        double wn = 0.0;
+        const int dir_now = s.dir;
+        const int leaf_now = s.leaf;
+        if (act) {
+            const double lp = lpn[c];
+            const bool finite_pt = isfinite(lp) && nonfin == 0.0;
+            if (ph0 == PH_INIT) {
+                if (finite_pt) {
+                    s.lps = lp;
+                    cur2s = true;
+                    s.phase = PH_EPS; s.eps_dir = 0; s.eps_trials = 0;
+                    next = 3;
+                } else {
+                    const int att = s.init_attempt + 1;
+                    s.init_attempt = att;
+                    if (att >= 100) s.phase = PH_FAILED;
+                    else next = 4;
+                }
+            } else if (ph0 == PH_EPS) {
+                // Stan base_hmc::init_stepsize
+                if (l32 == 0) my_leaps += 1;
+                double h = -lp + kin;
+                if (isnan(h)) h = INFINITY;
+                const double dH = s.H0 - h;
+                const double thr = -0.2231435513142097557662950903;   // log(0.8)
+                bool finished = false;
+                const int trials = s.eps_trials;
+                const int edir = s.eps_dir;
+                double eps = s.eps;
+                if (trials == 0) {
+                    s.eps_dir = dH > thr ? 1 : -1;
+                } else {
+                    if (edir == 1 && !(dH > thr)) finished = true;
+                    else if (edir == -1 && !(dH < thr)) finished = true;
+                    else eps = edir == 1 ? 2.0 * eps : 0.5 * eps;
+                    if (!(eps > 1e-300) || eps > 1e7) finished = true;   // Stan throws here; we stop adapting
+                    s.eps = eps;
+                }
+                s.eps_trials = trials + 1;
+                if (finished) {
+                    // services::sample::hmc_nuts_diag_e_adapt sets mu = log(10*stepsize) from the CONFIGURED step
+                    // size before the first init_stepsize; after a metric update mu = log(10*eps) (adapt_diag_e_nuts)
+                    s.da_mu = s.iter == 0 ? log(10.0 * np.stepsize0) : log(10.0 * eps);
+                    s.da_counter = 0; s.da_sbar = 0.0; s.da_xbar = 0.0;
+                    s.phase = PH_TREE;
+                    next = 1;
+                } else {
+                    next = 3;
+                }
+            } else {   // PH_TREE: one new leaf
+                if (l32 == 0) my_leaps += 1;
+                s.n_leap_iter = s.n_leap_iter + 1;
+                double h = -lp + kin;
+                if (isnan(h)) h = INFINITY;
+                const double H0 = s.H0;
+                const bool divergent = (h - H0) > np.max_deltaH;
+                const double w = H0 - h;
+                s.sum_metro = s.sum_metro + (w > 0.0 ? 1.0 : exp(w));
+                if (divergent) {
+                    endt = 2;               // transition ends, subtree discarded, divergent
+                } else {
+                    const double lsw_new = log_sum_exp2(s.lsw_sub, w);
+                    // uniform sampling inside the new subtree: keep leaf i with probability w_i / W_i
+                    const double u = rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
+                    if (leaf_now == 0 || u < exp(w - lsw_new)) { copyq = true; s.lpq = lp; }
+                    s.lsw_sub = lsw_new;
+                    tree = true;
+                    ck = __popc((unsigned)(leaf_now >> 1));
+                    if ((leaf_now & 1) == 0) even = true;
+                    else { while ((leaf_now >> nm) & 1) ++nm; }     // trailing ones = sub-subtrees ending here
+                    last = leaf_now == s.nleaves - 1;
                 }
             }
         }
-        __syncthreads();
+        BDRT_NUTS_PROF(12);
 
         // ---- D: proposal copy, checkpoints, running rho, U-turn dot products, speculative subtree close ------
-        {
-            double acc[NQ_CHK];
+        double chk[NQ_CHK];
 #pragma unroll
-            for (int q = 0; q < NQ_CHK; ++q) acc[q] = 0.0;
-            const bool copyq = fl[F_COPYQ * NC + c] != 0.0, cur2s = fl[F_CUR2S * NC + c] != 0.0;
-            const bool tree = fl[F_TREE * NC + c] != 0.0, even = fl[F_EVEN * NC + c] != 0.0;
-            const bool last = fl[F_LAST * NC + c] != 0.0;
-            const int nm = (int)fl[F_NM * NC + c], ck = (int)fl[F_CKIDX * NC + c];
-            const int dir = (int)fl[F_DIR * NC + c];
-            const int leaf0 = tree && (sts[c].leaf == 0);
-            if (copyq || cur2s || tree) {
-                const double *TH = vec(V_TH), *Pm = vec(V_P), *G = vec(V_G), *MI = vec(V_MINV);
-                double *THQ = vec(V_THQ), *GQ = vec(V_GQ), *THS = vec(V_THS), *GS = vec(V_GS);
-                double *RHOC = vec(V_RHOC), *RHO = vec(V_RHO);
-                double *CKC = vec(V_CKC + (ck < MAXD ? ck : 0)), *CKP = vec(V_CKP + (ck < MAXD ? ck : 0));
-                double *THE = vec(dir > 0 ? V_THP : V_THM), *PE = vec(dir > 0 ? V_PP : V_PM), *GE = vec(dir > 0 ? V_GP : V_GM);
-                const double *PO = vec(dir > 0 ? V_PM : V_PP);     // momentum at the other end
-                for (int j = g; j < D; j += NG) {
-                    const int i = j * NC + c;
-                    const double th = TH[i], p = Pm[i], gj = G[i];
-                    if (copyq) { THQ[i] = th; GQ[i] = gj; }
-                    if (cur2s) { THS[i] = th; GS[i] = gj; }
-                    if (tree) {
-                        const double mi = MI[i];
-                        const double before = leaf0 ? 0.0 : RHOC[i];
-                        if (even) { CKC[i] = before; CKP[i] = p; }
-                        const double rc = before + p;
-                        RHOC[i] = rc;
+        for (int q = 0; q < NQ_CHK; ++q) chk[q] = 0.0;
+        if (copyq || cur2s || tree) {
+            double *THQ = row(V_THQ), *GQ = row(V_GQ), *THS = row(V_THS), *GS = row(V_GS);
+            double *RHOC = row(V_RHOC), *RHO = row(V_RHO);
+            double *CKC = row(V_CKC + (ck < MAXD ? ck : 0)), *CKP = row(V_CKP + (ck < MAXD ? ck : 0));
+            double *THE = row(dir_now > 0 ? V_THP : V_THM), *PE = row(dir_now > 0 ? V_PP : V_PM);
+            double *GE = row(dir_now > 0 ? V_GP : V_GM);
+            const double *PO = row(dir_now > 0 ? V_PM : V_PP);     // momentum at the other end
+            const bool leaf0 = leaf_now == 0;
+            for (int j = l32; j < D; j += 32) {
+                const double th = TH[j], p = Pm[j], gj = G[j];
+                if (copyq) { THQ[j] = th; GQ[j] = gj; }
+                if (cur2s) { THS[j] = th; GS[j] = gj; }
+                if (tree) {
+                    const double mi = MI[j];
+                    const double before = leaf0 ? 0.0 : RHOC[j];
+                    if (even) { CKC[j] = before; CKP[j] = p; }
+                    const double rc = before + p;
+                    RHOC[j] = rc;
 #pragma unroll
-                        for (int l = 0; l < MAXD; ++l) {
-                            if (l < nm) {
-                                const int idx = ck - l;
-                                const double rho = rc - V[((size_t)(V_CKC + idx) * D) * NC + i];
-                                acc[2 * l] += mi * V[((size_t)(V_CKP + idx) * D) * NC + i] * rho;
-                                acc[2 * l + 1] += mi * p * rho;
-                            }
+                    for (int l = 0; l < MAXD; ++l) {
+                        if (l < nm) {
+                            const int idx = ck - l;
+                            const double rho = rc - V[((size_t)(V_CKC + idx) * NC + c) * DS + j];
+                            chk[2 * l] += mi * V[((size_t)(V_CKP + idx) * NC + c) * DS + j] * rho;
+                            chk[2 * l + 1] += mi * p * rho;
                         }
-                        if (last) {
-                            // speculative close of the subtree: extend the trajectory end and test the whole trajectory
-                            const double rt = RHO[i] + rc;
-                            RHO[i] = rt;
-                            THE[i] = th; PE[i] = p; GE[i] = gj;
-                            acc[2 * MAXD] += mi * PO[i] * rt;
-                            acc[2 * MAXD + 1] += mi * p * rt;
-                        }
+                    }
+                    if (last) {
+                        // speculative close of the subtree: extend the trajectory end and test the whole trajectory
+                        const double rt = RHO[j] + rc;
+                        RHO[j] = rt;
+                        THE[j] = th; PE[j] = p; GE[j] = gj;
+                        chk[2 * MAXD] += mi * PO[j] * rt;
+                        chk[2 * MAXD + 1] += mi * p * rt;
                     }
                 }
             }
-            chain_reduce_big<NQ_CHK>(acc, bigred, fl + F_RED * NC, tid);
         }
+        BDRT_NUTS_PROF(13);
 
         // ---- S2: validity of the new subtree, trajectory-level decisions, adaptation scalars ---------------------
-        if (tid < NC) {
-            ChainState &s = sts[c];
-            const Philox rng = {np.seed_lo, np.seed_hi, (uint32_t)s.chain_id};
-            int endt = (int)fl[F_ENDT * NC + c];
-            if (fl[F_TREE * NC + c] != 0.0) {
-                const int nm = (int)fl[F_NM * NC + c];
-                bool ok = true;
-                for (int l = 0; l < nm; ++l)
-                    ok = ok && (fl[(F_RED + 2 * l) * NC + c] > 0.0) && (fl[(F_RED + 2 * l + 1) * NC + c] > 0.0);
-                if (!ok) {
-                    endt = 1;                                   // U-turn inside the new subtree: discard it, stop
-                } else if (fl[F_LAST * NC + c] != 0.0) {
-                    // subtree complete and valid (Stan base_nuts::transition after build_tree)
-                    s.depth += 1;
-                    bool take;
-                    if (s.lsw_sub > s.lsw) take = true;
-                    else take = rng_uniform(rng, 0, RNG_TOP, (uint32_t)s.depth, 0, (uint32_t)s.iter) < exp(s.lsw_sub - s.lsw);
-                    if (take) { fl[F_UPDS * NC + c] = 1; s.lps = s.lpq; }
-                    s.lsw = log_sum_exp2(s.lsw, s.lsw_sub);
-                    const bool keep_going = (fl[(F_RED + 2 * MAXD) * NC + c] > 0.0) && (fl[(F_RED + 2 * MAXD + 1) * NC + c] > 0.0);
-                    if (!keep_going || s.depth >= np.max_depth) endt = 1;
-                    else {
-                        // next doubling
-                        s.dir = rng_uniform(rng, 0, RNG_DIRECTION, (uint32_t)s.depth, 0, (uint32_t)s.iter) > 0.5 ? 1 : -1;
-                        s.leaf = 0; s.nleaves = 1 << s.depth; s.lsw_sub = -INFINITY;
-                        fl[F_NEXT * NC + c] = 2;
-                    }
-                } else {
-                    s.leaf += 1;
+        if (tree) {
+            bool ok = true;
+#pragma unroll
+            for (int l = 0; l < MAXD; ++l) {
+                if (l < nm) {
+                    const double a0 = half_sum(chk[2 * l]), a1 = half_sum(chk[2 * l + 1]);
+                    ok = ok && (a0 > 0.0) && (a1 > 0.0);
                 }
             }
-            if (endt) {
-                // end of transition (Stan adapt_diag_e_nuts::transition)
-                const double accept = s.sum_metro / (double)(s.n_leap_iter > 0 ? s.n_leap_iter : 1);
-                const bool warm = s.iter < np.warmup;
-                s.n_leap_total += s.n_leap_iter;
-                if (!warm) {
-                    s.n_post += 1;
-                    s.sum_accept += accept;
-                    if (endt == 2) s.n_div += 1;
-                    if (s.depth >= np.max_depth) s.n_maxdepth += 1;
-                    fl[F_DRAW * NC + c] = s.iter - np.warmup;
-                    if (a.lp_draws) a.lp_draws[(size_t)(c0 + c) * np.n_draws + (s.iter - np.warmup)] = s.lps;
+            if (!ok) {
+                endt = 1;                                   // U-turn inside the new subtree: discard it, stop
+            } else if (last) {
+                // subtree complete and valid (Stan base_nuts::transition after build_tree)
+                const double t0 = half_sum(chk[2 * MAXD]), t1 = half_sum(chk[2 * MAXD + 1]);
+                const int depth = s.depth + 1;
+                s.depth = depth;
+                const double lsw = s.lsw, lsw_sub = s.lsw_sub;
+                bool take;
+                if (lsw_sub > lsw) take = true;
+                else take = rng_uniform(rng, 0, RNG_TOP, (uint32_t)depth, 0, (uint32_t)s.iter) < exp(lsw_sub - lsw);
+                if (take) { upds = true; s.lps = s.lpq; }
+                s.lsw = log_sum_exp2(lsw, lsw_sub);
+                const bool keep_going = (t0 > 0.0) && (t1 > 0.0);
+                if (!keep_going || depth >= np.max_depth) endt = 1;
+                else {
+                    // next doubling
+                    s.dir = rng_uniform(rng, 0, RNG_DIRECTION, (uint32_t)depth, 0, (uint32_t)s.iter) > 0.5 ? 1 : -1;
+                    s.leaf = 0; s.nleaves = 1 << depth; s.lsw_sub = -INFINITY;
+                    next = 2;
                 }
-                bool redo_eps = false;
-                if (warm) {
-                    da_learn(s, np, accept);
-                    if (window_active(s, np.warmup)) { s.win_n += 1; fl[F_WELF * NC + c] = 1; fl[F_WN * NC + c] = s.win_n; }
-                    if (window_end(s, np.warmup)) {
-                        window_next(s, np.warmup);
-                        fl[F_WEND * NC + c] = 1; fl[F_WN * NC + c] = s.win_n;
-                        s.win_n = 0;
-                        redo_eps = true;
-                    }
-                    s.win_counter += 1;
-                }
-                s.iter += 1;
-                if (warm && s.iter == np.warmup) s.eps = exp(s.da_xbar);       // complete_adaptation
-                fl[F_ENDT * NC + c] = 1;
-                if (s.iter >= np.warmup + np.n_draws) {
-                    s.phase = PH_DONE;
-                    fl[F_NEXT * NC + c] = 0;
-                } else if (redo_eps && s.iter < np.warmup) {
-                    s.phase = PH_EPS; s.eps_dir = 0; s.eps_trials = 0;
-                    fl[F_NEXT * NC + c] = 3;
-                } else {
-                    fl[F_NEXT * NC + c] = 1;
-                }
+            } else {
+                s.leaf = leaf_now + 1;
             }
-            fl[F_ITER * NC + c] = s.iter;
-            fl[F_TRIAL * NC + c] = s.eps_trials;
-            fl[F_ATT * NC + c] = s.init_attempt;
-            fl[F_DIR * NC + c] = s.dir;
         }
-        __syncthreads();
+        if (endt) {
+            // end of transition (Stan adapt_diag_e_nuts::transition)
+            const int nli = s.n_leap_iter;
+            const double accept = s.sum_metro / (double)(nli > 0 ? nli : 1);
+            const int iter = s.iter;
+            const bool warm = iter < np.warmup;
+            s.n_leap_total = s.n_leap_total + nli;
+            if (!warm) {
+                s.n_post = s.n_post + 1;
+                s.sum_accept = s.sum_accept + accept;
+                if (endt == 2) s.n_div = s.n_div + 1;
+                if (s.depth >= np.max_depth) s.n_maxdepth = s.n_maxdepth + 1;
+                draw = iter - np.warmup;
+                if (a.lp_draws && valid && l32 == 0) a.lp_draws[(size_t)(c0 + c) * np.n_draws + draw] = s.lps;
+            }
+            bool redo_eps = false;
+            if (warm) {
+                // stepsize_adaptation::learn_stepsize (dual averaging)
+                const int cnt = s.da_counter + 1;
+                s.da_counter = cnt;
+                const double acc1 = accept > 1.0 ? 1.0 : accept;
+                const double eta = 1.0 / (cnt + np.t0);
+                const double sbar = (1.0 - eta) * s.da_sbar + eta * (np.delta - acc1);
+                s.da_sbar = sbar;
+                const double x = s.da_mu - sbar * sqrt((double)cnt) / np.gamma;
+                const double x_eta = pow((double)cnt, -np.kappa);
+                s.da_xbar = (1.0 - x_eta) * s.da_xbar + x_eta * x;
+                s.eps = exp(x);
+                // var_adaptation::learn_variance bookkeeping (windowed_adaptation)
+                const int wc = s.win_counter;
+                const bool w_act = wc >= s.init_buffer && wc < np.warmup - s.term_buffer && wc != np.warmup;
+                const bool w_end = wc == s.next_window && wc != np.warmup;
+                int win_n = s.win_n;
+                if (w_act) { win_n += 1; welf = true; wn = win_n; }
+                if (w_end) {
+                    // compute_next_window
+                    if (s.next_window != np.warmup - s.term_buffer - 1) {
+                        const int ws = s.win_size * 2;
+                        s.win_size = ws;
+                        int nw = wc + ws;
+                        if (nw != np.warmup - s.term_buffer - 1) {
+                            const int boundary = nw + 2 * ws;
+                            if (boundary >= np.warmup - s.term_buffer) nw = np.warmup - s.term_buffer - 1;
+                        }
+                        s.next_window = nw;
+                    }
+                    wend = true; wn = win_n;
+                    win_n = 0;
+                    redo_eps = true;
+                }
+                s.win_n = win_n;
+                s.win_counter = wc + 1;
+            }
+            s.iter = iter + 1;
+            if (warm && iter + 1 == np.warmup) s.eps = exp(s.da_xbar);       // complete_adaptation
+            if (iter + 1 >= np.warmup + np.n_draws) {
+                s.phase = PH_DONE;
+                next = 0;
+            } else if (redo_eps && iter + 1 < np.warmup) {
+                s.phase = PH_EPS; s.eps_dir = 0; s.eps_trials = 0;
+                next = 3;
+            } else {
+                next = 1;
+            }
+        }
+        BDRT_NUTS_PROF(14);
 
         // ---- E: sample update, metric adaptation, draw output, preparation of the next leapfrog -----------------
-        {
-            double acc[1] = {0.0};
-            const bool upds = fl[F_UPDS * NC + c] != 0.0, welf = fl[F_WELF * NC + c] != 0.0;
-            const bool wend = fl[F_WEND * NC + c] != 0.0;
-            const int draw = (int)fl[F_DRAW * NC + c], next = (int)fl[F_NEXT * NC + c];
-            const int dir = (int)fl[F_DIR * NC + c];
-            if (upds || welf || wend || draw >= 0 || next) {
-                const ChainState &s = sts[c];
-                const Philox rng = {np.seed_lo, np.seed_hi, (uint32_t)s.chain_id};
-                const uint32_t iter = (uint32_t)fl[F_ITER * NC + c], trial = (uint32_t)fl[F_TRIAL * NC + c];
-                const uint32_t att = (uint32_t)fl[F_ATT * NC + c];
-                const double wn = fl[F_WN * NC + c];
-                double *TH = vec(V_TH), *Pm = vec(V_P), *G = vec(V_G), *MI = vec(V_MINV);
-                double *THS = vec(V_THS), *GS = vec(V_GS);
-                const double *THQ = vec(V_THQ), *GQ = vec(V_GQ);
-                double *WM = vec(V_WMEAN), *W2 = vec(V_WM2);
-                double *dr = (draw >= 0 && valid) ? a.draws + ((size_t)(c0 + c) * np.n_draws + draw) * D : nullptr;
-                for (int j = g; j < D; j += NG) {
-                    const int i = j * NC + c;
-                    double ths = THS[i], gs = GS[i];
-                    if (upds) { ths = THQ[i]; gs = GQ[i]; THS[i] = ths; GS[i] = gs; }
-                    double mi = MI[i];
-                    if (welf) {            // Welford (stan::math::welford_var_estimator)
-                        const double delta = ths - WM[i];
-                        const double mean = WM[i] + delta / wn;
-                        WM[i] = mean;
-                        W2[i] += (ths - mean) * delta;
+        double kin0 = 0.0;
+        if (upds || welf || wend || draw >= 0 || next) {
+            const uint32_t iter = (uint32_t)s.iter, trial = (uint32_t)s.eps_trials, att = (uint32_t)s.init_attempt;
+            const int dir = s.dir;
+            double *THS = row(V_THS), *GS = row(V_GS);
+            const double *THQ = row(V_THQ), *GQ = row(V_GQ);
+            double *WM = row(V_WMEAN), *W2 = row(V_WM2);
+            double *dr = (draw >= 0 && valid) ? a.draws + ((size_t)(c0 + c) * np.n_draws + draw) * D : nullptr;
+            const double *ET = row(dir > 0 ? V_THP : V_THM), *EP = row(dir > 0 ? V_PP : V_PM), *EG = row(dir > 0 ? V_GP : V_GM);
+            for (int j = l32; j < D; j += 32) {
+                double ths = THS[j], gs = GS[j];
+                if (upds) { ths = THQ[j]; gs = GQ[j]; THS[j] = ths; GS[j] = gs; }
+                double mi = MI[j];
+                if (welf) {            // Welford (stan::math::welford_var_estimator)
+                    const double delta = ths - WM[j];
+                    const double mean = WM[j] + delta / wn;
+                    WM[j] = mean;
+                    W2[j] += (ths - mean) * delta;
+                }
+                if (wend) {            // var_adaptation::learn_variance
+                    const double var = wn > 1.0 ? W2[j] / (wn - 1.0) : 0.0;
+                    mi = (wn / (wn + 5.0)) * var + 1e-3 * (5.0 / (wn + 5.0));
+                    MI[j] = mi;
+                    WM[j] = 0.0; W2[j] = 0.0;
+                }
+                if (dr) dr[j] = ths;
+                if (next == 1 || next == 3) {
+                    // fresh momentum p ~ N(0, M), M = diag(1/Minv); restart from the current sample
+                    const double z = next == 1 ? rng_normal(rng, (uint32_t)j, RNG_MOMENTUM, 0, iter)
+                                               : rng_normal(rng, (uint32_t)j, RNG_EPS_MOMENTUM, trial, iter);
+                    const double p = z / sqrt(mi);
+                    Pm[j] = p; TH[j] = ths; G[j] = gs;
+                    kin0 += mi * p * p;
+                    if (next == 1) {
+                        row(V_THM)[j] = ths; row(V_THP)[j] = ths;
+                        row(V_PM)[j] = p; row(V_PP)[j] = p;
+                        row(V_GM)[j] = gs; row(V_GP)[j] = gs;
+                        row(V_RHO)[j] = p;
                     }
-                    if (wend) {            // var_adaptation::learn_variance
-                        const double var = wn > 1.0 ? W2[i] / (wn - 1.0) : 0.0;
-                        mi = (wn / (wn + 5.0)) * var + 1e-3 * (5.0 / (wn + 5.0));
-                        MI[i] = mi;
-                        WM[i] = 0.0; W2[i] = 0.0;
-                    }
-                    if (dr) dr[j] = ths;
-                    if (next == 1 || next == 3) {
-                        // fresh momentum p ~ N(0, M), M = diag(1/Minv); restart from the current sample
-                        const double z = next == 1 ? rng_normal(rng, (uint32_t)j, RNG_MOMENTUM, 0, iter)
-                                                   : rng_normal(rng, (uint32_t)j, RNG_EPS_MOMENTUM, trial, iter);
-                        const double p = z / sqrt(mi);
-                        Pm[i] = p; TH[i] = ths; G[i] = gs;
-                        acc[0] += mi * p * p;
-                        if (next == 1) {
-                            V[((size_t)V_THM * D) * NC + i] = ths; V[((size_t)V_THP * D) * NC + i] = ths;
-                            V[((size_t)V_PM * D) * NC + i] = p; V[((size_t)V_PP * D) * NC + i] = p;
-                            V[((size_t)V_GM * D) * NC + i] = gs; V[((size_t)V_GP * D) * NC + i] = gs;
-                            V[((size_t)V_RHO * D) * NC + i] = p;
-                        }
-                    } else if (next == 2) {
-                        // continue from the trajectory end in direction dir
-                        TH[i] = V[((size_t)(dir > 0 ? V_THP : V_THM) * D) * NC + i];
-                        Pm[i] = V[((size_t)(dir > 0 ? V_PP : V_PM) * D) * NC + i];
-                        G[i] = V[((size_t)(dir > 0 ? V_GP : V_GM) * D) * NC + i];
-                    } else if (next == 4) {
-                        TH[i] = np.init_radius * (2.0 * rng_uniform(rng, (uint32_t)j, RNG_INIT, 0, att, 0) - 1.0);
-                        Pm[i] = 0.0; G[i] = 0.0;
-                    }
+                } else if (next == 2) {
+                    // continue from the trajectory end in direction dir
+                    TH[j] = ET[j]; Pm[j] = EP[j]; G[j] = EG[j];
+                } else if (next == 4) {
+                    TH[j] = np.init_radius * (2.0 * rng_uniform(rng, (uint32_t)j, RNG_INIT, 0, att, 0) - 1.0);
+                    Pm[j] = 0.0; G[j] = 0.0;
                 }
             }
-            chain_reduce<1>(acc, smem + (size_t)P.XR * NC + (size_t)P.ZR * NC * (1 + P.npar) + (size_t)P.LR * NC,
-                            fl + F_KIN0 * NC, tid);
         }
+        BDRT_NUTS_PROF(15);
 
-        // ---- S3: Hamiltonian at the start point, step for the next round -------------------------------------------
-        if (tid < NC) {
-            ChainState &s = sts[c];
-            const Philox rng = {np.seed_lo, np.seed_hi, (uint32_t)s.chain_id};
-            const int next = (int)fl[F_NEXT * NC + c];
+        // ---- S3: Hamiltonian at the start point ---------------------------------------------------------------------
+        if (next == 1 || next == 3) {
+            kin0 = half_sum(kin0);
+            s.H0 = -s.lps + 0.5 * kin0;
             if (next == 1) {
-                s.H0 = -s.lps + 0.5 * fl[F_KIN0 * NC + c];
                 s.lsw = 0.0; s.lsw_sub = -INFINITY; s.depth = 0; s.leaf = 0; s.nleaves = 1;
                 s.n_leap_iter = 0; s.sum_metro = 0.0;
                 s.dir = rng_uniform(rng, 0, RNG_DIRECTION, 0, 0, (uint32_t)s.iter) > 0.5 ? 1 : -1;
-            } else if (next == 3) {
-                s.H0 = -s.lps + 0.5 * fl[F_KIN0 * NC + c];
             }
-            const bool on = s.phase == PH_INIT || s.phase == PH_EPS || s.phase == PH_TREE;
-            fl[F_ACT * NC + c] = on ? 1.0 : 0.0;
-            double en = 0.0;
-            if (s.phase == PH_EPS) en = s.eps;
-            else if (s.phase == PH_TREE) en = s.dir * s.eps;
-            fl[F_EPS * NC + c] = en;
         }
-        __syncthreads();
+        BDRT_NUTS_PROF(16);
     }
 
     // ---- write the chain states back -----------------------------------------------------------------------------
     __syncthreads();
-    if (tid < NC && valid) a.states[c0 + c] = sts[c];
-    if (tid < NC) {
-        unsigned long long x = my_leaps;
-        for (int off = 8; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        if (tid == 0 && x) atomicAdd(a.leap_counter, x);
+    if (l32 == 0 && valid) a.states[c0 + c] = s;
+    {
+        unsigned long long x = my_leaps;      // non-zero only in lane 0 of each half-wave
+        x += __shfl_xor(x, 32);
+        if (lane == 0 && x) atomicAdd(a.leap_counter, x);
     }
     {
-        const int ph = (tid < NC) ? sts[c].phase : PH_DONE;
+        const int ph = s.phase;
         const int busy = __syncthreads_or(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE);
         if (tid == 0 && !busy) atomicAdd(a.done_counter, 1);
     }
@@ -497,11 +463,12 @@ struct Sampler {
     int *d_done = nullptr;
     unsigned long long *d_leaps = nullptr;
     int rounds_default = 256;
+    long long *d_prof = nullptr;
 };
 
 static size_t nuts_lds_bytes(const DevProblem &P)
 {
-    return (lds_doubles(P) + (size_t)F_COUNT * NC) * sizeof(double) + NC * sizeof(ChainState) + NC * sizeof(int) + 16;
+    return (lds_doubles(P) + (size_t)NC) * sizeof(double) + NC * sizeof(ChainState) + NC * sizeof(int) + 16;
 }
 
 }  // namespace bdrt
@@ -533,6 +500,7 @@ void bdrt_sampler_destroy(bdrt_sampler *s)
     if (S.args.lp_draws) hipFree(S.args.lp_draws);
     if (S.d_done) hipFree(S.d_done);
     if (S.d_leaps) hipFree(S.d_leaps);
+    if (S.d_prof) hipFree(S.d_prof);
     if (S.stream) hipStreamDestroy(S.stream);
     delete s;
 }
@@ -563,7 +531,9 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     for (int u = 0; u < n_units; ++u)
         if (spec && (spec[u] < 0 || spec[u] >= P.dev.n_spectra)) return fail("bdrt_sampler_create: spectrum index out of range");
 
-    const size_t nvec = (size_t)S.n_wg * V_COUNT * S.D * NC;
+    const int DS = (S.D + 31) / 32 * 32;
+    S.args.ds = DS;
+    const size_t nvec = (size_t)S.n_wg * V_COUNT * NC * DS;
     std::vector<double> hv(nvec, 0.0);
     std::vector<ChainState> hs((size_t)n_units);
     for (int u = 0; u < n_units; ++u) {
@@ -577,11 +547,11 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         st.lsw_sub = -INFINITY;
         window_init(st, warmup, c.init_buffer, c.term_buffer, c.base_window);
         const int wg = u / NC, cc = u % NC;
-        double *V = hv.data() + (size_t)wg * V_COUNT * S.D * NC;
+        double *V = hv.data() + (size_t)wg * V_COUNT * NC * DS;
         const Philox rng = {S.np.seed_lo, S.np.seed_hi, (uint32_t)st.chain_id};
         for (int j = 0; j < S.D; ++j) {
-            V[((size_t)V_MINV * S.D + j) * NC + cc] = 1.0;
-            V[((size_t)V_TH * S.D + j) * NC + cc] =
+            V[((size_t)V_MINV * NC + cc) * DS + j] = 1.0;
+            V[((size_t)V_TH * NC + cc) * DS + j] =
                 init_theta ? init_theta[(size_t)u * S.D + j]
                            : c.init_radius * (2.0 * rng_uniform(rng, (uint32_t)j, RNG_INIT, 0, 0, 0) - 1.0);
         }
@@ -590,8 +560,8 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     // padded columns of the last workgroup: finite placeholders
     for (int u = n_units; u < S.n_wg * NC; ++u) {
         const int wg = u / NC, cc = u % NC;
-        double *V = hv.data() + (size_t)wg * V_COUNT * S.D * NC;
-        for (int j = 0; j < S.D; ++j) V[((size_t)V_MINV * S.D + j) * NC + cc] = 1.0;
+        double *V = hv.data() + (size_t)wg * V_COUNT * NC * DS;
+        for (int j = 0; j < S.D; ++j) V[((size_t)V_MINV * NC + cc) * DS + j] = 1.0;
     }
     if (hipMalloc((void **)&S.args.vecs, nvec * sizeof(double)) != hipSuccess) return fail("hipMalloc(vecs) failed");
     if (hipMalloc((void **)&S.args.states, hs.size() * sizeof(ChainState)) != hipSuccess) return fail("hipMalloc(states) failed");
@@ -732,6 +702,29 @@ int bdrt_sampler_kernel_time(bdrt_sampler *s, double *ms_total, int64_t *n_launc
     if (ms_total) *ms_total = S.ms_total;
     if (n_launches) *n_launches = S.n_launch;
     if (reset) { S.ms_total = 0.0; S.n_launch = 0; }
+    return 0;
+}
+
+int bdrt_sampler_phase_profile(bdrt_sampler *s, int enable, long long *cycles32)
+{
+    if (!s) return -1;
+    Sampler &S = s->impl;
+    BDRT_HIP(hipStreamSynchronize(S.stream));
+    if (cycles32) {
+        for (int k = 0; k < 32; ++k) cycles32[k] = 0;
+        if (S.d_prof) {
+            std::vector<long long> h((size_t)S.n_wg * 32);
+            BDRT_HIP(hipMemcpy(h.data(), S.d_prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            for (int w = 0; w < S.n_wg; ++w)
+                for (int k = 0; k < 32; ++k) cycles32[k] += h[(size_t)w * 32 + k];
+        }
+    }
+    if (enable && !S.d_prof) {
+        BDRT_HIP(hipMalloc((void **)&S.d_prof, (size_t)S.n_wg * 32 * sizeof(long long)));
+    }
+    if (S.d_prof) BDRT_HIP(hipMemset(S.d_prof, 0, (size_t)S.n_wg * 32 * sizeof(long long)));
+    if (!enable && S.d_prof) { hipFree(S.d_prof); S.d_prof = nullptr; }
+    S.args.prof = S.d_prof;
     return 0;
 }
 

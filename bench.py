@@ -103,6 +103,7 @@ def main():
     ap.add_argument('--chains', type=int, default=CHAINS_PER_SPECTRUM)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--phase-profile', action='store_true', help='print the in-kernel cycle breakdown (perturbs timing)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -170,6 +171,8 @@ def main():
 
     advance(args.warmup)
     sync_all()
+    if args.phase_profile:
+        check(lib.bdrt_sampler_phase_profile(h, 1, None), 'phase_profile')
     ms0 = C.c_double(); nl0 = C.c_int64()
     check(lib.bdrt_sampler_kernel_time(h, C.byref(ms0), C.byref(nl0), 1), 'kernel_time')
     n0 = lib.bdrt_sampler_total_leapfrogs(h)
@@ -186,6 +189,16 @@ def main():
     ms = C.c_double(); nl = C.c_int64()
     check(lib.bdrt_sampler_kernel_time(h, C.byref(ms), C.byref(nl), 0), 'kernel_time')
     evals = float(n1 - n0)
+    if args.phase_profile and rank == 0:
+        cyc = (C.c_longlong * 32)()
+        check(lib.bdrt_sampler_phase_profile(h, 0, cyc), 'phase_profile')
+        names = ['tile:scalars', 'tile:x', 'tile:gemmA', 'tile:Zacc', 'tile:likelihood', 'tile:x2', 'tile:gemmL',
+                 'tile:prior', 'tile:gemmBwd', 'tile:epilogue', 'nuts:A kick-drift', 'nuts:C kick+kin', 'nuts:S1',
+                 'nuts:D tree', 'nuts:S2', 'nuts:E next', 'nuts:S3']
+        tot = float(sum(cyc[:17])) or 1.0
+        n_wg = (n_units + 15) // 16
+        for k, nm in enumerate(names):
+            print('PHASE %-20s %6.2f %%  %9.0f cycles/round' % (nm, 100 * cyc[k] / tot, cyc[k] / n_wg / args.steps), file=sys.stderr)
     lib.bdrt_sampler_destroy(h)
 
     if world > 1:

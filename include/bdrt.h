@@ -176,6 +176,9 @@ int bdrt_sampler_results(bdrt_sampler *s, double *draws_unconstrained, double *l
 int64_t bdrt_sampler_total_leapfrogs(bdrt_sampler *s);
 /* HIP-event time (ms) and launch count of the NUTS kernel accumulated since creation / last reset */
 int bdrt_sampler_kernel_time(bdrt_sampler *s, double *ms_total, int64_t *n_launches, int reset);
+/* phase profile of the NUTS kernel (development aid): cycles32[0..9] = phases of the log-posterior tile, [10..16] =
+ * NUTS stages, summed over workgroups since the last call; enable != 0 switches the in-kernel clock reads on */
+int bdrt_sampler_phase_profile(bdrt_sampler *s, int enable, long long *cycles32);
 /* convenience: create + run + results.  draws [n_units x n_draws x D] */
 int bdrt_sample(bdrt_problem *p, int n_units, const int *spec, const int *chain_id, int warmup, int n_draws,
                 uint64_t seed, const double *init_theta, const bdrt_nuts_control *ctrl, double *draws, double *lp,
