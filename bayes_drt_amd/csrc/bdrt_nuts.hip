@@ -62,6 +62,10 @@ struct NutsArgs {
 // 32*(c%2)..+31); its D-vectors are contiguous rows, lane l handles elements l, l+32, ...  Per-chain dot products are
 // 5-step xor-shuffle reductions, the per-chain scalar logic runs redundantly in the 32 lanes of the half-wave (state
 // in LDS), and no stage between two tile evaluations needs a workgroup barrier.
+// NJ = elements of a D-vector per lane (D <= 32*NJ): compile-time so that every pass over a chain's vectors is fully
+// unrolled into a batch of independent loads followed by the arithmetic (one memory round trip per stage instead of one
+// per element -- the state vectors of 2048+ chains live in HBM/MALL, not in L2).
+template <int NJ>
 __global__ __launch_bounds__(NT) void nuts_kernel(DevProblem P, NutsParams np, NutsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -116,10 +120,17 @@ __global__ __launch_bounds__(NT) void nuts_kernel(DevProblem P, NutsParams np, N
 
         // ---- A: half kick + drift --------------------------------------------------------------------
         if (act) {
-            for (int j = l32; j < D; j += 32) {
-                const double p = Pm[j] + 0.5 * e * G[j];
-                Pm[j] = p;
-                TH[j] += e * MI[j] * p;
+            double pa_[NJ], ga_[NJ], ma_[NJ], th_[NJ];
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) {
+                const int j = l32 + 32 * m, jj = j;
+                pa_[m] = Pm[jj]; ga_[m] = G[jj]; ma_[m] = MI[jj]; th_[m] = TH[jj];
+            }
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) {
+                const int j = l32 + 32 * m;
+                const double p = pa_[m] + 0.5 * e * ga_[m];
+                if (j < D) { Pm[j] = p; TH[j] = th_[m] + e * ma_[m] * p; }
             }
         }
         __syncthreads();
@@ -130,14 +141,27 @@ __global__ __launch_bounds__(NT) void nuts_kernel(DevProblem P, NutsParams np, N
         if (io.prof && tid == 0) tnp = clock64();
 
         // ---- C: second half kick, kinetic energy, finiteness of the gradient -----------------------------
+        // (p, g, Minv of this chain stay in registers from here to the end of stage D)
         double kin = 0.0, nonfin = 0.0;
+        double p_[NJ], g_[NJ], mi_[NJ];
+#pragma unroll
+        for (int m = 0; m < NJ; ++m) { p_[m] = 0.0; g_[m] = 0.0; mi_[m] = 1.0; }
         if (act) {
-            for (int j = l32; j < D; j += 32) {
-                const double gj = G[j];
-                const double p = Pm[j] + 0.5 * e * gj;
-                Pm[j] = p;
-                kin += MI[j] * p * p;
-                nonfin += isfinite(gj) ? 0.0 : 1.0;
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) {
+                const int j = l32 + 32 * m, jj = j;
+                p_[m] = Pm[jj]; g_[m] = G[jj]; mi_[m] = MI[jj];
+            }
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) {
+                const int j = l32 + 32 * m;
+                if (j < D) {
+                    const double p = p_[m] + 0.5 * e * g_[m];
+                    p_[m] = p;
+                    Pm[j] = p;
+                    kin += mi_[m] * p * p;
+                    nonfin += isfinite(g_[m]) ? 0.0 : 1.0;
+                }
             }
         }
         kin = 0.5 * half_sum(kin);
@@ -224,65 +248,86 @@ __global__ __launch_bounds__(NT) void nuts_kernel(DevProblem P, NutsParams np, N
         }
         BDRT_NUTS_PROF(12);
 
-        // ---- D: proposal copy, checkpoints, running rho, U-turn dot products, speculative subtree close ------
-        double chk[NQ_CHK];
-#pragma unroll
-        for (int q = 0; q < NQ_CHK; ++q) chk[q] = 0.0;
-        if (copyq || cur2s || tree) {
+        // ---- D: proposal copy, checkpoints, running rho, U-turn tests, subtree close ----------------------------
+        if (copyq || cur2s) {
             double *THQ = row(V_THQ), *GQ = row(V_GQ), *THS = row(V_THS), *GS = row(V_GS);
-            double *RHOC = row(V_RHOC), *RHO = row(V_RHO);
-            double *CKC = row(V_CKC + (ck < MAXD ? ck : 0)), *CKP = row(V_CKP + (ck < MAXD ? ck : 0));
-            double *THE = row(dir_now > 0 ? V_THP : V_THM), *PE = row(dir_now > 0 ? V_PP : V_PM);
-            double *GE = row(dir_now > 0 ? V_GP : V_GM);
-            const double *PO = row(dir_now > 0 ? V_PM : V_PP);     // momentum at the other end
-            const bool leaf0 = leaf_now == 0;
-            for (int j = l32; j < D; j += 32) {
-                const double th = TH[j], p = Pm[j], gj = G[j];
-                if (copyq) { THQ[j] = th; GQ[j] = gj; }
-                if (cur2s) { THS[j] = th; GS[j] = gj; }
-                if (tree) {
-                    const double mi = MI[j];
-                    const double before = leaf0 ? 0.0 : RHOC[j];
-                    if (even) { CKC[j] = before; CKP[j] = p; }
-                    const double rc = before + p;
-                    RHOC[j] = rc;
+            double th_[NJ];
 #pragma unroll
-                    for (int l = 0; l < MAXD; ++l) {
-                        if (l < nm) {
-                            const int idx = ck - l;
-                            const double rho = rc - V[((size_t)(V_CKC + idx) * NC + c) * DS + j];
-                            chk[2 * l] += mi * V[((size_t)(V_CKP + idx) * NC + c) * DS + j] * rho;
-                            chk[2 * l + 1] += mi * p * rho;
-                        }
-                    }
-                    if (last) {
-                        // speculative close of the subtree: extend the trajectory end and test the whole trajectory
-                        const double rt = RHO[j] + rc;
-                        RHO[j] = rt;
-                        THE[j] = th; PE[j] = p; GE[j] = gj;
-                        chk[2 * MAXD] += mi * PO[j] * rt;
-                        chk[2 * MAXD + 1] += mi * p * rt;
-                    }
+            for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; th_[m] = TH[j]; }
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) {
+                const int j = l32 + 32 * m;
+                if (j < D) {
+                    if (copyq) { THQ[j] = th_[m]; GQ[j] = g_[m]; }
+                    if (cur2s) { THS[j] = th_[m]; GS[j] = g_[m]; }
                 }
             }
         }
-        BDRT_NUTS_PROF(13);
-
-        // ---- S2: validity of the new subtree, trajectory-level decisions, adaptation scalars ---------------------
         if (tree) {
-            bool ok = true;
+            double *RHOC = row(V_RHOC);
+            double rc_[NJ];
+            // running sum of the momenta of the new subtree; checkpoint (sum before, p) at even leaves
+            if (leaf_now == 0) {
 #pragma unroll
-            for (int l = 0; l < MAXD; ++l) {
-                if (l < nm) {
-                    const double a0 = half_sum(chk[2 * l]), a1 = half_sum(chk[2 * l + 1]);
-                    ok = ok && (a0 > 0.0) && (a1 > 0.0);
+                for (int m = 0; m < NJ; ++m) rc_[m] = 0.0;
+            } else {
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; rc_[m] = RHOC[j]; }
+            }
+            if (even) {
+                double *CKC = row(V_CKC + ck), *CKP = row(V_CKP + ck);
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; if (j < D) { CKC[j] = rc_[m]; CKP[j] = p_[m]; } }
+            }
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; rc_[m] += p_[m]; if (j < D) RHOC[j] = rc_[m]; }
+            // generalised U-turn test of every sub-subtree that ends at this (odd) leaf
+            bool ok = true;
+            for (int l = 0; l < nm; ++l) {
+                const double *CKC = row(V_CKC + ck - l), *CKP = row(V_CKP + ck - l);
+                double cc_[NJ], cp_[NJ];
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m, jj = j; cc_[m] = CKC[jj]; cp_[m] = CKP[jj]; }
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) {
+                    const int j = l32 + 32 * m;
+                    if (j < D) {
+                        const double rho = rc_[m] - cc_[m];
+                        a0 += mi_[m] * cp_[m] * rho;
+                        a1 += mi_[m] * p_[m] * rho;
+                    }
                 }
+                a0 = half_sum(a0); a1 = half_sum(a1);
+                ok = ok && (a0 > 0.0) && (a1 > 0.0);
             }
             if (!ok) {
                 endt = 1;                                   // U-turn inside the new subtree: discard it, stop
             } else if (last) {
-                // subtree complete and valid (Stan base_nuts::transition after build_tree)
-                const double t0 = half_sum(chk[2 * MAXD]), t1 = half_sum(chk[2 * MAXD + 1]);
+                // subtree complete and valid (Stan base_nuts::transition after build_tree): extend the trajectory
+                double *RHO = row(V_RHO);
+                double *THE = row(dir_now > 0 ? V_THP : V_THM), *PE = row(dir_now > 0 ? V_PP : V_PM);
+                double *GE = row(dir_now > 0 ? V_GP : V_GM);
+                const double *PO = row(dir_now > 0 ? V_PM : V_PP);     // momentum at the other end
+                double rt_[NJ], po_[NJ], th_[NJ];
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) {
+                    const int j = l32 + 32 * m, jj = j;
+                    rt_[m] = RHO[jj]; po_[m] = PO[jj]; th_[m] = TH[jj];
+                }
+                double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) {
+                    const int j = l32 + 32 * m;
+                    if (j < D) {
+                        const double rt = rt_[m] + rc_[m];
+                        RHO[j] = rt;
+                        THE[j] = th_[m]; PE[j] = p_[m]; GE[j] = g_[m];
+                        t0 += mi_[m] * po_[m] * rt;
+                        t1 += mi_[m] * p_[m] * rt;
+                    }
+                }
+                t0 = half_sum(t0); t1 = half_sum(t1);
                 const int depth = s.depth + 1;
                 s.depth = depth;
                 const double lsw = s.lsw, lsw_sub = s.lsw_sub;
@@ -531,7 +576,8 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     for (int u = 0; u < n_units; ++u)
         if (spec && (spec[u] < 0 || spec[u] >= P.dev.n_spectra)) return fail("bdrt_sampler_create: spectrum index out of range");
 
-    const int DS = (S.D + 31) / 32 * 32;
+    const int DS = S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : 32 * 27);   // = 32*NJ of the kernel instantiation
+    if (S.D > 32 * 27) { set_error("bdrt_sampler_create: D = %d > 864 not supported", S.D); bdrt_sampler_destroy(s); return nullptr; }
     S.args.ds = DS;
     const size_t nvec = (size_t)S.n_wg * V_COUNT * NC * DS;
     std::vector<double> hv(nvec, 0.0);
@@ -581,8 +627,9 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     static size_t attr_bytes = 0;
     if (S.lds_bytes > attr_bytes) {
-        hipError_t e = hipFuncSetAttribute((const void *)nuts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)S.lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)nuts_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nuts_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nuts_kernel<27>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(nuts_kernel, %zu B dynamic LDS) failed: %s", S.lds_bytes, hipGetErrorString(e));
             bdrt_sampler_destroy(s);
@@ -619,7 +666,9 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
     BDRT_HIP(hipEventCreate(&e0));
     BDRT_HIP(hipEventCreate(&e1));
     BDRT_HIP(hipEventRecord(e0, S.stream));
-    hipLaunchKernelGGL(nuts_kernel, dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, S.prob->dev, S.np, S.args);
+    if (S.D <= 32 * 11) hipLaunchKernelGGL(nuts_kernel<11>, dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, S.prob->dev, S.np, S.args);
+    else if (S.D <= 32 * 16) hipLaunchKernelGGL(nuts_kernel<16>, dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, S.prob->dev, S.np, S.args);
+    else hipLaunchKernelGGL(nuts_kernel<27>, dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, S.prob->dev, S.np, S.args);
     BDRT_HIP(hipGetLastError());
     BDRT_HIP(hipEventRecord(e1, S.stream));
     S.pending.emplace_back(e0, e1);
