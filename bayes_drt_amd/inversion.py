@@ -1,0 +1,1016 @@
+"""Inverter -- the reference's user-facing API (bayes_drt/inversion.py, class Inverter) on the MI355X hot path.
+
+Same constructor, `fit`, `ridge_fit`, `predict_*`, `coef_percentile`, `check_outliers` signatures, attribute names
+and error behaviour as the reference, so that notebooks written for `bayes_drt.inversion.Inverter` run unchanged
+with `from bayes_drt_amd.inversion import Inverter`.  What runs where:
+  * A / L / M matrices          -> GPU (matrices.py -> bdrt_build_A/_L/_M)
+  * `fit` MAP / HMC             -> GPU (stan_models.py -> engine.StanModel -> bdrt_optimize / bdrt_sampler_*)
+  * `ridge_fit` Gram + QP       -> bdrt_gram (MFMA) + bdrt_qp_box (interior point, replaces cvxopt)
+  * scaling, weights, Stan data dict, prediction algebra: numpy on the host (not hot: microseconds)
+Out of scope (drift fits, MultiDist, fitY/SA, peak fitting, plotting, file loaders) raise
+NotImplementedError instead of silently doing something else.
+"""
+import os
+import warnings
+from copy import deepcopy
+
+import numpy as np
+
+from . import _lib
+from ._lib import f64, ptr
+from .matrices import construct_A, construct_L, construct_M
+from .stan_models import load_pickle
+from .utils import get_outlier_thresh, is_loguniform, rel_round
+
+script_dir = os.path.dirname(os.path.realpath(__file__))
+
+
+def _same(a, b):
+    try:
+        np.testing.assert_equal(a, b)
+        return True
+    except AssertionError:
+        return False
+
+
+def _gaussian(y, epsilon):
+    return np.exp(-(epsilon * y) ** 2)
+
+
+class _QPResult(dict):
+    """Mapping with the two keys the reference reads from cvxopt's result ('x', 'primal objective')."""
+
+
+class Inverter:
+    def __init__(self, basis_freq=None, basis='gaussian', epsilon=None, fit_inductance=True,
+                 distributions={'DRT': {'kernel': 'DRT'}}):
+        """See the reference docstring (bayes_drt/inversion.py:29-49): basis_freq (10 points per decade recommended),
+        basis ('gaussian' only), epsilon (None: 1/mean spacing of ln tau), fit_inductance (ridge_fit only),
+        distributions {name: {kernel, dist_type, symmetry, bc, ct, k_ct, basis_freq, epsilon, x_scale}}."""
+        self._recalc_mat = True
+        self.distribution_matrices = {}
+        self.set_basis_freq(basis_freq)
+        self.set_basis(basis)
+        self.set_epsilon(epsilon)
+        self.set_fit_inductance(fit_inductance)
+        self.set_distributions(deepcopy(distributions))
+        self._cached_distributions = self.distributions.copy()
+        self.f_train = [0]
+        self.Z_train = None
+        self.f_pred = None
+        self._Z_scale = 1.0
+        self._init_params = {}
+        self.distribution_fits = {}
+        self._iter_history = None
+
+    # ------------------------------------------------------------------ distributions (reference :66-137)
+    def set_distributions(self, distributions):
+        for name, info in distributions.items():
+            if info['kernel'] == 'DRT':
+                if info.get('dist_type', 'series') != 'series':
+                    warnings.warn("dist_type for DRT kernel must be series. Overwriting supplied dist_type '{}' for "
+                                  "distribution '{}' with 'series'".format(name, info['dist_type']))
+                info['dist_type'] = 'series'
+                bad = np.intersect1d(list(info.keys()), ['symmetry', 'bc', 'ct', 'k_ct'])
+                if len(bad) > 0:
+                    warnings.warn("The following keys are invalid for distribution '{}': {}.\n These keys will be "
+                                  "ignored".format(name, bad))
+            elif info['kernel'] == 'DDT':
+                if info.get('dist_type', 'parallel') not in ['series', 'parallel']:
+                    raise ValueError("Invalid dist_type '{}' for distribution '{}'".format(info.get('dist_type', 'NA'), name))
+                elif info.get('symmetry', 'planar') not in ['planar', 'spherical']:
+                    raise ValueError("Invalid symmetry '{}' for distribution '{}'".format(info.get('symmetry', 'NA'), name))
+                elif info.get('bc', 'transmissive') not in ['transmissive', 'blocking']:
+                    raise ValueError("Invalid bc '{}' for distribution '{}'".format(info.get('bc', 'NA'), name))
+                elif info.get('ct', True) not in [True, False]:
+                    raise ValueError("Invalid ct {} for distribution '{}'".format(info['ct'], name))
+                if info.get('ct', False) == True and 'k_ct' not in info.keys():
+                    raise ValueError("k_ct must be supplied for distribution '{}' if ct==True".format(name))
+                # defaults as coded in the reference (:119), which differ from its docstring
+                full = {'dist_type': 'parallel', 'symmetry': 'planar', 'bc': 'blocking', 'ct': False}
+                full.update(info)
+                distributions[name] = full
+            else:
+                raise ValueError("Invalid kernel '{}' for distribution '{}'".format(info['kernel'], name))
+            if name not in self.distribution_matrices.keys():
+                self.distribution_matrices[name] = {}
+        self._distributions = distributions
+        self._recalc_mat = True
+        self.f_pred = None
+
+    def get_distributions(self):
+        return self._distributions
+
+    distributions = property(get_distributions, set_distributions)
+
+    # ------------------------------------------------------------------ properties (reference :4069-4110)
+    def get_basis_freq(self):
+        return self._basis_freq
+
+    def set_basis_freq(self, basis_freq):
+        self._basis_freq = basis_freq
+        self._recalc_mat = True
+        self.f_pred = None
+
+    basis_freq = property(get_basis_freq, set_basis_freq)
+
+    def get_basis(self):
+        return self._basis
+
+    def set_basis(self, basis):
+        if basis != 'gaussian':
+            raise ValueError(f'Invalid basis {basis}. Options are gaussian')
+        self._basis = basis
+        self._recalc_mat = True
+        self.f_pred = None
+
+    basis = property(get_basis, set_basis)
+
+    def get_epsilon(self):
+        return self._epsilon
+
+    def set_epsilon(self, epsilon, override_distributions=False):
+        self._epsilon = epsilon
+        self._recalc_mat = True
+        if override_distributions:
+            for name in self.distributions.keys():
+                self.distributions[name]['epsilon'] = epsilon
+        self.f_pred = None
+
+    epsilon = property(get_epsilon, set_epsilon)
+
+    def get_fit_inductance(self):
+        return self._fit_inductance_
+
+    def set_fit_inductance(self, fit_inductance):
+        self._fit_inductance_ = fit_inductance
+
+    fit_inductance = property(get_fit_inductance, set_fit_inductance)
+
+    # ================================================================== ridge (reference :142-1067)
+    def ridge_fit(self, frequencies, Z, part='both', penalty='discrete', reg_ord=2, L1_penalty=0, scale_Z=True,
+                  nonneg=True, weights=None, preset=None, hyper_lambda=True, hl_solution='analytic', hl_beta=2.5,
+                  hl_fbeta=None, lambda_0=1e-2, cv_lambdas=np.logspace(-10, 5, 31), hyper_weights=False, hw_beta=2,
+                  hw_wbar=1, xtol=1e-3, max_iter=20, hyper_a=False, alpha_a=2, hl_beta_a=2, hyper_b=False, sb=1,
+                  correct_phase_offset=False, IERange=None, lambda_phz=1, init_phase_offset=False, x0=None, dZ=False,
+                  dZ_power=0.5):
+        """Hierarchical ridge fit of a single distribution (arguments as in the reference, :142-290)."""
+        if preset is not None:
+            if preset not in ('Ciucci', 'Huang'):
+                raise ValueError('Invalid preset {}. Options are {}'.format(preset, ['Ciucci', 'Huang']))
+            if preset == 'Ciucci':
+                penalty, lambda_0, hl_fbeta = 'discrete', 'cv', 0.1
+            else:
+                penalty, hl_beta, lambda_0, weights = 'integral', 2.5, 1e-2, 'modulus'
+        if penalty == 'discrete':
+            if np.min(hl_beta) <= 1:
+                raise ValueError('hl_beta must be greater than 1 for penalty cholesky and discrete')
+        elif penalty == 'integral':
+            if np.min(hl_beta) <= 2:
+                raise ValueError('hl_beta must be greater than 2 for penalty integral')
+        elif penalty == 'cholesky':
+            raise NotImplementedError("penalty='cholesky' is not implemented (the reference does not recommend it)")
+        else:
+            raise ValueError(f'Invalid penalty argument {penalty}. Options are integral, discrete, and cholesky')
+        if hyper_lambda and hyper_weights:
+            raise ValueError('hyper_lambda and hyper_weights fits cannot be performed simultaneously')
+        if len(self.distributions) > 1:
+            raise ValueError('ridge_fit cannot be used to fit multiple distributions')
+        if correct_phase_offset or hyper_a or hyper_b or hl_solution != 'analytic':
+            raise NotImplementedError('correct_phase_offset / hyper_a / hyper_b / hl_solution="lm" are outside the '
+                                      'hot-path scope of this build')
+        self.distribution_fits = {}
+        if isinstance(lambda_0, str) and lambda_0 == 'cv':
+            lambda_0 = self.ridge_ReImCV(frequencies, Z, lambdas=cv_lambdas, penalty=penalty, hyper_lambda=hyper_lambda,
+                                         hl_solution=hl_solution, hl_beta=hl_beta, hl_fbeta=hl_fbeta, reg_ord=reg_ord,
+                                         L1_penalty=L1_penalty, x0=x0, weights=weights, xtol=xtol, max_iter=max_iter,
+                                         scale_Z=scale_Z, nonneg=nonneg, dZ=dZ, dZ_power=dZ_power)
+        name = list(self.distributions.keys())[0]
+        info = self.distributions[name]
+        if info['kernel'] != 'DRT' and dZ:
+            warnings.warn('dZ should only be set to True for DRT recovery. Proceeding with dZ=False')
+            dZ = False
+        Z = np.asarray(Z)
+        series = info['dist_type'] == 'series'
+        target = Z if series else 1 / Z
+        frequencies, target_s, WT_re, WT_im, W_re, W_im, dist_mat = self._prep_matrices(frequencies, target, part, weights,
+                                                                                       dZ, scale_Z, penalty, 'ridge')
+        info = self.distributions[name]
+        if not series and scale_Z:
+            # admittance target: the scale is defined on Z, the target is 1/Z_scaled (reference :378-383)
+            target_s = 1 / self._scale_Z(1 / self.Z_train, 'ridge')
+            WT_re, WT_im = W_re @ target_s.real, W_im @ target_s.imag
+        mats = dist_mat[name]
+        A_re, A_im, B = mats['A_re'], mats['A_im'], mats['B']
+        tau, epsilon = info['tau'], info['epsilon']
+        K = A_re.shape[1]
+        off = 2 if series else 0                    # augmented unknowns [R_inf, L/1e-4, x] for series (:402-417)
+        n = K + off
+        if series:
+            Ar = np.zeros((len(frequencies), n)); Ar[:, 2:] = A_re; Ar[:, 0] = 1
+            Ai = np.zeros((len(frequencies), n)); Ai[:, 2:] = A_im
+            if self.fit_inductance:
+                Ai[:, 1] = 2 * np.pi * frequencies * 1e-4
+            A_re, A_im = Ar, Ai
+            if B is not None:
+                B = np.hstack((np.zeros((B.shape[0], 2)), B))
+
+        def pad(Mx):
+            out = np.zeros((n, n)); out[off:, off:] = Mx
+            return out
+        if penalty == 'integral':
+            base = [pad(mats['M%d' % o]) for o in (0, 1, 2)]
+            Ls = None
+        else:
+            Ls = [np.hstack((np.zeros((K, off)), mats['L%d' % o])) for o in (0, 1, 2)]
+            base = [L.T @ L for L in Ls]
+        if isinstance(reg_ord, (int, np.integer)):
+            ro = np.zeros(3); ro[int(reg_ord)] = 1
+            reg_ord = ro
+        reg_ord = np.asarray(reg_ord, dtype=float)
+        L1_vec = np.ones(n) * np.pi ** 0.5 / epsilon * L1_penalty
+        if series:
+            L1_vec[0:2] = 0
+        hl_beta = np.array([hl_beta] * 3, dtype=float) if np.ndim(hl_beta) == 0 else np.asarray(hl_beta, dtype=float)
+        a_list = hl_beta / 2
+        if penalty == 'integral':
+            b_list = 0.5 * (2 * a_list - 2) / lambda_0
+            lam0s = [(2 * a - 2) / (2 * b) * np.ones(n) for a, b in zip(a_list, b_list)]
+        else:
+            b_list = 0.5 * (2 * a_list - 1) / lambda_0
+            lam0s = [(2 * a - 1) / (2 * b) * np.ones(n) for a, b in zip(a_list, b_list)]
+        betas = [2 * a * np.ones(n) for a in a_list]
+
+        lo = np.zeros(n) if nonneg else np.concatenate([np.zeros(min(2, n)), -10 * np.ones(n - min(2, n))])
+        use_re, use_im = part in ('both', 'real'), part in ('both', 'imag')
+        if part not in ('both', 'real', 'imag'):
+            raise ValueError(f"Invalid part {part}. Options are 'both', 'real', or 'imag'")
+
+        def gram(W_re_, W_im_, T_re_, T_im_):
+            """G = sum over the fitted parts of (W A)^T (W A), g = sum of (W A)^T (W T): on the GPU (bdrt_gram)."""
+            rows, tg = [], []
+            if use_re:
+                rows.append(W_re_ @ A_re); tg.append(T_re_)
+            if use_im:
+                rows.append(W_im_ @ A_im); tg.append(T_im_)
+            WA = np.ascontiguousarray(np.vstack(rows)); WT = np.ascontiguousarray(np.concatenate(tg))
+            lib = _lib.require_gpu()
+            G = np.empty((n, n)); g = np.empty(n)
+            _lib.check(lib.bdrt_gram(ptr(WA), ptr(WT), WA.shape[0], n, None, None, ptr(G), ptr(g)), 'bdrt_gram')
+            return G, -g                                   # bdrt_gram returns q = -(WA^T WT)
+
+        def solve(G, g, L2_mat):
+            lib = _lib.load_library()
+            P = np.ascontiguousarray(G + L2_mat); q = np.ascontiguousarray(-g + L1_vec)
+            x = np.empty(n); obj = np.zeros(1)
+            _lib.check(lib.bdrt_qp_box(ptr(P), ptr(q), ptr(np.ascontiguousarray(lo)), n, ptr(x), ptr(obj)), 'bdrt_qp_box')
+            return _QPResult({'x': x, 'primal objective': float(obj[0])}), P, q
+
+        def penalty_matrix(lams, dz):
+            D = 1.0 / dz
+            out = np.zeros((n, n))
+            for Mb, lam, frac in zip(base, lams, reg_ord):
+                if frac > 0:
+                    sc = D * np.sqrt(lam)
+                    out += frac * (sc[:, None] * Mb * sc[None, :])
+            return out
+
+        dZ_re = np.ones(n)
+        lam_vectors = [np.ones(n) * lambda_0 for _ in range(3)]
+        if hyper_lambda or hyper_weights:
+            self._iter_history = []
+        if hyper_lambda:
+            G, g = gram(W_re, W_im, WT_re, WT_im)
+            coef = np.asarray(x0, dtype=float) if x0 is not None else np.zeros(n) + 1e-6
+            it = 0
+            while it < max_iter:
+                prev = coef.copy()
+                if dZ and it > 0:
+                    dZ_raw = B @ prev / (np.mean(np.diff(np.log(tau))) / 0.23026)
+                    dZ_re[off:] = np.abs(dZ_raw) ** dZ_power
+                    dZ_re[np.abs(dZ_re < 1e-8)] = 1e-8      # (sic) the reference's mask, :527
+                xs = prev / dZ_re
+                for i in range(3):
+                    if reg_ord[i] <= 0:
+                        continue
+                    if penalty == 'discrete':
+                        Lx2 = (Ls[i] @ xs) ** 2
+                        if hl_fbeta is not None:           # _hyper_lambda_fbeta (:956-964)
+                            lam = lambda_0 / (Lx2 / (np.max(Lx2) * hl_fbeta) + 1)
+                        else:                              # _hyper_lambda_discrete (:947-954)
+                            lam = 1 / (Lx2 / (betas[i][off:] - 1) + 1 / lam0s[i][off:])
+                        lam_vectors[i] = np.hstack((np.ones(off), lam))
+                    else:                                  # _hyper_lambda_integral (:973-983)
+                        factor = (100, 10, 1)[i]
+                        c = factor * xs
+                        sl = np.sqrt(lam_vectors[i])
+                        xlm = (c * sl)[:, None] * base[i] * c[None, :]
+                        xlm = xlm - np.diag(np.diagonal(xlm))
+                        Cv = np.sum(xlm, axis=0)
+                        a = betas[i] / 2
+                        b = 0.5 * (2 * a - 2) / lam0s[i]
+                        d = c ** 2 * np.diagonal(base[i]) + 2 * b
+                        lam = (Cv ** 2 - np.sign(Cv) * Cv * np.sqrt(4 * d * (2 * a - 2) + Cv ** 2) + 2 * d * (2 * a - 2)) / (2 * d ** 2)
+                        lam[lam <= 0] = 1e-15
+                        lam_vectors[i] = lam
+                L2_mat = penalty_matrix(lam_vectors, dZ_re)
+                result, P, q = solve(G, g, L2_mat)
+                coef = np.array(result['x'])
+                cost = 0.5 * coef @ P @ coef + q @ coef
+                self._iter_history.append({'lambda_vectors': [l.copy() for l in lam_vectors], 'coef': coef.copy(),
+                                           'fun': result['primal objective'], 'cost': cost, 'result': result,
+                                           'dZ_re': dZ_re.copy()})
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    delta = (coef - prev) / prev
+                if series and (self.fit_inductance == False or part == 'real'):
+                    delta[1] = 0
+                if np.mean(np.abs(delta)) < xtol:
+                    break
+                elif it == max_iter - 1:
+                    warnings.warn(f'Hyperparametric solution did not converge within {max_iter} iterations')
+                it += 1
+            self.distribution_fits[name] = {'opt_result': result, 'coef': coef.copy(),
+                                            'lambda_vectors': [l.copy() for l in lam_vectors], 'cost': cost}
+        elif hyper_weights:
+            coef = np.zeros(n) + 1e-6
+            wbar = self._format_weights(frequencies, target_s, hw_wbar, part)
+            w = wbar
+            L2_mat = penalty_matrix(lam_vectors, dZ_re)
+            it = 0
+            while it < max_iter:
+                prev = coef.copy()
+                if it > 0:                                 # _hyper_weights (:1010-1041)
+                    zr, zi = hw_beta / np.real(wbar), hw_beta / np.imag(wbar)
+                    res = target_s - (A_re @ coef + 1j * (A_im @ coef))
+                    w = (np.real(wbar) - 1 / zr) / (res.real ** 2 / zr + 1) + 1j * (np.imag(wbar) - 1 / zi) / (res.imag ** 2 / zi + 1)
+                Wr, Wi = np.diag(np.real(w)), np.diag(np.imag(w))
+                G, g = gram(Wr, Wi, Wr @ target_s.real, Wi @ target_s.imag)
+                result, P, q = solve(G, g, L2_mat)
+                coef = np.array(result['x'])
+                cost = 0.5 * coef @ P @ coef + q @ coef
+                self._iter_history.append({'weights': w.copy(), 'coef': coef.copy(), 'fun': result['primal objective'],
+                                           'cost': cost, 'result': result, 'dZ_re': dZ_re.copy()})
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    delta = (coef - prev) / prev
+                if series and self.fit_inductance == False:
+                    delta[1] = 0
+                if np.mean(np.abs(delta)) < xtol:
+                    break
+                elif it == max_iter - 1:
+                    warnings.warn(f'Hyperparametric solution did not converge within {max_iter} iterations')
+                it += 1
+            self.distribution_fits[name] = {'opt_result': result, 'coef': coef.copy(), 'weights': w.copy(), 'cost': cost}
+        else:
+            G, g = gram(W_re, W_im, WT_re, WT_im)
+            result, P, q = solve(G, g, penalty_matrix(lam_vectors, dZ_re))
+            coef = np.array(result['x'])
+            self.distribution_fits[name] = {'opt_result': result, 'coef': coef.copy(),
+                                            'cost': 0.5 * coef @ P @ coef + q @ coef}
+        fitc = self.distribution_fits[name]['coef']
+        # the unfitted part's offset is recovered by least squares on the other part (:841-863); both are 1-D linear
+        if part == 'imag' and series:
+            fitc[0] = np.mean(target_s.real - A_re[:, 2:] @ fitc[2:])
+        elif part == 'real' and series and self.fit_inductance:
+            col = frequencies * 2 * np.pi * 1e-4
+            fitc[1] = col @ (target_s.imag - A_im[:, 2:] @ fitc[2:]) / (col @ col)
+        if scale_Z:
+            self.distribution_fits[name]['scaled_coef'] = fitc.copy()
+            self.distribution_fits[name]['coef'] = self._rescale_coef(fitc, info['dist_type'])
+        fitc = self.distribution_fits[name]['coef']
+        if series:
+            fitc[1] *= 1e-4
+            if not self.fit_inductance:
+                fitc[1] = 0
+            self.R_inf, self.inductance = fitc[0], fitc[1]
+            self.distribution_fits[name]['coef'] = fitc[2:]
+        else:
+            self.R_inf, self.inductance = 0, 0
+        self.fit_type = 'ridge'
+
+    def ridge_ReImCV(self, frequencies, Z, lambdas=np.logspace(-10, 5, 31), **kw):
+        """Re-Im cross-validation for lambda_0 (reference :902-945)."""
+        frequencies, Z = np.asarray(frequencies), np.asarray(Z)
+        recv, imcv = np.zeros_like(lambdas), np.zeros_like(lambdas)
+        for i, lam in enumerate(lambdas):
+            self.ridge_fit(frequencies, Z, part='real', lambda_0=lam, **kw)
+            Zi = np.imag(self.predict_Z(frequencies))
+            self.ridge_fit(frequencies, Z, part='imag', lambda_0=lam, **kw)
+            Zr = np.real(self.predict_Z(frequencies))
+            recv[i], imcv[i] = np.sum((Z.real - Zr) ** 2), np.sum((Z.imag - Zi) ** 2)
+        tot = recv + imcv
+        best = lambdas[np.argmin(tot)]
+        if best == np.min(lambdas) or best == np.max(lambdas):
+            warnings.warn('Optimal lambda_0 {} determined by Re-Im CV is at the boundary of the evaluated range. Re-run '
+                          'with an expanded lambda_0 range to obtain an accurate estimate of the optimal lambda_0.'.format(best))
+        self.cv_result = {'lambda': lambdas.copy(), 'recv': recv, 'imcv': imcv, 'totcv': tot}
+        return best
+
+    # ================================================================== Bayesian fit (reference :1072-1289)
+    def fit(self, frequencies, Z, part='both', scale_Z=True, nonneg=False, outliers=False, check_outliers=True,
+            init_from_ridge=False, ridge_kw={}, sigma_min=0.002, inductance_scale=1, outlier_lambda=None,
+            mode='optimize', random_seed=1234, max_iter=50000, warmup=200, samples=200, chains=2, add_stan_data={},
+            model_str=None, fitY=False, SA=False, SASY=False):
+        """Fit the distribution(s) with the calibrated hierarchical Bayesian model: mode='optimize' (MAP) or
+        'sample' (NUTS).  Arguments as in the reference (:1072-1152)."""
+        if fitY or SA or SASY:
+            raise NotImplementedError('fitY / SA / SASY are experimental flags of the reference ("for testing only") and '
+                                      'are not part of this build')
+        if part != 'both':
+            raise NotImplementedError("fit() supports part='both' (the reference's Stan data for other parts is "
+                                      "inconsistent with its model files)")
+        if mode not in ('optimize', 'sample'):
+            raise ValueError("mode must be 'optimize' or 'sample'")
+        if init_from_ridge:
+            if len(self.distributions) > 1:
+                raise ValueError('Ridge initialization can only be performed for single-distribution fits')
+            init = self._get_init_from_ridge(frequencies, Z, mode, nonneg=nonneg, outliers=outliers,
+                                             inductance_scale=inductance_scale, ridge_kw=ridge_kw)
+            self._init_params = init()
+        else:
+            init = 'random'
+        frequencies, Z_scaled, WZ_re, WZ_im, W_re, W_im, dist_mat = self._prep_matrices(
+            frequencies, Z, part, weights=None, dZ=False, scale_Z=scale_Z, penalty='discrete', fit_type='map')
+        Z_sorted = self.Z_train
+        if outliers == 'auto':
+            idx = self.check_outliers(frequencies, Z_sorted, threshold=4, use_existing_fit=bool(init_from_ridge), **ridge_kw)
+            if len(idx) > 0:
+                outliers = True
+                warnings.warn('Identified likely outliers at indices {}, f={} Hz. An outlier-robust error model will be '
+                              'used. To disable this behavior, pass outliers=False.'.format(idx, frequencies[idx]))
+                # check_outliers may have re-run ridge_fit: restore the 'discrete' matrices for the Bayesian fit
+                frequencies, Z_scaled, WZ_re, WZ_im, W_re, W_im, dist_mat = self._prep_matrices(
+                    frequencies, Z_sorted, part, weights=None, dZ=False, scale_Z=scale_Z, penalty='discrete', fit_type='map')
+            else:
+                outliers = False
+                frequencies, Z_scaled, WZ_re, WZ_im, W_re, W_im, dist_mat = self._prep_matrices(
+                    frequencies, Z_sorted, part, weights=None, dZ=False, scale_Z=scale_Z, penalty='discrete', fit_type='map')
+        if model_str is None:
+            model, model_str = self._get_stan_model(nonneg, outliers, False, None, fitY, SA)
+        else:
+            model = load_pickle(os.path.join(script_dir, 'stan_model_files', model_str))
+        self.stan_model_name = model_str
+        model_type = model_str.split('_')[0]
+        if model_type == 'Series-Parallel' and nonneg == False:
+            warnings.warn('For mixed series-parallel models, it is highly recommended to set nonnneg_drt=True')
+        dat = self._prep_stan_data(frequencies, Z_scaled, part, model_type, dist_mat, outliers, sigma_min, mode=mode,
+                                   inductance_scale=inductance_scale, outlier_lambda=outlier_lambda, fitY=fitY, SA=SA,
+                                   SASY=SASY)
+        dat.update(add_stan_data)
+        if outliers and model_type == 'Series':
+            dat['N'] = len(frequencies)        # package Series outlier models declare N = Nf (:1208-1211)
+        self._stan_input = dat.copy()
+        if mode == 'optimize':
+            self._opt_result = model.optimizing(dat, iter=max_iter, seed=random_seed, init=init)
+            self._opt_report = model.last_report
+        else:
+            self._sample_result = model.sampling(dat, warmup=warmup, iter=warmup + samples, chains=chains,
+                                                 seed=random_seed, init=init,
+                                                 control={'adapt_delta': 0.9, 'adapt_t0': 10})
+        self.distribution_fits = {}
+        self.error_fit = {}
+        if model_type in ['Series', 'Parallel']:
+            name = [k for k, v in self.distributions.items() if v['dist_type'] == model_type.lower()][0]
+            self.distribution_fits[name] = {'coef': self._extract_parameter('x', self.distributions[name]['dist_type'], mode)}
+        elif model_type == 'Series-Parallel':
+            for name, info in self.distributions.items():
+                key = 'xs' if info['dist_type'] == 'series' else 'xp'
+                self.distribution_fits[name] = {'coef': self._extract_parameter(key, info['dist_type'], mode)}
+        elif model_type == 'Series-2Parallel':
+            for name, info in self.distributions.items():
+                key = 'xs' if info['dist_type'] == 'series' else 'xp%d' % info['order']
+                self.distribution_fits[name] = {'coef': self._extract_parameter(key, info['dist_type'], mode)}
+        self.R_inf = self._extract_parameter('Rinf', 'series', mode)
+        self.inductance = self._extract_parameter('induc', 'series', mode)
+        self.error_fit['sigma_min'] = self._rescale_coef(sigma_min, 'series')
+        for p_ in ['sigma_tot', 'sigma_res']:
+            self.error_fit[p_] = self._extract_parameter(p_, 'series', mode)
+        for p_ in ['alpha_prop', 'alpha_re', 'alpha_im']:
+            self.error_fit[p_] = self._extract_parameter(p_, None, mode)
+        if outliers == True:
+            self.error_fit['sigma_out'] = self._extract_parameter('sigma_out', 'series', mode)
+        self.fit_type = 'map' if mode == 'optimize' else 'bayes'
+        if outliers == False and check_outliers:
+            idx = self.check_outliers(frequencies, Z_sorted, threshold=3.5, use_existing_fit=True)
+            if len(idx) > 0:
+                warnings.warn('Possible outliers were identified at indices {}, f={} Hz. Check the residuals and consider '
+                              're-running with outliers=True'.format(idx, frequencies[idx]))
+
+    def drift_map_fit(self, *a, **k):
+        raise NotImplementedError('drift fits: the reference ships no Stan model files for them (SURVEY section 2 row 15)')
+
+    def _get_stan_model(self, nonneg, outliers, drift, drift_model, fitY, SA):
+        """Model selection (reference :1566-1614)."""
+        ns = len([1 for i in self.distributions.values() if i['dist_type'] == 'series'])
+        npar = len([1 for i in self.distributions.values() if i['dist_type'] == 'parallel'])
+        table = {(1, 0): 'Series', (0, 1): 'Parallel', (1, 1): 'Series-Parallel', (1, 2): 'Series-2Parallel'}
+        if (ns, npar) not in table:
+            raise NotImplementedError('The MultiDist model is a placeholder in the reference (no Stan file shipped)')
+        s = table[(ns, npar)]
+        if nonneg and ns >= 1:
+            s += '_pos'
+        if outliers:
+            s += '_outliers'
+        s += '_StanModel.pkl'
+        return load_pickle(os.path.join(script_dir, 'stan_model_files', s)), s
+
+    def _get_init_from_ridge(self, frequencies, Z, mode, nonneg, outliers, inductance_scale, ridge_kw):
+        """Initial values from an under-fitted hyper-ridge solution (reference :1616-1682)."""
+        name = list(self.distributions.keys())[0]
+        dist_type = self.distributions[name]['dist_type']
+        kw = dict(penalty='integral', hyper_lambda=True, lambda_0=1, hl_beta=5, weights='modulus')
+        kw.update(ridge_kw)
+        self.ridge_fit(frequencies, Z, **kw)
+        coef = self.distribution_fits[name]['coef']
+        iv = {'x': coef / self._Z_scale if dist_type == 'series' else coef * self._Z_scale}
+        iv['Rinf'] = self.R_inf / self._Z_scale
+        iv['Rinf_raw'] = iv['Rinf'] / 100
+        iv['induc'] = self.inductance / self._Z_scale
+        if iv['induc'] <= 0:
+            iv['induc'] = 1e-10
+        iv['induc_raw'] = iv['induc'] / inductance_scale
+        if outliers:
+            idx = self.check_outliers(frequencies, Z, threshold=3, use_existing_fit=True)
+            if outliers is True or len(idx) > 0:
+                so = np.zeros(len(Z)) + 0.1
+                so[idx] = 1
+                iv['sigma_out_raw'] = so
+        return lambda: iv
+
+    def _prep_stan_data(self, frequencies, Z, part, model_type, dist_mat, outliers, sigma_min, mode, inductance_scale,
+                        outlier_lambda, fitY, SA, SASY):
+        """The Stan `data` dict with the calibrated hyper-parameter table (reference :1684-2122)."""
+        if outlier_lambda is None:
+            outlier_lambda = 10
+        samp = mode == 'sample'
+        ups_alpha, ups_beta = (1, 0.1) if samp else (0.05, 0.1)
+
+        def Ls(m, kind):
+            if samp:
+                return m['L0'], m['L1'], 0.75 * m['L2']
+            return (1.5 * (0.36 if kind == 'parallel_multi' else 0.24)) * m['L0'], 1.5 * 0.16 * m['L1'], 1.5 * 0.08 * m['L2']
+
+        def stack(m):
+            return np.concatenate((m['A_re'], m['A_im']))
+        Z_stack = np.concatenate((Z.real, Z.imag))
+        nf = len(frequencies)
+        common = {'N': 2 * nf, 'freq': frequencies, 'Z': Z_stack, 'N_tilde': 2 * nf, 'freq_tilde': frequencies,
+                  'sigma_min': sigma_min, 'ups_alpha': ups_alpha, 'ups_beta': ups_beta, 'induc_scale': inductance_scale}
+        if model_type in ['Series', 'Parallel']:
+            name = [k for k, v in self.distributions.items() if v['dist_type'] == model_type.lower()][0]
+            m = dist_mat[name]
+            L0, L1, L2 = Ls(m, 'single')
+            A = stack(m)
+            dat = dict(common, K=A.shape[1], A=A, A_tilde=A, L0=L0, L1=L1, L2=L2)
+            if outliers:
+                dat.update(sigma_out_lambda=outlier_lambda, sigma_out_alpha=5 if samp else 2, sigma_out_beta=1)
+        elif model_type == 'Series-Parallel':
+            if len(self.distributions) > 2:
+                raise ValueError('Too many distributions for Series-Parallel model')
+            sn = [k for k, v in self.distributions.items() if v['dist_type'] == 'series'][0]
+            pn = [k for k, v in self.distributions.items() if v['dist_type'] == 'parallel'][0]
+            ms, mp = dist_mat[sn], dist_mat[pn]
+            L0s, L1s, L2s = Ls(ms, 'single')
+            L0p, L1p, L2p = Ls(mp, 'parallel_multi')
+            As, Ap = stack(ms), stack(mp)
+            dat = dict(common, Ks=As.shape[1], Kp=Ap.shape[1], As=As, Ap=Ap, As_tilde=As, Ap_tilde=Ap, L0s=L0s, L1s=L1s,
+                       L2s=L2s, L0p=L0p, L1p=L1p, L2p=L2p, x_sum_invscale=1 if samp else 0.,
+                       xp_scale=self.distributions[pn].get('x_scale', 1))
+            if outliers:
+                dat['so_invscale'] = outlier_lambda
+        elif model_type == 'Series-2Parallel':
+            sn = [k for k, v in self.distributions.items() if v['dist_type'] == 'series'][0]
+            p1, p2 = sorted([k for k, v in self.distributions.items() if v['dist_type'] == 'parallel'])
+            self.distributions[p1]['order'] = 1
+            self.distributions[p2]['order'] = 2
+            ms, m1, m2 = dist_mat[sn], dist_mat[p1], dist_mat[p2]
+            L0s, L1s, L2s = Ls(ms, 'single')
+            a = Ls(m1, 'parallel_multi'); b = Ls(m2, 'parallel_multi')
+            As, A1, A2 = stack(ms), stack(m1), stack(m2)
+            dat = dict(common, Ks=As.shape[1], Kp1=A1.shape[1], Kp2=A2.shape[1], As=As, Ap1=A1, Ap2=A2, As_tilde=As,
+                       Ap1_tilde=A1, Ap2_tilde=A2, L0s=L0s, L1s=L1s, L2s=L2s, L0p1=a[0], L1p1=a[1], L2p1=a[2],
+                       L0p2=b[0], L1p2=b[1], L2p2=b[2], x_sum_invscale=0.1 if samp else 0.,
+                       xp1_scale=self.distributions[p1].get('x_scale', 1), xp2_scale=self.distributions[p2].get('x_scale', 1))
+            if outliers:
+                dat['so_invscale'] = outlier_lambda
+        else:
+            raise NotImplementedError('MultiDist is a placeholder in the reference')
+        return dat
+
+    # ================================================================== matrices / scaling (reference :2127-2450)
+    def _prep_matrices(self, frequencies, Z, part, weights, dZ, scale_Z, penalty, fit_type, sort_desc=True):
+        if len(frequencies) != len(Z):
+            raise ValueError("Length of frequencies and Z must be equal")
+        Z = np.array(Z) if type(Z) != np.ndarray else Z
+        frequencies = np.array(frequencies, dtype=float) if type(frequencies) != np.ndarray else frequencies
+        if sort_desc:
+            order = np.argsort(frequencies)[::-1]
+            frequencies, Z = frequencies[order], Z[order]
+        self.Z_train = Z
+        if not _same(self.distributions, self._cached_distributions):
+            self._recalc_mat = True
+            self.f_pred = None
+        freq_subset = False
+        ft = np.asarray(self.f_train, dtype=float)
+        same_grid = len(ft) == len(frequencies) and bool(np.min(rel_round(ft, 10) == rel_round(frequencies, 10)))
+        if not same_grid:
+            rt = set(rel_round(ft, 10).tolist()) if len(ft) > 1 else set()
+            if len(rt) and all(v in rt for v in rel_round(frequencies, 10).tolist()):
+                freq_subset = True
+            else:
+                self.f_train = frequencies
+                self._recalc_mat = True
+        else:
+            self.f_train = frequencies
+        if scale_Z:
+            Z = self._scale_Z(Z, fit_type)
+            if type(weights) in (list, np.ndarray):
+                weights = np.array(weights) / self._Z_scale
+        else:
+            self._Z_scale = 1
+        weights = self._format_weights(frequencies, Z, weights, part)
+        W_re, W_im = np.diag(np.real(weights)), np.diag(np.imag(weights))
+        dist_mat = {}
+        for name, info in self.distributions.items():
+            tmp = deepcopy(self.distributions)
+            bf = info.get('basis_freq', self.basis_freq)
+            if bf is None:
+                # one decade beyond the measured range on each side, 10 points per decade (:2191-2197); the
+                # int() truncation is reproduced with the same float64 operation order
+                tmin = np.log10(1 / (2 * np.pi * np.max(frequencies))) - 1
+                tmax = np.log10(1 / (2 * np.pi * np.min(frequencies))) + 1
+                num_decades = tmax - tmin
+                tau = np.logspace(tmin, tmax, int(10 * num_decades + 1))
+            else:
+                tau = 1 / (2 * np.pi * np.asarray(bf, dtype=float))
+            tmp[name]['tau'] = tau
+            if info.get('epsilon', self.epsilon) is None:
+                tmp[name]['epsilon'] = 1 / np.mean(np.diff(np.log(tau)))
+            elif info.get('epsilon', None) is None:
+                tmp[name]['epsilon'] = self.epsilon
+            epsilon = tmp[name].get('epsilon', self.epsilon)
+            keep = self._recalc_mat
+            self.distributions = tmp
+            self._recalc_mat = keep
+            info = self.distributions[name]
+            akw = dict(tau=tau, basis=self.basis, epsilon=epsilon, kernel=info['kernel'], dist_type=info['dist_type'],
+                       symmetry=info.get('symmetry', ''), bc=info.get('bc', ''), ct=info.get('ct', False),
+                       k_ct=info.get('k_ct', None))
+            store = self.distribution_matrices.setdefault(name, {})
+            if self._recalc_mat or 'A_re' not in store or 'A_im' not in store:
+                store['A_re'] = construct_A(frequencies, 'real', fit_inductance=self.fit_inductance, **akw)
+                store['A_im'] = construct_A(frequencies, 'imag', fit_inductance=self.fit_inductance, **akw)
+                store.pop('B', None)
+                A_re, A_im = store['A_re'].copy(), store['A_im'].copy()
+            elif freq_subset:
+                rt = rel_round(np.asarray(self.f_train, dtype=float), 10)
+                idx = np.array([np.where(rt == v)[0][0] for v in rel_round(frequencies, 10)])
+                A_re, A_im = store['A_re'][idx, :].copy(), store['A_im'][idx, :].copy()
+            else:
+                A_re, A_im = store['A_re'].copy(), store['A_im'].copy()
+            B = None
+            if dZ and info['kernel'] == 'DRT':
+                if 'B' not in store:
+                    # first difference of A' on a half-shifted tau grid: B@coef ~ dZ'/dln(tau) (:2273-2285)
+                    step = np.mean(np.diff(np.log(tau)))
+                    edges = np.logspace(np.log10(np.exp(np.log(tau[0]) - step / 2)), np.log10(np.exp(np.log(tau[-1]) + step / 2)),
+                                        len(tau) + 1)
+                    Bp = construct_A(1 / (2 * np.pi * edges), 'real', **akw)
+                    store['B'] = Bp[1:, :] - Bp[:-1, :]
+                B = store['B'].copy()
+            dist_mat[name] = {}
+            fb = 1 / (2 * np.pi * tau)
+            if penalty == 'integral':
+                for o in (0, 1, 2):
+                    dist_mat[name]['M%d' % o] = construct_M(fb, basis=self.basis, order=o, epsilon=epsilon)
+            elif penalty == 'discrete':
+                for o in (0, 1, 2):
+                    dist_mat[name]['L%d' % o] = construct_L(fb, tau=tau, basis=self.basis, epsilon=epsilon, order=o)
+            else:
+                raise NotImplementedError("penalty='cholesky' is not implemented")
+            store.update(dist_mat[name])
+            dist_mat[name].update({'A_re': A_re, 'A_im': A_im, 'WA_re': W_re @ A_re, 'WA_im': W_im @ A_im, 'B': B})
+        self._recalc_mat = False
+        self._cached_distributions = self.distributions.copy()
+        return frequencies, Z, W_re @ Z.real, W_im @ Z.imag, W_re, W_im, dist_mat
+
+    def _format_weights(self, frequencies, Z, weights, part):
+        """Complex weight vector: real part weights Z', imaginary part Z'' (reference :2338-2395)."""
+        if weights is None or (isinstance(weights, str) and weights == 'unity'):
+            weights = np.ones_like(frequencies) * (1 + 1j)
+        elif isinstance(weights, str):
+            if weights == 'modulus':
+                weights = (1 + 1j) / np.sqrt(np.real(Z * Z.conjugate()))
+            elif weights == 'Orazem':
+                weights = (1 + 1j) / (np.abs(Z.real) + np.abs(Z.imag))
+            elif weights == 'proportional':
+                weights = 1 / np.abs(Z.real) + 1j / np.abs(Z.imag)
+            elif weights == 'prop_adj':
+                zm = np.real(Z * Z.conjugate())
+                weights = 1 / (np.abs(Z.real) + np.percentile(zm, 25)) + 1j / (np.abs(Z.imag) + np.percentile(zm, 25))
+            else:
+                raise ValueError(f"Invalid weights argument {weights}. String options are 'unity', 'modulus', "
+                                 f"'proportional', and 'prop_adj'")
+        elif type(weights) in (float, int):
+            weights = np.ones_like(frequencies) * (1 + 1j) * weights
+        elif type(weights) == complex:
+            weights = np.ones_like(frequencies) * weights
+        elif len(weights) != len(frequencies):
+            raise ValueError("Weights array must match length of data")
+        if part == 'both':
+            if np.min(np.isreal(weights)) == True:
+                weights = weights + 1j * weights
+        elif part == 'real':
+            weights = np.real(weights) + 1j * np.ones_like(frequencies)
+        elif part == 'imag':
+            if np.min(np.isreal(weights)) == True:
+                weights = np.ones_like(frequencies) + 1j * weights
+        else:
+            raise ValueError(f"Invalid part {part}. Options are 'both', 'real', or 'imag'")
+        return weights
+
+    def _scale_Z(self, Z, fit_type):
+        """_Z_scale = std|Z| / sqrt(N/81); pure parallel planar DDT scales the admittance instead (reference :2411-2443)."""
+        ns = len([1 for i in self.distributions.values() if i['dist_type'] == 'series'])
+        npar = len([1 for i in self.distributions.values() if i['dist_type'] == 'parallel'])
+        Zmod = np.abs(Z)
+        self._Z_scale = np.std(Zmod) / np.sqrt(len(Z) / 81)
+        if npar == 1 and ns == 0 and fit_type != 'ridge':
+            info = [i for i in self.distributions.values() if i['dist_type'] == 'parallel'][0]
+            if info['kernel'] == 'DDT' and info['symmetry'] == 'planar':
+                target = 14 if info['bc'] == 'transmissive' else 2.4
+                self._Z_scale = target * np.sqrt(len(Z) / 81) / np.std(np.abs(1 / Z))
+        return Z / self._Z_scale
+
+    def _rescale_coef(self, coef, dist_type):
+        if dist_type == 'series':
+            return coef * self._Z_scale
+        elif dist_type == 'parallel':
+            return coef / self._Z_scale
+
+    # ================================================================== result extraction (reference :2494-2566)
+    def _extract_parameter(self, stan_key, dist_type, mode):
+        unscaled = stan_key in ['alpha_prop', 'alpha_re', 'alpha_im']
+        if mode == 'optimize':
+            v = self._opt_result[stan_key]
+            return v if unscaled else self._rescale_coef(v, dist_type)
+        v = self._sample_result[stan_key]
+        return np.mean(v) if unscaled else self._rescale_coef(np.mean(v, axis=0), dist_type)
+
+    def _get_stan_coef_name(self, distribution_name):
+        dist_type = self.distributions[distribution_name]['dist_type']
+        model_type = self.stan_model_name.split('_')[0]
+        if model_type in ['Series', 'Parallel']:
+            return 'x'
+        if dist_type == 'series':
+            return 'xs'
+        if model_type == 'Series-Parallel':
+            return 'xp'
+        return 'xp%d' % self.distributions[distribution_name]['order']
+
+    def coef_percentile(self, distribution_name, percentile):
+        """Percentile of each coefficient over the draws (then rescaled) -- per coefficient, as the reference does (:2547-2566, H6)."""
+        if self.fit_type != 'bayes':
+            raise ValueError('Percentile prediction is only available for bayes_fit')
+        coef = np.percentile(self._sample_result[self._get_stan_coef_name(distribution_name)], percentile, axis=0)
+        return self._rescale_coef(coef, self.distributions[distribution_name]['dist_type'])
+
+    # ================================================================== prediction (reference :2571-3311)
+    def _get_prediction_matrices(self, frequencies, distributions):
+        frequencies = np.asarray(frequencies, dtype=float)
+        rf = rel_round(frequencies, 10)
+
+        def lookup(src_f, src):
+            rs = rel_round(np.asarray(src_f, dtype=float), 10)
+            if len(rs) == len(rf) and bool(np.min(rs == rf)):
+                return {n: {'A_re': src[n]['A_re'].copy(), 'A_im': src[n]['A_im'].copy()} for n in distributions}
+            pos = {v: i for i, v in enumerate(rs.tolist())}
+            if all(v in pos for v in rf.tolist()):
+                idx = np.array([pos[v] for v in rf.tolist()])
+                return {n: {'A_re': src[n]['A_re'][idx, :].copy(), 'A_im': src[n]['A_im'][idx, :].copy()} for n in distributions}
+            return None
+
+        def build():
+            out = {}
+            for n in distributions:
+                info = self.distributions[n]
+                kw = dict(tau=info['tau'], basis=self.basis, fit_inductance=self.fit_inductance, epsilon=info['epsilon'],
+                          kernel=info['kernel'], dist_type=info['dist_type'], symmetry=info.get('symmetry', ''),
+                          bc=info.get('bc', ''), ct=info.get('ct', False), k_ct=info.get('k_ct', None))
+                out[n] = {'A_re': construct_A(frequencies, 'real', **kw), 'A_im': construct_A(frequencies, 'imag', **kw)}
+            return out
+        if self.f_pred is not None and all(n in getattr(self, 'prediction_matrices', {}) for n in distributions):
+            pm = lookup(self.f_pred, self.prediction_matrices)
+            if pm is None:
+                pm = build()
+                self.prediction_matrices, self.f_pred = pm, frequencies
+            return pm
+        have = all(len(self.distribution_matrices.get(n, {})) > 0 and 'A_re' in self.distribution_matrices[n] for n in distributions)
+        pm = lookup(self.f_train, self.distribution_matrices) if have and len(np.atleast_1d(self.f_train)) > 1 else None
+        if pm is None:
+            pm = build()
+        self.f_pred, self.prediction_matrices = frequencies, pm
+        return pm
+
+    def _dist_list(self, distributions):
+        if distributions is None:
+            return [k for k in self.distribution_fits.keys()]
+        return [distributions] if type(distributions) == str else list(distributions)
+
+    def predict_Z_distribution(self, frequencies, distributions=None, include_offsets=True):
+        """Impedance of every posterior draw (rows) (reference :2963-3031)."""
+        if self.fit_type != 'bayes':
+            raise ValueError('predict_Z_distribution is only available for bayes_fit results')
+        frequencies = np.asarray(frequencies, dtype=float)
+        distributions = self._dist_list(distributions)
+        full = len(distributions) == len(self.distributions) and include_offsets
+        if not full:
+            warnings.warn('All distributions and offsets should be included for meaningful results from predict_Z_distribution')
+        ft = np.asarray(self.f_train, dtype=float)
+        if full and len(ft) == len(frequencies) and bool(np.min(rel_round(ft, 10) == rel_round(frequencies, 10))):
+            Zs = self._sample_result['Z_hat'] * self._Z_scale
+            return Zs[:, :len(frequencies)] + 1j * Zs[:, len(frequencies):]
+        pm = self._get_prediction_matrices(frequencies, distributions)
+        ns = len(self._sample_result['Rinf'])
+        Zm = np.zeros((ns, len(frequencies)), dtype=complex)
+        for name, mat in pm.items():
+            dt = self.distributions[name]['dist_type']
+            cm = self._rescale_coef(self._sample_result[self._get_stan_coef_name(name)], dt)
+            v = cm @ mat['A_re'].T + 1j * (cm @ mat['A_im'].T)
+            Zm += v if dt == 'series' else 1 / v
+        if include_offsets:
+            Zm += self._rescale_coef(self._sample_result['Rinf'], 'series')[:, None]
+            Zm += 1j * 2 * np.pi * frequencies * self._rescale_coef(self._sample_result['induc'], 'series')[:, None]
+        return Zm
+
+    def predict_Z(self, frequencies, times=None, distributions=None, include_offsets=True, percentile=None):
+        """Impedance predicted by the fitted distributions (reference :2669-2961)."""
+        frequencies = np.asarray(frequencies, dtype=float)
+        if times is not None:
+            raise NotImplementedError('drift predictions are out of scope')
+        distributions = self._dist_list(distributions)
+        if percentile is not None:
+            if self.fit_type != 'bayes':
+                raise ValueError('Percentile prediction is only available for bayes_fit results')
+            full = len(distributions) == len(self.distributions) and include_offsets
+            if not full:
+                warnings.warn('If percentile is specified, all distributions and offsets should be included for meaningful results')
+            ft = np.asarray(self.f_train, dtype=float)
+            if full and len(ft) == len(frequencies) and bool(np.min(rel_round(ft, 10) == rel_round(frequencies, 10))):
+                Zp = np.percentile(self._sample_result['Z_hat'], percentile, axis=0) * self._Z_scale
+                return Zp[:len(frequencies)] + 1j * Zp[len(frequencies):]
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                Zm = self.predict_Z_distribution(frequencies, distributions, include_offsets)
+            return np.percentile(Zm.real, percentile, axis=0) + 1j * np.percentile(Zm.imag, percentile, axis=0)
+        pm = self._get_prediction_matrices(frequencies, distributions)
+        Zp = np.zeros(len(frequencies), dtype=complex)
+        for name, mat in pm.items():
+            coef = self.distribution_fits[name]['coef']
+            v = mat['A_re'] @ coef + 1j * (mat['A_im'] @ coef)
+            Zp += v if self.distributions[name]['dist_type'] == 'series' else 1 / v
+        if include_offsets:
+            Zp += self.R_inf
+            Zp += 1j * 2 * np.pi * frequencies * self.inductance
+        return Zp
+
+    def predict_Rp(self, distributions=None, percentile=None, time=None):
+        """Polarisation resistance (reference :3033-3087)."""
+        distributions = self._dist_list(distributions)
+        if len(distributions) > 1:
+            ends = np.array([1e20, 1e-20])
+            if percentile is None:
+                Zr = self.predict_Z(ends, distributions=distributions)
+                return np.real(Zr[1] - Zr[0])
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                Zm = self.predict_Z_distribution(ends, distributions=distributions)
+            return np.percentile(np.real(Zm[:, 1] - Zm[:, 0]), percentile)
+        info = self.distributions[distributions[0]]
+        if info['kernel'] == 'DRT' and 'coef' in self.distribution_fits[distributions[0]]:
+            if percentile is None:                         # area under the DRT
+                return np.sum(self.distribution_fits[distributions[0]]['coef']) * np.pi ** 0.5 / info['epsilon']
+            if self.fit_type != 'bayes':
+                raise ValueError('Percentile prediction is only available for bayes_fit results')
+            cm = self._rescale_coef(self._sample_result[self._get_stan_coef_name(distributions[0])], 'series')
+            return np.percentile(np.sum(cm, axis=1) * np.pi ** 0.5 / info['epsilon'], percentile)
+        ends = np.array([1e20, 1e-20])
+        if percentile is None:
+            Zr = self.predict_Z(ends, distributions=distributions)
+            return np.real(Zr[1] - Zr[0])
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            Zm = self.predict_Z_distribution(ends, distributions=distributions)
+        return np.percentile(np.real(Zm[:, 1] - Zm[:, 0]), percentile)
+
+    def predict_sigma(self, frequencies, percentile=None, times=None):
+        """Error scale (sigma_re, sigma_im) of the fitted error model (reference :3089-3139)."""
+        frequencies = np.asarray(frequencies, dtype=float)
+        if percentile is not None and self.fit_type != 'bayes':
+            raise ValueError('Percentile prediction is only available for bayes_fit')
+        if self.fit_type not in ('bayes', 'map'):
+            raise ValueError('Error scale prediction only available for bayes_fit and map_fit')
+        ft = np.asarray(self.f_train, dtype=float)
+        nf = len(ft)
+        if nf == len(frequencies) and bool(np.min(rel_round(ft, 10) == rel_round(frequencies, 10))):
+            if self.fit_type == 'bayes' and percentile is not None:
+                st = np.percentile(self._sample_result['sigma_tot'], percentile, axis=0) * self._Z_scale
+            else:
+                st = self.error_fit['sigma_tot']
+            return st[:nf].copy(), st[nf:].copy()
+        if self.fit_type == 'bayes' and percentile is not None:
+            sres = np.percentile(self._sample_result['sigma_res'], percentile) * self._Z_scale
+            ap, ar, ai = [np.percentile(self._sample_result[k], percentile) for k in ('alpha_prop', 'alpha_re', 'alpha_im')]
+            try:
+                sout = np.percentile(self._sample_result['sigma_out'], percentile, axis=0) * self._Z_scale
+            except (ValueError, KeyError):
+                sout = np.zeros(2 * nf)
+        else:
+            sres, ap, ar, ai = [self.error_fit[k] for k in ('sigma_res', 'alpha_prop', 'alpha_re', 'alpha_im')]
+            sout = self.error_fit.get('sigma_out', np.zeros(2 * nf))
+        Zp = self.predict_Z(frequencies, percentile=percentile)
+        base2 = sres ** 2 + np.min(sout) ** 2 + self.error_fit['sigma_min'] ** 2
+        common = (ar * Zp.real) ** 2 + (ai * Zp.imag) ** 2
+        return np.sqrt(base2 + (ap * Zp.real) ** 2 + common), np.sqrt(base2 + (ap * Zp.imag) ** 2 + common)
+
+    def predict_distribution(self, name=None, eval_tau=None, percentile=None, time=None):
+        """gamma(tau) = sum_m coef_m exp(-(eps ln(tau/tau_m))^2) (reference :3162, :3298-3311)."""
+        if time is not None:
+            raise NotImplementedError('drift predictions are out of scope')
+        if name is None:
+            name = list(self.distributions.keys())[0]
+        info = self.distributions[name]
+        if eval_tau is None:
+            eval_tau = info['tau']
+        coef = self.coef_percentile(name, percentile) if percentile is not None else self.distribution_fits[name]['coef']
+        y = np.log(np.asarray(eval_tau, dtype=float)[:, None] / info['tau'][None, :])
+        return _gaussian(y, info['epsilon']) @ coef
+
+    def score(self, frequencies, Z, metric='chi_sq', weights=None, part='both', times=None):
+        """Fit quality: weighted chi-square or r2 of the predicted impedance (reference :3141-3160)."""
+        frequencies, Z = np.asarray(frequencies, dtype=float), np.asarray(Z)
+        w = self._format_weights(frequencies, Z, weights, part)
+        Zp = self.predict_Z(frequencies)
+        if part == 'both':
+            y = np.concatenate((Z.real, Z.imag)); yh = np.concatenate((Zp.real, Zp.imag)); ww = np.concatenate((w.real, w.imag))
+        else:
+            y, yh, ww = getattr(Z, part), getattr(Zp, part), getattr(w, part)
+        if metric == 'chi_sq':
+            return np.sum(((yh - y) * ww) ** 2) / len(frequencies)
+        if metric == 'r2':
+            ss_res = np.sum(ww ** 2 * (yh - y) ** 2)
+            ss_tot = np.sum(ww ** 2 * (y - np.average(y, weights=ww ** 2)) ** 2)
+            return 1 - ss_res / ss_tot
+        raise ValueError(f"Invalid metric {metric}. Options are 'chi_sq', 'r2'")
+
+    # ================================================================== outliers (reference :3313-3376)
+    def check_outliers(self, frequencies, Z, threshold, use_existing_fit, **ridge_kw):
+        """Indices of likely outliers: IQR test on ridge residuals, or z-score with the fitted error model."""
+        frequencies, Z = np.asarray(frequencies), np.asarray(Z)
+        fit_exists = (_same(frequencies, self.f_train) and _same(Z, self.Z_train) and not self._recalc_mat
+                      and hasattr(self, 'distribution_fits') and len(self.distribution_fits) > 0)
+        if not (use_existing_fit and fit_exists):
+            self.ridge_fit(frequencies, Z, preset='Huang', **ridge_kw)
+            order = np.argsort(frequencies)[::-1]
+            frequencies, Z = frequencies[order], Z[order]
+        Z_err = self.predict_Z(frequencies) - Z
+        if self.fit_type == 'ridge':
+            Zmod = np.sqrt(Z.real ** 2 + Z.imag ** 2)
+            re_t = get_outlier_thresh(np.abs(Z_err.real / Zmod), iqr_factor=threshold)
+            im_t = get_outlier_thresh(np.abs(Z_err.imag / Zmod), iqr_factor=threshold)
+            return np.argwhere((Z_err.real / Zmod) ** 2 + (Z_err.imag / Zmod) ** 2 >= re_t ** 2 + im_t ** 2)
+        s_re, s_im = self.predict_sigma(frequencies)
+        zs = np.sqrt(((Z_err.real / s_re) ** 2 + (Z_err.imag / s_im) ** 2) / 2)
+        return np.argwhere(zs > threshold)
+
+    # ================================================================== persistence (reference :3980-4064), arrays only
+    def get_fit_data(self, which='all'):
+        core = ['distribution_fits', 'R_inf', 'inductance', 'fit_type', '_Z_scale', 'f_train', 'Z_train', 'stan_model_name',
+                'error_fit']
+        detail = ['_opt_result', '_init_params', '_iter_history', 'distribution_matrices', '_stan_input']
+        keys = core if which == 'core' else (detail if which == 'detail' else core + detail)
+        out = {k: deepcopy(getattr(self, k)) for k in keys if hasattr(self, k)}
+        out['distributions'] = deepcopy(self.distributions)
+        return out
+
+    def save_fit_data(self, filename=None, which='all'):
+        import pickle
+        data = self.get_fit_data(which)
+        if filename is None:
+            return data
+        with open(filename, 'wb') as f:
+            pickle.dump(data, f, pickle.HIGHEST_PROTOCOL)
+
+    def load_fit_data(self, data):
+        import pickle
+        if isinstance(data, str):
+            with open(data, 'rb') as f:
+                data = pickle.load(f)
+        data = dict(data)
+        if 'distributions' in data:
+            self._distributions = data.pop('distributions')
+        for k, v in data.items():
+            setattr(self, k, v)
+        self._recalc_mat = False
+        self._cached_distributions = self.distributions.copy()
+        self.f_pred = None
+

@@ -1,0 +1,156 @@
+"""GPU end-to-end tests (-m gpu) of the Inverter mirror on the reference's simulated spectra (BASELINE configs 1-3, 5)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from tests.helpers import load, rel_l2, kat_to_model
+
+pytestmark = pytest.mark.gpu
+TAU_PLOT = np.logspace(-7, 2, 200)
+
+
+def _spectrum(stem='2ZARC_uniform_0.25'):
+    c = load('csv_' + stem)
+    Z = c['Z']
+    return Z[:, 0], Z[:, 1] + 1j * Z[:, 2], c
+
+
+def test_fit_map_2zarc_matches_published_reference_result():
+    """Config 2: MAP on the 2-ZARC spectrum with the published settings (basis = measurement frequencies, K = 81,
+    non-negative).  Against the reference's committed result code_EchemActa/map_results/Gout_2ZARC_uniform_0.25.csv the
+    agreement is a few % rel-L2 -- the published curve is an un-converged L-BFGS iterate; ours is the
+    stationary point (|grad|_inf < 1e-8)."""
+    from bayes_drt_amd.inversion import Inverter
+    f, Z, c = _spectrum()
+    inv = Inverter(basis_freq=f)
+    inv.fit(f, Z, nonneg=True, mode='optimize')
+    assert inv.fit_type == 'map' and inv.stan_model_name == 'Series_pos_StanModel.pkl'
+    assert inv._opt_report['return_code'] == 0 and inv._opt_report['grad_inf'] < 1e-8
+    g = inv.predict_distribution('DRT', eval_tau=TAU_PLOT)
+    ref, true = c['Gout_map'][:, 1], c['gamma_true'][:, 1]
+    assert rel_l2(g, ref) < 0.05, rel_l2(g, ref)
+    assert rel_l2(g, true) < 0.12
+    Zp = inv.predict_Z(f)
+    assert np.sqrt(np.mean(np.abs(Zp - Z) ** 2)) < 0.01
+    zref = c['Zout_map']
+    assert np.max(np.abs(Zp.real - zref[:, 1])) < 5e-3 and np.max(np.abs(Zp.imag - zref[:, 2])) < 5e-3
+    s_re, s_im = inv.predict_sigma(f)
+    assert np.allclose(s_re, zref[:, 3], rtol=0.5) and np.allclose(s_im, zref[:, 4], rtol=0.5)
+    assert set(inv.error_fit) >= {'sigma_min', 'sigma_tot', 'sigma_res', 'alpha_prop', 'alpha_re', 'alpha_im'}
+    assert inv.R_inf == pytest.approx(1.0, abs=0.02) and abs(inv.inductance) < 1e-6
+    assert inv.predict_Rp() == pytest.approx(2.0, rel=0.03)
+
+
+def test_fit_map_default_basis_and_refit_reuses_matrices():
+    from bayes_drt_amd.inversion import Inverter
+    f, Z, c = _spectrum('2ZARC_noiseless')
+    inv = Inverter()
+    inv.fit(f, Z, nonneg=True, sigma_min=0.005)
+    assert len(inv.distributions['DRT']['tau']) == 101          # default grid
+    g = inv.predict_distribution(eval_tau=TAU_PLOT)
+    assert rel_l2(g, c['gamma_true'][:, 1]) < 0.15
+    A_before = inv.distribution_matrices['DRT']['A_re']
+    inv.fit(f[::2], Z[::2], nonneg=True, sigma_min=0.005)       # subset of f_train: sub-matrices reused
+    assert inv.distribution_matrices['DRT']['A_re'] is A_before
+
+
+def test_fit_sample_2zarc_within_reference_mc_error():
+    """Config 3 (short): NUTS posterior mean / 95 % band vs the reference's committed HMC result
+    (bayes_results/Gout_2ZARC_uniform_0.25.csv, 2 chains x (200+200)).  Acceptance bands from the reference's own
+    run-to-run scatter: mean 1-2 %, bands ~6 %; widened for our shorter chains."""
+    from bayes_drt_amd.inversion import Inverter
+    f, Z, c = _spectrum()
+    inv = Inverter(basis_freq=f)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        inv.fit(f, Z, nonneg=True, mode='sample', warmup=200, samples=200, chains=4)
+    fit = inv._sample_result
+    assert inv.fit_type == 'bayes' and fit['x'].shape == (800, 81)
+    g = inv.predict_distribution('DRT', eval_tau=TAU_PLOT)
+    lo = inv.predict_distribution('DRT', eval_tau=TAU_PLOT, percentile=2.5)
+    hi = inv.predict_distribution('DRT', eval_tau=TAU_PLOT, percentile=97.5)
+    ref = c['Gout_bayes']
+    print('HMC gamma mean rel-L2 vs reference: %.4f, lo %.4f, hi %.4f; leapfrogs %d, divergent %d, treedepth hits %d'
+          % (rel_l2(g, ref[:, 1]), rel_l2(lo, ref[:, 2]), rel_l2(hi, ref[:, 3]), fit.n_leapfrog, fit.n_divergent,
+             fit.n_max_treedepth))
+    assert rel_l2(g, ref[:, 1]) < 0.04
+    assert rel_l2(hi, ref[:, 3]) < 0.10 and rel_l2(lo, ref[:, 2]) < 0.35
+    assert np.all(lo <= g + 1e-12) and np.all(g <= hi + 1e-12)
+    # split R-hat of the coefficients that matter
+    x = fit.chain_draws('x')
+    big = x.mean(axis=(0, 1)) > 0.01 * x.mean(axis=(0, 1)).max()
+    halves = np.concatenate([x[:, :100], x[:, 100:]], axis=0)[:, :, big]
+    W = halves.var(axis=1, ddof=1).mean(axis=0); Bv = halves.mean(axis=1).var(axis=0, ddof=1) * 100
+    rhat = np.sqrt((99 / 100 * W + Bv / 100) / W)
+    assert np.median(rhat) < 1.1, np.median(rhat)
+    Zp = inv.predict_Z(f, percentile=50)
+    assert np.sqrt(np.mean(np.abs(Zp - Z) ** 2)) < 0.02
+    assert fit.n_divergent < 40
+
+
+def test_ridge_fit_and_cv():
+    from bayes_drt_amd.inversion import Inverter
+    f, Z, c = _spectrum()
+    true = c['gamma_true'][:, 1]
+    inv = Inverter(basis_freq=f)
+    inv.ridge_fit(f, Z)
+    assert inv.fit_type == 'ridge' and len(inv.distribution_fits['DRT']['coef']) == 81
+    g = inv.predict_distribution(eval_tau=TAU_PLOT)
+    assert rel_l2(g, true) < 0.35
+    assert np.sqrt(np.mean(np.abs(inv.predict_Z(f) - Z) ** 2)) < 0.02
+    assert np.all(inv.distribution_fits['DRT']['coef'] > 0)          # interior-point solution: strictly positive
+    inv.ridge_fit(f, Z, preset='Huang')
+    gh = inv.predict_distribution(eval_tau=TAU_PLOT)
+    assert rel_l2(gh, true) < 0.35
+    # ordinary ridge, signed coefficients, Re-Im cross-validation over a short lambda grid
+    inv.ridge_fit(f, Z, hyper_lambda=False, nonneg=False, lambda_0='cv', cv_lambdas=np.logspace(-6, 0, 7))
+    assert inv.cv_result['totcv'].shape == (7,) and np.all(np.isfinite(inv.cv_result['totcv']))
+    with pytest.raises(ValueError):
+        inv.ridge_fit(f, Z, penalty='integral', hl_beta=1.5)
+    with pytest.raises(ValueError):
+        inv.ridge_fit(f, Z, hyper_lambda=True, hyper_weights=True)
+
+
+def test_init_from_ridge_and_outliers_auto():
+    from bayes_drt_amd.inversion import Inverter
+    f, Z, c = _spectrum()
+    Zo = Z.copy()
+    for i in (10, 40, 70):
+        Zo[i] *= 1.5
+    inv = Inverter(basis_freq=f)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        inv.fit(f, Zo, nonneg=True, outliers='auto', init_from_ridge=True)
+    assert any('outlier-robust error model' in str(x.message) for x in w)
+    assert inv.stan_model_name == 'Series_pos_outliers_StanModel.pkl'
+    assert 'sigma_out' in inv.error_fit and inv.error_fit['sigma_out'].shape == (81,)
+    so = inv.error_fit['sigma_out']
+    assert set(np.argsort(so)[-3:]) == {10, 40, 70}
+    g = inv.predict_distribution(eval_tau=TAU_PLOT)
+    assert rel_l2(g, c['gamma_true'][:, 1]) < 0.2
+    assert set(inv._init_params) >= {'x', 'Rinf_raw', 'induc_raw'}
+
+
+def test_series_parallel_fit_config5_family():
+    """DRT + transmissive planar DDT (Series-Parallel_pos) on the spectrum of the stored reference fit
+    obj_DRT-2-TpDDT_uniform_0.25: our MAP has a log-posterior >= the stored Stan MAP's."""
+    from bayes_drt_amd.inversion import Inverter
+    from bayes_drt_amd.model import Problem
+    k = kat_to_model('DRT-2-TpDDT_uniform_0.25')
+    d = load('kat_DRT-2-TpDDT_uniform_0.25')
+    f, Z = d['data_freq'], d['data_Z']
+    dists = {'DRT': {'kernel': 'DRT'},
+             'TP-DDT': {'kernel': 'DDT', 'symmetry': 'planar', 'bc': 'transmissive', 'dist_type': 'parallel', 'x_scale': 0.8}}
+    inv = Inverter(basis_freq=f, distributions=dists)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        inv.fit(f, Z, nonneg=True)
+    assert inv.stan_model_name == 'Series-Parallel_pos_StanModel.pkl'
+    assert set(inv.distribution_fits) == {'DRT', 'TP-DDT'}
+    prob = Problem(**k['kw'])
+    lp_ref, _ = prob.logp_grad(prob.unconstrain(k['params'])[None], jacobian=False)
+    print('Series-Parallel MAP lp %.3f vs stored reference MAP lp %.3f' % (inv._opt_report['lp'], lp_ref[0]))
+    assert inv._opt_report['lp'] >= lp_ref[0] - 1e-6
+    assert np.sqrt(np.mean(np.abs(inv.predict_Z(f) - Z) ** 2)) < 0.02 * np.mean(np.abs(Z))
+    assert inv.predict_Rp() > 0
