@@ -50,6 +50,8 @@ struct DevProblem {
     int outlier_mode, use_x_sum;
     int n_spectra;
     int XR, ZR, LR, npar;     // LDS row counts
+    int XCR;                  // rows of the x cache (0: exp(theta_x) is recomputed where needed)
+    int xc_off[MAXB];         // first cache row of each block
     int dbg;                  // timing ablation only (env BDRT_DEBUG_SKIP): 1 skip forward GEMMs, 2 skip backward GEMM
     double sigma_min, ups_alpha, ups_beta, induc_scale;
     double so_lambda, so_alpha, so_beta, x_sum_invscale;
@@ -60,7 +62,7 @@ struct DevProblem {
 
 __host__ __device__ inline size_t lds_doubles(const DevProblem &P)
 {
-    return (size_t)NC * ((size_t)P.XR + (size_t)P.ZR * (1 + P.npar) + (size_t)P.LR + NW * NRED + 32);
+    return (size_t)NC * ((size_t)P.XR + (size_t)P.ZR * (1 + P.npar) + (size_t)P.LR + (size_t)P.XCR + NW * NRED + 32);
 }
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -173,7 +175,7 @@ __device__ __forceinline__ void chain_reduce(double (&v)[NQ], double *red, doubl
 
 // per-chain scalar slots in LDS
 enum { S_RINF = 0, S_INDUC, S_SRES, S_AP, S_AR, S_AI, S_D0 /* 9 slots */, S_XSUM = 15, S_LP = 16, S_TMP = 17 /* 8 slots */,
-       S_REJ = 25, S_NSLOT = 32 };
+       S_REJ = 25, S_RAW = 26 /* 6 slots: Rinf_raw, induc_raw, sigma_res_raw, alpha_*_raw */, S_NSLOT = 32 };
 
 struct TileIO {
     const double *theta;   // unconstrained parameters
@@ -190,8 +192,13 @@ struct TileIO {
     long long *prof;       // optional cycle counters per phase (thread 0 of the workgroup), slots 0..9
 };
 
+constexpr int UK = 6;      // elements per thread handled per unrolled batch in the K-loops  (K <= 192 -> one batch)
+constexpr int UN = 3;      // ... in the Nf-loops (Nf <= 96 -> one batch)
+
 // Evaluate lp and gradient for the 16 chains of this workgroup.  smem: lds_doubles(P) doubles.
 // All threads of the workgroup must call.  Ends with a __syncthreads().
+// Element-wise phases are written as "issue all loads of a batch, then compute": the strided theta / Z reads are
+// L2 hits whose latency would otherwise be paid once per element.
 __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, double *smem)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -205,8 +212,10 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
     double *Zh = Xs + (size_t)P.XR * NC;
     double *Yp = Zh + (size_t)P.ZR * NC;
     double *Lr = Yp + (size_t)P.ZR * NC * P.npar;
-    double *red = Lr + (size_t)P.LR * NC;
+    double *XC = Lr + (size_t)P.LR * NC;
+    double *red = XC + (size_t)P.XCR * NC;
     double *sc = red + NW * NRED * NC;
+    const bool cache_x = P.XCR > 0;
 
     const double *th = io.theta + (long)cc * io.t_sc;
     auto TH = [&](int j) -> double { return th[(long)j * io.t_sj]; };
@@ -217,17 +226,22 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
 
     long long tprev = (io.prof && tid == 0) ? clock64() : 0;
 #define BDRT_TILE_PROF(slot) do { if (io.prof && tid == 0) { const long long t_ = clock64(); io.prof[slot] += t_ - tprev; tprev = t_; } } while (0)
-    // ---- phase 0: per-chain scalars -------------------------------------------------------------
-    if (tid < NC) {
-        const double rinf_raw = exp(TH(0)), induc_raw = exp(TH(1));
-        sc[S_RINF * NC + c] = 100.0 * rinf_raw;
-        sc[S_INDUC * NC + c] = induc_raw * P.induc_scale;
-        for (int j = 0; j < 4; ++j) sc[(S_SRES + j) * NC + c] = 0.05 * exp(TH(P.o_err + j));
-        for (int b = 0; b < P.nblocks; ++b)
-            for (int i = 0; i < 3; ++i) sc[(S_D0 + 3 * b + i) * NC + c] = exp(TH(P.blk[b].o_d + i));
-        sc[S_LP * NC + c] = 0.0;
-        sc[S_XSUM * NC + c] = 0.0;
-        sc[S_REJ * NC + c] = 0.0;
+    // ---- phase 0: per-chain scalars, one exp per thread ------------------------------------------------
+    {
+        const int which = tid >> 4;                       // 0..5: Rinf_raw, induc_raw, 4 error raws; 6..: d strengths
+        const int nsc = 6 + 3 * P.nblocks;
+        if (which < nsc) {
+            int j;
+            if (which < 2) j = which;
+            else if (which < 6) j = P.o_err + (which - 2);
+            else j = P.blk[(which - 6) / 3].o_d + (which - 6) % 3;
+            const double raw = exp(TH(j));
+            if (which == 0) { sc[S_RINF * NC + c] = 100.0 * raw; sc[(S_RAW + 0) * NC + c] = raw; }
+            else if (which == 1) { sc[S_INDUC * NC + c] = raw * P.induc_scale; sc[(S_RAW + 1) * NC + c] = raw; }
+            else if (which < 6) { sc[(S_SRES + which - 2) * NC + c] = 0.05 * raw; sc[(S_RAW + which) * NC + c] = raw; }
+            else sc[(S_D0 + which - 6) * NC + c] = raw;
+        }
+        if (tid < NC) { sc[S_LP * NC + c] = 0.0; sc[S_XSUM * NC + c] = 0.0; sc[S_REJ * NC + c] = 0.0; }
     }
     for (int i = tid; i < P.ZR * NC; i += NT) Zh[i] = 0.0;
     __syncthreads();
@@ -236,21 +250,35 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
     // ---- phase 1: Z_hat = sum_b (A_b x_b  or  1/(A_b x_b)) + offsets --------------------------------
     for (int b = 0; b < P.nblocks; ++b) {
         const DevBlock &B = P.blk[b];
-        double xsum[1] = {0.0};
-        for (int k = g; k < 8 * B.kpairs; k += NG) {
-            double x = 0.0;
-            if (k < B.K) {
-                const double t = TH(B.o_x + k);
-                const double xr = B.is_pos ? exp(t) : t;
-                xsum[0] += xr;
-                x = xr * B.x_scale;                       // xp = xp_raw * xp_scale (1 for series blocks)
-                PW(B.o_x + k, xr);
+        const int KP = 8 * B.kpairs;
+        double *xc = XC + (size_t)P.xc_off[b] * NC;
+        double xs2[2] = {0.0, 0.0};                       // sum x_raw, sum theta_x (log-Jacobian)
+        for (int k0 = g; k0 < KP; k0 += NG * UK) {
+            double t_[UK];
+#pragma unroll
+            for (int u = 0; u < UK; ++u) { const int k = k0 + NG * u; t_[u] = k < B.K ? TH(B.o_x + k) : 0.0; }
+#pragma unroll
+            for (int u = 0; u < UK; ++u) {
+                const int k = k0 + NG * u;
+                if (k < KP) {
+                    double xr = 0.0;
+                    if (k < B.K) {
+                        xr = B.is_pos ? exp(t_[u]) : t_[u];
+                        xs2[0] += xr;
+                        if (B.is_pos) xs2[1] += t_[u];
+                        PW(B.o_x + k, xr);
+                    }
+                    Xs[k * NC + c] = xr * B.x_scale;      // xp = xp_raw * xp_scale (1 for series blocks)
+                    if (cache_x) xc[k * NC + c] = xr;
+                }
             }
-            Xs[k * NC + c] = x;
         }
-        if (P.use_x_sum) {
-            chain_reduce<1>(xsum, red, sc + S_TMP * NC, tid);
-            if (tid < NC) sc[S_XSUM * NC + c] += sc[S_TMP * NC + c];
+        if (P.use_x_sum || (io.jacobian && B.is_pos)) {
+            chain_reduce<2>(xs2, red, sc + S_TMP * NC, tid);
+            if (tid < NC) {
+                sc[S_XSUM * NC + c] += sc[(S_TMP + 0) * NC + c];
+                if (io.jacobian) sc[S_LP * NC + c] += sc[(S_TMP + 1) * NC + c];
+            }
         }
         __syncthreads();
         BDRT_TILE_PROF(1);
@@ -266,9 +294,9 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
                 double *Y = Yp + (size_t)B.yp_slot * P.ZR * NC;
                 Y[n * NC + c] = yr;
                 Y[(nf + n) * NC + c] = yi;
-                const double dn = yr * yr + yi * yi;
-                Zh[n * NC + c] += yr / dn;                // Z_hat_p (Parallel_modelcode.txt:47)
-                Zh[(nf + n) * NC + c] += -yi / dn;
+                const double idn = 1.0 / (yr * yr + yi * yi);
+                Zh[n * NC + c] += yr * idn;               // Z_hat_p (Parallel_modelcode.txt:47)
+                Zh[(nf + n) * NC + c] += -yi * idn;
             }
         }
         __syncthreads();
@@ -285,74 +313,91 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
         const int sp = io.spec ? io.spec[cc] : 0;
         const double *Zm = P.Z + (size_t)sp * N2;
         double acc[7] = {0, 0, 0, 0, 0, 0, 0};   // lp, S_R, S_L, S_h, S_hz2, S_hzr2, S_hzi2
-        for (int n = g; n < nf; n += NG) {
-            const double wn = P.w[n];
-            const double zr = Zh[n * NC + c] + Rinf;
-            const double zi = Zh[(nf + n) * NC + c] + induc * wn;
-            double so_re = 0.0, so_im = 0.0, r0 = 0.0, r1 = 0.0;
-            if (P.outlier_mode) {
-                r0 = exp(TH(P.o_so + n));
-                r1 = exp(TH(P.o_so + nf + n));
-                PW(P.o_so + n, r0); PW(P.o_so + nf + n, r1);
-                if (P.outlier_mode == 1) so_re = so_im = 0.05 * r0 * r1;
-                else { so_re = 0.05 * r0; so_im = 0.05 * r1; }
+        for (int n0 = g; n0 < nf; n0 += NG * UN) {
+            double zre_[UN], zim_[UN], wn_[UN], t0_[UN], t1_[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int n = n0 + NG * u, nn = n < nf ? n : 0;
+                zre_[u] = Zm[nn]; zim_[u] = Zm[nf + nn]; wn_[u] = P.w[nn];
+                t0_[u] = 0.0; t1_[u] = 0.0;
+                if (P.outlier_mode) { t0_[u] = TH(P.o_so + nn); t1_[u] = TH(P.o_so + nf + nn); }
             }
-            const double common = ar2 * zr * zr + ai2 * zi * zi;
-            const double s2_re = c0 + ap2 * zr * zr + common + so_re * so_re;
-            const double s2_im = c0 + ap2 * zi * zi + common + so_im * so_im;
-            const double e_re = Zm[n] - zr, e_im = Zm[nf + n] - zi;
-            const double w_re = 1.0 / s2_re, w_im = 1.0 / s2_im;
-            acc[0] += -0.5 * log(s2_re) - 0.5 * e_re * e_re * w_re - 0.5 * log(s2_im) - 0.5 * e_im * e_im * w_im;
-            const double h_re = -0.5 * w_re + 0.5 * e_re * e_re * w_re * w_re;
-            const double h_im = -0.5 * w_im + 0.5 * e_im * e_im * w_im * w_im;
-            const double gzr = e_re * w_re + 2.0 * zr * (h_re * (ap2 + ar2) + h_im * ar2);
-            const double gzi = e_im * w_im + 2.0 * zi * (h_im * (ap2 + ai2) + h_re * ai2);
-            Zh[n * NC + c] = gzr;
-            Zh[(nf + n) * NC + c] = gzi;
-            acc[1] += gzr;
-            acc[2] += gzi * wn;
-            acc[3] += h_re + h_im;
-            acc[4] += h_re * zr * zr + h_im * zi * zi;
-            acc[5] += (h_re + h_im) * zr * zr;
-            acc[6] += (h_re + h_im) * zi * zi;
-            if (io.Z_hat && valid) { io.Z_hat[(size_t)c * N2 + n] = zr; io.Z_hat[(size_t)c * N2 + nf + n] = zi; }
-            if (io.sigma_tot && valid) {
-                io.sigma_tot[(size_t)c * N2 + n] = sqrt(s2_re);
-                io.sigma_tot[(size_t)c * N2 + nf + n] = sqrt(s2_im);
-            }
-            if (P.outlier_mode == 1) {
-                // sigma_out = raw .* scale * 0.05 ; raw ~ exponential(lambda) ; scale ~ inv_gamma(alpha, beta)
-                const double dso = 2.0 * so_re * (h_re + h_im);
-                GW(P.o_so + n, r0 * (0.05 * r1 * dso - P.so_lambda) + jac);
-                GW(P.o_so + nf + n, 0.05 * r0 * r1 * dso - (P.so_alpha + 1.0) + P.so_beta / r1 + jac);
-                acc[0] += -P.so_lambda * r0 - (P.so_alpha + 1.0) * TH(P.o_so + nf + n) - P.so_beta / r1 +
-                          jac * (TH(P.o_so + n) + TH(P.o_so + nf + n));
-            } else if (P.outlier_mode == 2) {
-                GW(P.o_so + n, r0 * (0.05 * 2.0 * so_re * h_re - P.so_lambda) + jac);
-                GW(P.o_so + nf + n, r1 * (0.05 * 2.0 * so_im * h_im - P.so_lambda) + jac);
-                acc[0] += -P.so_lambda * (r0 + r1) + jac * (TH(P.o_so + n) + TH(P.o_so + nf + n));
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int n = n0 + NG * u;
+                if (n >= nf) continue;
+                const double wn = wn_[u];
+                const double zr = Zh[n * NC + c] + Rinf;
+                const double zi = Zh[(nf + n) * NC + c] + induc * wn;
+                double so_re = 0.0, so_im = 0.0, r0 = 0.0, r1 = 0.0;
+                if (P.outlier_mode) {
+                    r0 = exp(t0_[u]);
+                    r1 = exp(t1_[u]);
+                    PW(P.o_so + n, r0); PW(P.o_so + nf + n, r1);
+                    if (P.outlier_mode == 1) so_re = so_im = 0.05 * r0 * r1;
+                    else { so_re = 0.05 * r0; so_im = 0.05 * r1; }
+                }
+                const double common = ar2 * zr * zr + ai2 * zi * zi;
+                const double s2_re = c0 + ap2 * zr * zr + common + so_re * so_re;
+                const double s2_im = c0 + ap2 * zi * zi + common + so_im * so_im;
+                const double e_re = zre_[u] - zr, e_im = zim_[u] - zi;
+                // one reciprocal and one logarithm for the (re, im) pair
+                const double prod = s2_re * s2_im, ip = 1.0 / prod;
+                const double w_re = s2_im * ip, w_im = s2_re * ip;
+                acc[0] += -0.5 * log(prod) - 0.5 * e_re * e_re * w_re - 0.5 * e_im * e_im * w_im;
+                const double h_re = -0.5 * w_re + 0.5 * e_re * e_re * w_re * w_re;
+                const double h_im = -0.5 * w_im + 0.5 * e_im * e_im * w_im * w_im;
+                const double gzr = e_re * w_re + 2.0 * zr * (h_re * (ap2 + ar2) + h_im * ar2);
+                const double gzi = e_im * w_im + 2.0 * zi * (h_im * (ap2 + ai2) + h_re * ai2);
+                Zh[n * NC + c] = gzr;
+                Zh[(nf + n) * NC + c] = gzi;
+                acc[1] += gzr;
+                acc[2] += gzi * wn;
+                acc[3] += h_re + h_im;
+                acc[4] += h_re * zr * zr + h_im * zi * zi;
+                acc[5] += (h_re + h_im) * zr * zr;
+                acc[6] += (h_re + h_im) * zi * zi;
+                if (io.Z_hat && valid) { io.Z_hat[(size_t)c * N2 + n] = zr; io.Z_hat[(size_t)c * N2 + nf + n] = zi; }
+                if (io.sigma_tot && valid) {
+                    io.sigma_tot[(size_t)c * N2 + n] = sqrt(s2_re);
+                    io.sigma_tot[(size_t)c * N2 + nf + n] = sqrt(s2_im);
+                }
+                if (P.outlier_mode == 1) {
+                    // sigma_out = raw .* scale * 0.05 ; raw ~ exponential(lambda) ; scale ~ inv_gamma(alpha, beta)
+                    const double dso = 2.0 * so_re * (h_re + h_im);
+                    GW(P.o_so + n, r0 * (0.05 * r1 * dso - P.so_lambda) + jac);
+                    GW(P.o_so + nf + n, 0.05 * r0 * r1 * dso - (P.so_alpha + 1.0) + P.so_beta / r1 + jac);
+                    acc[0] += -P.so_lambda * r0 - (P.so_alpha + 1.0) * t1_[u] - P.so_beta / r1 + jac * (t0_[u] + t1_[u]);
+                } else if (P.outlier_mode == 2) {
+                    GW(P.o_so + n, r0 * (0.05 * 2.0 * so_re * h_re - P.so_lambda) + jac);
+                    GW(P.o_so + nf + n, r1 * (0.05 * 2.0 * so_im * h_im - P.so_lambda) + jac);
+                    acc[0] += -P.so_lambda * (r0 + r1) + jac * (t0_[u] + t1_[u]);
+                }
             }
         }
         chain_reduce<7>(acc, red, sc + S_TMP * NC, tid);
-        if (tid < NC) {
+        if (tid < 6 * NC) {
+            // one thread per (scalar parameter, chain): Rinf_raw, induc_raw ~ std_normal(); error raws ~ std_normal()
+            const int which = tid >> 4;
             const double *S = sc + S_TMP * NC;
-            const double t0 = TH(0), t1 = TH(1);
-            const double rinf_raw = exp(t0), induc_raw = exp(t1);
-            double lp = S[0 * NC + c];
-            // Rinf_raw, induc_raw ~ std_normal(); lower=0 -> log transform
-            GW(0, rinf_raw * (100.0 * S[1 * NC + c] - rinf_raw) + jac);
-            GW(1, induc_raw * (P.induc_scale * S[2 * NC + c] - induc_raw) + jac);
-            lp += -0.5 * rinf_raw * rinf_raw - 0.5 * induc_raw * induc_raw + jac * (t0 + t1);
-            PW(0, rinf_raw); PW(1, induc_raw);
-            const double sums[4] = {S[3 * NC + c], S[4 * NC + c], S[5 * NC + c], S[6 * NC + c]};
+            const double raw = sc[(S_RAW + which) * NC + c];
+            const int j = which < 2 ? which : P.o_err + (which - 2);
+            double dl;                                        // d lp / d(constrained raw), likelihood part
+            if (which == 0) dl = 100.0 * S[1 * NC + c];
+            else if (which == 1) dl = P.induc_scale * S[2 * NC + c];
+            else dl = 0.05 * 2.0 * (0.05 * raw) * S[(3 + which - 2) * NC + c];
+            GW(j, raw * (dl - raw) + jac);
+            PW(j, raw);
+        }
+        if (tid < NC) {
+            double lp = sc[(S_TMP + 0) * NC + c];
+            double tsum = 0.0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double t = TH(P.o_err + j);
-                const double raw = exp(t);
-                const double val = 0.05 * raw;            // sigma_res, alpha_prop, alpha_re, alpha_im
-                GW(P.o_err + j, raw * (0.05 * 2.0 * val * sums[j] - raw) + jac);
-                lp += -0.5 * raw * raw + jac * t;
-                PW(P.o_err + j, raw);
+            for (int q = 0; q < 6; ++q) { const double raw = sc[(S_RAW + q) * NC + c]; lp += -0.5 * raw * raw; }
+            if (io.jacobian) {
+                tsum = TH(0) + TH(1);
+                for (int q = 0; q < 4; ++q) tsum += TH(P.o_err + q);
+                lp += tsum;
             }
             if (P.use_x_sum) {
                 const double xs_raw = sc[S_XSUM * NC + c];
@@ -369,56 +414,80 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
     // ---- phase 3: per block: q-prior, ups prior, back-propagation ------------------------------------
     for (int b = 0; b < P.nblocks; ++b) {
         const DevBlock &B = P.blk[b];
-        const int K = B.K;
-        for (int k = g; k < 8 * B.kpairs; k += NG) {
-            double x = 0.0;
-            if (k < K) { const double t = TH(B.o_x + k); x = B.is_pos ? exp(t) : t; }
-            Xs[k * NC + c] = x;                           // raw x: q uses L * x_raw (Series-Parallel_modelcode.txt:55)
+        const int K = B.K, KP = 8 * B.kpairs;
+        const double *xc = XC + (size_t)P.xc_off[b] * NC;
+        if (cache_x) {
+            for (int k = g; k < KP; k += NG) Xs[k * NC + c] = xc[k * NC + c];
+        } else {
+            for (int k0 = g; k0 < KP; k0 += NG * UK) {
+                double t_[UK];
+#pragma unroll
+                for (int u = 0; u < UK; ++u) { const int k = k0 + NG * u; t_[u] = k < K ? TH(B.o_x + k) : 0.0; }
+#pragma unroll
+                for (int u = 0; u < UK; ++u) {
+                    const int k = k0 + NG * u;
+                    if (k < KP) Xs[k * NC + c] = k < K ? (B.is_pos ? exp(t_[u]) : t_[u]) : 0.0;   // raw x: q uses L * x_raw
+                }
+            }
         }
         __syncthreads();
         BDRT_TILE_PROF(5);
         if (!(P.dbg & 1)) gemm_forward(B.Lf, B.tilesL, B.kpairs, Xs, Lr, wave, lane);     // v = [L0 x; L1 x; L2 x]
         __syncthreads();
         BDRT_TILE_PROF(6);
-        for (int k = g; k < K; k += NG) Xs[k * NC + c] = 0.15 * exp(TH(B.o_ups + k));   // ups = ups_raw*0.15
-        __syncthreads();
         {
             const double d0 = sc[(S_D0 + 3 * b + 0) * NC + c], d1 = sc[(S_D0 + 3 * b + 1) * NC + c],
                          d2 = sc[(S_D0 + 3 * b + 2) * NC + c];
             double acc[4] = {0, 0, 0, 0};                 // lp, Sv0, Sv1, Sv2
-            for (int k = g; k < K; k += NG) {
-                const double u = Xs[k * NC + c];
-                const double iu2 = 1.0 / (u * u);
-                const double v0 = Lr[k * NC + c], v1 = Lr[(K + k) * NC + c], v2 = Lr[(2 * K + k) * NC + c];
-                const double q2 = d0 * v0 * v0 + d1 * v1 * v1 + d2 * v2 * v2;
-                const double t = TH(B.o_ups + k);
-                const double r = u / 0.15;
-                // q ~ normal(0, ups) evaluated on q^2; ups_raw ~ inv_gamma(alpha, beta); log transform
-                acc[0] += -(t + LOG_015) - 0.5 * q2 * iu2 - (P.ups_alpha + 1.0) * t - P.ups_beta / r + jac * t;
-                acc[1] += v0 * v0 * iu2; acc[2] += v1 * v1 * iu2; acc[3] += v2 * v2 * iu2;
-                double gu = -1.0 / u + q2 * iu2 / u;
-                // dups[k] = 0.5*(ups[k+1] - 0.5*(ups[k]+ups[k+2]))/ups[k+1] ~ std_normal()
-                if (k >= 1 && k + 1 < K) {
-                    const double um = Xs[(k - 1) * NC + c], up = Xs[(k + 1) * NC + c];
-                    const double du = 0.5 * (u - 0.5 * (um + up)) / u;
-                    acc[0] += -0.5 * du * du;
-                    gu += -du * 0.25 * (um + up) * iu2;
+            // ups = ups_raw*0.15 for every k first (the dups prior couples neighbours)
+            for (int k0 = g; k0 < K; k0 += NG * UK) {
+                double t_[UK];
+#pragma unroll
+                for (int u = 0; u < UK; ++u) { const int k = k0 + NG * u; t_[u] = k < K ? TH(B.o_ups + k) : 0.0; }
+#pragma unroll
+                for (int u = 0; u < UK; ++u) { const int k = k0 + NG * u; if (k < K) Xs[k * NC + c] = 0.15 * exp(t_[u]); }
+            }
+            __syncthreads();
+            for (int k0 = g; k0 < K; k0 += NG * UK) {
+                double t_[UK];
+#pragma unroll
+                for (int u = 0; u < UK; ++u) { const int k = k0 + NG * u; t_[u] = k < K ? TH(B.o_ups + k) : 0.0; }
+#pragma unroll
+                for (int u = 0; u < UK; ++u) {
+                    const int k = k0 + NG * u;
+                    if (k >= K) continue;
+                    const double uu = Xs[k * NC + c], t = t_[u];
+                    const double iu = 1.0 / uu, iu2 = iu * iu;
+                    const double v0 = Lr[k * NC + c], v1 = Lr[(K + k) * NC + c], v2 = Lr[(2 * K + k) * NC + c];
+                    const double q2 = d0 * v0 * v0 + d1 * v1 * v1 + d2 * v2 * v2;
+                    const double ir = 0.15 * iu;          // 1 / ups_raw
+                    // q ~ normal(0, ups) evaluated on q^2; ups_raw ~ inv_gamma(alpha, beta); log transform
+                    acc[0] += -(t + LOG_015) - 0.5 * q2 * iu2 - (P.ups_alpha + 1.0) * t - P.ups_beta * ir + jac * t;
+                    acc[1] += v0 * v0 * iu2; acc[2] += v1 * v1 * iu2; acc[3] += v2 * v2 * iu2;
+                    double gu = -iu + q2 * iu2 * iu;
+                    // dups[k] = 0.5*(ups[k+1] - 0.5*(ups[k]+ups[k+2]))/ups[k+1] ~ std_normal()
+                    const double um1 = k >= 1 ? Xs[(k - 1) * NC + c] : 1.0, up1 = k + 1 < K ? Xs[(k + 1) * NC + c] : 1.0;
+                    if (k >= 1 && k + 1 < K) {
+                        const double du = 0.5 * (uu - 0.5 * (um1 + up1)) * iu;
+                        acc[0] += -0.5 * du * du;
+                        gu += -du * 0.25 * (um1 + up1) * iu2;
+                    }
+                    if (k >= 2) {                             // k is the right neighbour of centre k-1
+                        const double um2 = Xs[(k - 2) * NC + c], i0 = 1.0 / um1;
+                        const double du = 0.5 * (um1 - 0.5 * (um2 + uu)) * i0;
+                        gu += du * 0.25 * i0;
+                    }
+                    if (k + 2 < K) {                          // k is the left neighbour of centre k+1
+                        const double up2 = Xs[(k + 2) * NC + c], i0 = 1.0 / up1;
+                        const double du = 0.5 * (up1 - 0.5 * (uu + up2)) * i0;
+                        gu += du * 0.25 * i0;
+                    }
+                    GW(B.o_ups + k, uu * gu - (P.ups_alpha + 1.0) + P.ups_beta * ir + jac);
+                    PW(B.o_ups + k, uu * (1.0 / 0.15));
+                    Lr[k * NC + c] = -d0 * v0 * iu2;
+                    Lr[(K + k) * NC + c] = -d1 * v1 * iu2;
+                    Lr[(2 * K + k) * NC + c] = -d2 * v2 * iu2;
                 }
-                if (k >= 2) {                             // k is the right neighbour of centre k-1
-                    const double u0 = Xs[(k - 1) * NC + c], um = Xs[(k - 2) * NC + c];
-                    const double du = 0.5 * (u0 - 0.5 * (um + u)) / u0;
-                    gu += du * 0.25 / u0;
-                }
-                if (k + 2 < K) {                          // k is the left neighbour of centre k+1
-                    const double u0 = Xs[(k + 1) * NC + c], up = Xs[(k + 2) * NC + c];
-                    const double du = 0.5 * (u0 - 0.5 * (u + up)) / u0;
-                    gu += du * 0.25 / u0;
-                }
-                GW(B.o_ups + k, u * gu - (P.ups_alpha + 1.0) + P.ups_beta / r + jac);
-                PW(B.o_ups + k, r);
-                Lr[k * NC + c] = -d0 * v0 * iu2;
-                Lr[(K + k) * NC + c] = -d1 * v1 * iu2;
-                Lr[(2 * K + k) * NC + c] = -d2 * v2 * iu2;
             }
             // rows 3K .. 8*rpairsL of the reduction must be exactly zero
             for (int r = 3 * K + g; r < 8 * B.rpairsL; r += NG) Lr[r * NC + c] = 0.0;
@@ -436,19 +505,18 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
                 for (int r = N2 + g; r < P.ZR; r += NG) Y[r * NC + c] = 0.0;
             }
             chain_reduce<4>(acc, red, sc + S_TMP * NC, tid);
-            if (tid < NC) {
-                const double *S = sc + S_TMP * NC;
-                double lp = S[0 * NC + c];
-                const double dd[3] = {d0, d1, d2};
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {             // d ~ inv_gamma(5,5), log transform
-                    const double t = TH(B.o_d + i);
-                    GW(B.o_d + i, -0.5 * dd[i] * S[(1 + i) * NC + c] - 6.0 + 5.0 / dd[i] + jac);
-                    lp += -6.0 * t - 5.0 / dd[i] + jac * t;
-                    PW(B.o_d + i, dd[i]);
-                }
-                sc[S_LP * NC + c] += lp;
+            if (tid < 3 * NC) {                           // d ~ inv_gamma(5,5), log transform: one thread per (i, chain)
+                const int i = tid >> 4;
+                const double dv = sc[(S_D0 + 3 * b + i) * NC + c];
+                const double idv = 1.0 / dv;
+                GW(B.o_d + i, -0.5 * dv * sc[(S_TMP + 1 + i) * NC + c] - 6.0 + 5.0 * idv + jac);
+                PW(B.o_d + i, dv);
+                sc[(S_TMP + 4 + i) * NC + c] = -5.0 * idv + (jac - 6.0) * TH(B.o_d + i);
             }
+            __syncthreads();
+            if (tid < NC)
+                sc[S_LP * NC + c] += sc[(S_TMP + 0) * NC + c] + sc[(S_TMP + 4) * NC + c] + sc[(S_TMP + 5) * NC + c] +
+                                     sc[(S_TMP + 6) * NC + c];
         }
         __syncthreads();
         const double *Ra = B.is_parallel ? Yp + (size_t)B.yp_slot * P.ZR * NC : Zh;
@@ -458,26 +526,23 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
         BDRT_TILE_PROF(8);
         if (gr) {
             const double xs_term = P.use_x_sum ? -sc[S_XSUM * NC + c] * P.x_sum_invscale * P.x_sum_invscale : 0.0;
-            double lpj[1] = {0.0};
-            for (int k = g; k < K; k += NG) {
-                const double graw = Xs[k * NC + c] + xs_term;
-                if (B.is_pos) {
-                    const double t = TH(B.o_x + k);
-                    GW(B.o_x + k, exp(t) * graw + jac);
-                    lpj[0] += jac * t;
-                } else {
-                    GW(B.o_x + k, graw);
+            for (int k0 = g; k0 < K; k0 += NG * UK) {
+                double x_[UK];
+#pragma unroll
+                for (int u = 0; u < UK; ++u) {
+                    const int k = k0 + NG * u;
+                    x_[u] = 1.0;
+                    if (B.is_pos && k < K) x_[u] = cache_x ? xc[k * NC + c] : TH(B.o_x + k);
+                }
+#pragma unroll
+                for (int u = 0; u < UK; ++u) {
+                    const int k = k0 + NG * u;
+                    if (k >= K) continue;
+                    const double graw = Xs[k * NC + c] + xs_term;
+                    if (B.is_pos) GW(B.o_x + k, (cache_x ? x_[u] : exp(x_[u])) * graw + jac);
+                    else GW(B.o_x + k, graw);
                 }
             }
-            if (io.jacobian && B.is_pos) {
-                chain_reduce<1>(lpj, red, sc + S_TMP * NC, tid);
-                if (tid < NC) sc[S_LP * NC + c] += sc[S_TMP * NC + c];
-            }
-        } else if (io.jacobian && B.is_pos) {
-            double lpj[1] = {0.0};
-            for (int k = g; k < K; k += NG) lpj[0] += TH(B.o_x + k);
-            chain_reduce<1>(lpj, red, sc + S_TMP * NC, tid);
-            if (tid < NC) sc[S_LP * NC + c] += sc[S_TMP * NC + c];
         }
         __syncthreads();
     }

@@ -144,6 +144,13 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
     D.ZR = 8 * rpairsA;
     D.LR = std::max(LR, MIN_LR);
     D.npar = npar;
+    // cache exp(theta_x) in LDS when the workgroup's LDS budget allows it (it always does for one 81x161 block)
+    {
+        int rows = 0;
+        for (int b = 0; b < dat->nblocks; ++b) { D.xc_off[b] = rows; rows += 8 * D.blk[b].kpairs; }
+        D.XCR = rows;
+        if (lds_doubles(D) * sizeof(double) + 8192 > 160 * 1024) { D.XCR = 0; for (int b = 0; b < MAXB; ++b) D.xc_off[b] = 0; }
+    }
     if (const char *e = getenv("BDRT_DEBUG_SKIP")) D.dbg = atoi(e);
     P.lds_bytes = lds_doubles(D) * sizeof(double);
     if (P.lds_bytes > 160 * 1024) {
