@@ -24,6 +24,7 @@ constexpr int NW = NT / 64;   // waves per workgroup
 constexpr int NG = NT / NC;   // row groups in the element-wise phases
 constexpr int MAXB = 3;
 constexpr int NRED = 8;       // max quantities per block reduction
+constexpr int MAXBW = 8;      // half bandwidth handled by the structured (banded Toeplitz) L path
 constexpr int MIN_LR = 192;    // the NUTS kernel borrows the Lr buffer (>= 8*22*16 doubles) for its reductions
 constexpr double LOG_015 = -1.8971199848858813;   // log(0.15): ups = 0.15*ups_raw
 
@@ -42,6 +43,11 @@ struct DevBlock {
     const double *Af; // [tilesA][kpairs][64][2]   A rows x K cols, fragment order
     const double *Lf; // [tilesL][kpairs][64][2]   (L0;L1;L2) rows x K cols
     const double *Bk; // [tilesK][rpairsA+rpairsL][64][2]  transposed: K rows x (2nf pad | 3K pad) reduction
+    // structured path: when L0, L1, L2 are banded Toeplitz (log-uniform tau grid, the
+    // reference's recommended basis) the three L products are 2*MAXBW+1-tap convolutions on the VALU and only A uses MFMA
+    int toep;         // 1: use T[][] instead of Lf / the L part of Bk
+    const double *BkA;// [tilesK][rpairsA][64][2]  transposed A only
+    double T[3][2 * MAXBW + 1];   // T[i][d + MAXBW] = L_i[k][k + d]
 };
 
 struct DevProblem {
@@ -50,6 +56,7 @@ struct DevProblem {
     int outlier_mode, use_x_sum;
     int n_spectra;
     int XR, ZR, LR, npar;     // LDS row counts
+    int toep_all;             // every block takes the structured (banded Toeplitz) L path
     int XCR;                  // rows of the x cache (0: exp(theta_x) is recomputed where needed)
     int xc_off[MAXB];         // first cache row of each block
     int dbg;                  // timing ablation only (env BDRT_DEBUG_SKIP): 1 skip forward GEMMs, 2 skip backward GEMM
@@ -199,6 +206,7 @@ constexpr int UN = 3;      // ... in the Nf-loops (Nf <= 96 -> one batch)
 // All threads of the workgroup must call.  Ends with a __syncthreads().
 // Element-wise phases are written as "issue all loads of a batch, then compute": the strided theta / Z reads are
 // L2 hits whose latency would otherwise be paid once per element.
+template <bool TOEP>
 __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, double *smem)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -269,9 +277,13 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
                         PW(B.o_x + k, xr);
                     }
                     Xs[k * NC + c] = xr * B.x_scale;      // xp = xp_raw * xp_scale (1 for series blocks)
-                    if (cache_x) xc[k * NC + c] = xr;
+                    if (cache_x) xc[(MAXBW + k) * NC + c] = xr;
                 }
             }
+        }
+        if (cache_x && g < MAXBW) {                       // zero borders of the cached x (convolution halo)
+            xc[g * NC + c] = 0.0;
+            xc[(MAXBW + KP + g) * NC + c] = 0.0;
         }
         if (P.use_x_sum || (io.jacobian && B.is_pos)) {
             chain_reduce<2>(xs2, red, sc + S_TMP * NC, tid);
@@ -417,7 +429,7 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
         const int K = B.K, KP = 8 * B.kpairs;
         const double *xc = XC + (size_t)P.xc_off[b] * NC;
         if (cache_x) {
-            for (int k = g; k < KP; k += NG) Xs[k * NC + c] = xc[k * NC + c];
+            if (!TOEP) for (int k = g; k < KP; k += NG) Xs[k * NC + c] = xc[(MAXBW + k) * NC + c];
         } else {
             for (int k0 = g; k0 < KP; k0 += NG * UK) {
                 double t_[UK];
@@ -430,10 +442,30 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
                 }
             }
         }
-        __syncthreads();
-        BDRT_TILE_PROF(5);
-        if (!(P.dbg & 1)) gemm_forward(B.Lf, B.tilesL, B.kpairs, Xs, Lr, wave, lane);     // v = [L0 x; L1 x; L2 x]
-        __syncthreads();
+        const int WS = K + 2 * MAXBW;                     // row stride of the w_i buffers in the structured path
+        double cv_[3][TOEP ? UK : 1];                      // structured path: v_i[k] of this thread's k's
+        if (TOEP) {
+            // v_i = L_i x as a (2*MAXBW+1)-tap convolution of the cached x.  Tap-outer loop: only the three
+            // coefficients of one tap are live (scalar loads), the 18 accumulators stay in registers.
+#pragma unroll
+            for (int u = 0; u < UK; ++u) { cv_[0][u] = 0.0; cv_[1][u] = 0.0; cv_[2][u] = 0.0; }
+#pragma unroll 1
+            for (int d = 0; d <= 2 * MAXBW; ++d) {
+                const double t0 = B.T[0][d], t1 = B.T[1][d], t2 = B.T[2][d];
+#pragma unroll
+                for (int u = 0; u < UK; ++u) {
+                    const int k = g + NG * u;
+                    const double xv = k < K ? xc[(k + d) * NC + c] : 0.0;           // x[k + d - MAXBW]
+                    cv_[0][u] += t0 * xv; cv_[1][u] += t1 * xv; cv_[2][u] += t2 * xv;
+                }
+            }
+            BDRT_TILE_PROF(5);
+        } else {
+            __syncthreads();
+            BDRT_TILE_PROF(5);
+            if (!(P.dbg & 1)) gemm_forward(B.Lf, B.tilesL, B.kpairs, Xs, Lr, wave, lane);     // v = [L0 x; L1 x; L2 x]
+            __syncthreads();
+        }
         BDRT_TILE_PROF(6);
         {
             const double d0 = sc[(S_D0 + 3 * b + 0) * NC + c], d1 = sc[(S_D0 + 3 * b + 1) * NC + c],
@@ -458,7 +490,9 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
                     if (k >= K) continue;
                     const double uu = Xs[k * NC + c], t = t_[u];
                     const double iu = 1.0 / uu, iu2 = iu * iu;
-                    const double v0 = Lr[k * NC + c], v1 = Lr[(K + k) * NC + c], v2 = Lr[(2 * K + k) * NC + c];
+                    double v0, v1, v2;
+                    if (TOEP) { v0 = cv_[0][TOEP ? u : 0]; v1 = cv_[1][TOEP ? u : 0]; v2 = cv_[2][TOEP ? u : 0]; }     // (K <= NG*UK: k0 == g)
+                    else { v0 = Lr[k * NC + c]; v1 = Lr[(K + k) * NC + c]; v2 = Lr[(2 * K + k) * NC + c]; }
                     const double q2 = d0 * v0 * v0 + d1 * v1 * v1 + d2 * v2 * v2;
                     const double ir = 0.15 * iu;          // 1 / ups_raw
                     // q ~ normal(0, ups) evaluated on q^2; ups_raw ~ inv_gamma(alpha, beta); log transform
@@ -484,13 +518,26 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
                     }
                     GW(B.o_ups + k, uu * gu - (P.ups_alpha + 1.0) + P.ups_beta * ir + jac);
                     PW(B.o_ups + k, uu * (1.0 / 0.15));
-                    Lr[k * NC + c] = -d0 * v0 * iu2;
-                    Lr[(K + k) * NC + c] = -d1 * v1 * iu2;
-                    Lr[(2 * K + k) * NC + c] = -d2 * v2 * iu2;
+                    if (TOEP) {
+                        Lr[(MAXBW + k) * NC + c] = -d0 * v0 * iu2;
+                        Lr[(WS + MAXBW + k) * NC + c] = -d1 * v1 * iu2;
+                        Lr[(2 * WS + MAXBW + k) * NC + c] = -d2 * v2 * iu2;
+                    } else {
+                        Lr[k * NC + c] = -d0 * v0 * iu2;
+                        Lr[(K + k) * NC + c] = -d1 * v1 * iu2;
+                        Lr[(2 * K + k) * NC + c] = -d2 * v2 * iu2;
+                    }
+                }
+            }
+            if (TOEP && g < MAXBW) {                    // zero halo of the three w_i buffers
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    Lr[(i * WS + g) * NC + c] = 0.0;
+                    Lr[(i * WS + MAXBW + K + g) * NC + c] = 0.0;
                 }
             }
             // rows 3K .. 8*rpairsL of the reduction must be exactly zero
-            for (int r = 3 * K + g; r < 8 * B.rpairsL; r += NG) Lr[r * NC + c] = 0.0;
+            if (!TOEP) for (int r = 3 * K + g; r < 8 * B.rpairsL; r += NG) Lr[r * NC + c] = 0.0;
             if (B.is_parallel) {
                 // chain through Z_hat_p = conj(Y)/|Y|^2 : g_Y = J^T g_Z
                 double *Y = Yp + (size_t)B.yp_slot * P.ZR * NC;
@@ -521,7 +568,27 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
         __syncthreads();
         const double *Ra = B.is_parallel ? Yp + (size_t)B.yp_slot * P.ZR * NC : Zh;
         BDRT_TILE_PROF(7);
-        if (!(P.dbg & 2)) gemm_backward(B.Bk, B.tilesK, B.rpairsA, B.rpairsL, Ra, Lr, Xs, wave, lane);
+        double gl_[TOEP ? UK : 1];                        // structured path: (sum_i L_i^T w_i)[k] of this thread's k's
+#pragma unroll
+        for (int u = 0; u < (TOEP ? UK : 1); ++u) gl_[u] = 0.0;
+        if (TOEP) {
+            if (!(P.dbg & 2)) gemm_backward(B.BkA, B.tilesK, B.rpairsA, 0, Ra, Lr, Xs, wave, lane);   // A^T g only
+#pragma unroll 1
+            for (int d = 0; d <= 2 * MAXBW; ++d) {
+                // (L^T w)[k] = sum_d' L[k - d'][k] w[k - d'] with d' = d - MAXBW
+                const double t0 = B.T[0][d], t1 = B.T[1][d], t2 = B.T[2][d];
+#pragma unroll
+                for (int u = 0; u < UK; ++u) {
+                    const int k = g + NG * u;
+                    if (k < K) {
+                        const int r = 2 * MAXBW + k - d;                      // = MAXBW + (k - d')
+                        gl_[u] += t0 * Lr[r * NC + c] + t1 * Lr[(WS + r) * NC + c] + t2 * Lr[(2 * WS + r) * NC + c];
+                    }
+                }
+            }
+        } else {
+            if (!(P.dbg & 2)) gemm_backward(B.Bk, B.tilesK, B.rpairsA, B.rpairsL, Ra, Lr, Xs, wave, lane);
+        }
         __syncthreads();
         BDRT_TILE_PROF(8);
         if (gr) {
@@ -532,13 +599,13 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
                 for (int u = 0; u < UK; ++u) {
                     const int k = k0 + NG * u;
                     x_[u] = 1.0;
-                    if (B.is_pos && k < K) x_[u] = cache_x ? xc[k * NC + c] : TH(B.o_x + k);
+                    if (B.is_pos && k < K) x_[u] = cache_x ? xc[(MAXBW + k) * NC + c] : TH(B.o_x + k);
                 }
 #pragma unroll
                 for (int u = 0; u < UK; ++u) {
                     const int k = k0 + NG * u;
                     if (k >= K) continue;
-                    const double graw = Xs[k * NC + c] + xs_term;
+                    const double graw = Xs[k * NC + c] + xs_term + (TOEP ? gl_[TOEP ? u : 0] : 0.0);
                     if (B.is_pos) GW(B.o_x + k, (cache_x ? x_[u] : exp(x_[u])) * graw + jac);
                     else GW(B.o_x + k, graw);
                 }

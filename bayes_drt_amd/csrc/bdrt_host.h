@@ -24,7 +24,9 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 struct Problem {
-    DevProblem dev;                 // device view (pointers are device pointers)
+    DevProblem dev;                 // device view (pointers are device pointers), host copy
+    DevProblem *d_dev = nullptr;    // the same struct in HBM: kernels take it by pointer (uniform scalar loads)
+    int sync_dev();                 // upload `dev` to d_dev
     std::vector<void *> allocs;     // owned device allocations
     std::vector<unsigned char> is_pos;
     hipStream_t stream = nullptr;

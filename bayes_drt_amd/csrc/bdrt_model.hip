@@ -50,6 +50,13 @@ static int upload(Problem &P, const std::vector<T> &h, const T **dptr)
     return 0;
 }
 
+int Problem::sync_dev()
+{
+    if (!d_dev) BDRT_HIP(hipMalloc((void **)&d_dev, sizeof(DevProblem)));
+    BDRT_HIP(hipMemcpy(d_dev, &dev, sizeof(DevProblem), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int Problem::ensure_scratch(size_t rows)
 {
     if (rows <= scratch_rows) return 0;
@@ -105,6 +112,7 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
             for (int k = 0; k < dat->K[b]; ++k) P.is_pos[P.o_x[b] + k] = 0;
 
     int XR = 0, LR = 0, npar = 0;
+    int toep_ok[MAXB] = {0, 0, 0};
     const int rpairsA = cdiv(N2, 8), tilesA = cdiv(N2, 16);
     for (int b = 0; b < dat->nblocks; ++b) {
         const int K = dat->K[b];
@@ -137,6 +145,32 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
         if ((rc = upload(P, pack_fragments(B.tilesA, B.kpairs, Aelem), &B.Af))) return rc;
         if ((rc = upload(P, pack_fragments(B.tilesL, B.kpairs, Lelem), &B.Lf))) return rc;
         if ((rc = upload(P, pack_fragments(B.tilesK, B.rpairsA + B.rpairsL, Telem), &B.Bk))) return rc;
+        auto TAelem = [&](int k, int r) -> double { return Aelem(r, k); };
+        if ((rc = upload(P, pack_fragments(B.tilesK, B.rpairsA, TAelem), &B.BkA))) return rc;
+        // banded-Toeplitz detection of L0, L1, L2 (log-uniform tau grids): every entry outside the band
+        // is below 1e-19 of the largest entry and every diagonal is constant to 1e-12 relative.  The dense MFMA path
+        // remains for any other grid.
+        {
+            bool ok = K <= NG * UK && K > 2 * MAXBW + 2;
+            for (int i = 0; i < 3 && ok; ++i) {
+                const double *L = Ls[i];
+                double mx = 0.0;
+                for (size_t e = 0; e < (size_t)K * K; ++e) mx = std::max(mx, std::fabs(L[e]));
+                for (int d = -(K - 1); d <= K - 1 && ok; ++d) {
+                    double lo = INFINITY, hi = -INFINITY;
+                    for (int r = std::max(0, -d); r < std::min(K, K - d); ++r) {
+                        const double v = L[(size_t)r * K + r + d];
+                        lo = std::min(lo, v); hi = std::max(hi, v);
+                    }
+                    if (std::abs(d) > MAXBW) { if (std::max(std::fabs(lo), std::fabs(hi)) > 1e-19 * mx) ok = false; }
+                    else {
+                        if (hi - lo > 1e-12 * mx) ok = false;
+                        B.T[i][d + MAXBW] = L[(size_t)(K / 2) * K + K / 2 + d];
+                    }
+                }
+            }
+            toep_ok[b] = ok ? 1 : 0;
+        }
         XR = std::max(XR, std::max(8 * B.kpairs, 16 * B.tilesK));
         LR = std::max(LR, std::max(16 * B.tilesL, 16 * B.tilesA));
     }
@@ -147,9 +181,23 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
     // cache exp(theta_x) in LDS when the workgroup's LDS budget allows it (it always does for one 81x161 block)
     {
         int rows = 0;
-        for (int b = 0; b < dat->nblocks; ++b) { D.xc_off[b] = rows; rows += 8 * D.blk[b].kpairs; }
+        for (int b = 0; b < dat->nblocks; ++b) { D.xc_off[b] = rows; rows += 8 * D.blk[b].kpairs + 2 * MAXBW; }
         D.XCR = rows;
-        if (lds_doubles(D) * sizeof(double) + 8192 > 160 * 1024) { D.XCR = 0; for (int b = 0; b < MAXB; ++b) D.xc_off[b] = 0; }
+        // structured path needs the cache and 3 halo-padded w buffers in Lr
+        int LRs = D.LR;
+        for (int b = 0; b < dat->nblocks; ++b) if (toep_ok[b]) LRs = std::max(LRs, (3 * (dat->K[b] + 2 * MAXBW) + 15) / 16 * 16);
+        const int LR0 = D.LR;
+        D.LR = LRs;
+        if (lds_doubles(D) * sizeof(double) + 8192 > 160 * 1024) {
+            D.LR = LR0; D.XCR = 0;
+            for (int b = 0; b < MAXB; ++b) { D.xc_off[b] = 0; toep_ok[b] = 0; }
+            if (lds_doubles(D) * sizeof(double) > 160 * 1024) { /* reported below */ }
+        }
+        bool all = D.XCR > 0 && !getenv("BDRT_DENSE_L");
+        for (int b = 0; b < dat->nblocks; ++b) all = all && toep_ok[b];
+        for (int b = 0; b < dat->nblocks; ++b) D.blk[b].toep = all ? 1 : 0;
+        D.toep_all = all ? 1 : 0;
+        if (!all) D.LR = LR0;
     }
     if (const char *e = getenv("BDRT_DEBUG_SKIP")) D.dbg = atoi(e);
     P.lds_bytes = lds_doubles(D) * sizeof(double);
@@ -178,14 +226,16 @@ static int set_Z(Problem &P, const double *Z, int n_spectra)
     BDRT_HIP(hipMemcpy(P.d_Z, Z, need * sizeof(double), hipMemcpyHostToDevice));
     P.dev.Z = P.d_Z;
     P.dev.n_spectra = n_spectra;
-    return 0;
+    return P.sync_dev();
 }
 
-__global__ __launch_bounds__(NT) void logp_grad_kernel(DevProblem P, const double *theta, const int *spec, int B,
+template <bool TOEP>
+__global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restrict__ Pp, const double *theta, const int *spec, int B,
                                                        int jacobian, double *lp, double *grad, double *params,
                                                        double *Zhat, double *sig)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    const DevProblem &P = *Pp;
     const int c0 = blockIdx.x * NC;
     TileIO io;
     io.theta = theta + (size_t)c0 * P.D;
@@ -200,7 +250,7 @@ __global__ __launch_bounds__(NT) void logp_grad_kernel(DevProblem P, const doubl
     io.sigma_tot = sig ? sig + (size_t)c0 * 2 * P.nf : nullptr;
     io.params = params ? params + (size_t)c0 * P.D : nullptr;
     io.prof = nullptr;
-    logp_grad_tile(P, io, smem);
+    if (TOEP) logp_grad_tile<true>(P, io, smem); else logp_grad_tile<false>(P, io, smem);
 }
 
 int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
@@ -209,13 +259,19 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
     if (B <= 0) return 0;
     static size_t attr_bytes = 0;
     if (p->lds_bytes > attr_bytes) {
-        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)p->lds_bytes));
+        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)p->lds_bytes));
         attr_bytes = p->lds_bytes;
     }
     const int grid = cdiv(B, NC);
-    hipLaunchKernelGGL(logp_grad_kernel, dim3(grid), dim3(NT), p->lds_bytes, stream, p->dev, d_theta, d_spec, B,
-                       jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
+    if (p->dev.toep_all)
+        hipLaunchKernelGGL(logp_grad_kernel<true>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
+                           d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
+    else
+        hipLaunchKernelGGL(logp_grad_kernel<false>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
+                           d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
     BDRT_HIP(hipGetLastError());
     return 0;
 }
@@ -260,6 +316,7 @@ void bdrt_problem_destroy(bdrt_problem *p)
     Problem &P = p->impl;
     for (void *d : P.allocs) hipFree(d);
     if (P.d_Z) hipFree(P.d_Z);
+    if (P.d_dev) hipFree(P.d_dev);
     if (P.d_theta) { hipFree(P.d_theta); hipFree(P.d_grad); hipFree(P.d_lp); hipFree(P.d_spec); }
     if (P.stream) hipStreamDestroy(P.stream);
     delete p;

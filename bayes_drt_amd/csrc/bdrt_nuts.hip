@@ -65,10 +65,11 @@ struct NutsArgs {
 // NJ = elements of a D-vector per lane (D <= 32*NJ): compile-time so that every pass over a chain's vectors is fully
 // unrolled into a batch of independent loads followed by the arithmetic (one memory round trip per stage instead of one
 // per element -- the state vectors of 2048+ chains live in HBM/MALL, not in L2).
-template <int NJ>
-__global__ __launch_bounds__(NT) void nuts_kernel(DevProblem P, NutsParams np, NutsArgs a)
+template <int NJ, bool TOEP>
+__global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    const DevProblem &P = *Pp;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = 2 * wave + (lane >> 5);
     const int l32 = lane & 31;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(DevProblem P, NutsParams np, N
         BDRT_NUTS_PROF(10);
 
         // ---- B: log-posterior + gradient at the new point (MFMA tile) ------------------------------------
-        logp_grad_tile(P, io, smem);
+        logp_grad_tile<TOEP>(P, io, smem);
         if (io.prof && tid == 0) tnp = clock64();
 
         // ---- C: second half kick, kinetic energy, finiteness of the gradient -----------------------------
@@ -627,9 +628,12 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     static size_t attr_bytes = 0;
     if (S.lds_bytes > attr_bytes) {
-        hipError_t e = hipFuncSetAttribute((const void *)nuts_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nuts_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nuts_kernel<27>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
+        hipError_t e = hipSuccess;
+        const void *fns[6] = {(const void *)nuts_kernel<11, true>, (const void *)nuts_kernel<11, false>,
+                              (const void *)nuts_kernel<16, true>, (const void *)nuts_kernel<16, false>,
+                              (const void *)nuts_kernel<27, true>, (const void *)nuts_kernel<27, false>};
+        for (int i = 0; i < 6 && e == hipSuccess; ++i)
+            e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(nuts_kernel, %zu B dynamic LDS) failed: %s", S.lds_bytes, hipGetErrorString(e));
             bdrt_sampler_destroy(s);
@@ -666,9 +670,19 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
     BDRT_HIP(hipEventCreate(&e0));
     BDRT_HIP(hipEventCreate(&e1));
     BDRT_HIP(hipEventRecord(e0, S.stream));
-    if (S.D <= 32 * 11) hipLaunchKernelGGL(nuts_kernel<11>, dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, S.prob->dev, S.np, S.args);
-    else if (S.D <= 32 * 16) hipLaunchKernelGGL(nuts_kernel<16>, dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, S.prob->dev, S.np, S.args);
-    else hipLaunchKernelGGL(nuts_kernel<27>, dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, S.prob->dev, S.np, S.args);
+    {
+        const DevProblem *dp = (const DevProblem *)S.prob->d_dev;
+        const bool tp = S.prob->dev.toep_all != 0;
+#define BDRT_LAUNCH_NUTS(NJV)                                                                                          \
+        do {                                                                                                           \
+            if (tp) hipLaunchKernelGGL((nuts_kernel<NJV, true>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args); \
+            else hipLaunchKernelGGL((nuts_kernel<NJV, false>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);   \
+        } while (0)
+        if (S.D <= 32 * 11) BDRT_LAUNCH_NUTS(11);
+        else if (S.D <= 32 * 16) BDRT_LAUNCH_NUTS(16);
+        else BDRT_LAUNCH_NUTS(27);
+#undef BDRT_LAUNCH_NUTS
+    }
     BDRT_HIP(hipGetLastError());
     BDRT_HIP(hipEventRecord(e1, S.stream));
     S.pending.emplace_back(e0, e1);

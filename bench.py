@@ -2,8 +2,9 @@
 """bench.py -- HMC log-posterior+gradient evaluations per second, 81 frequencies x 161 tau-basis (BASELINE.json).
 
 Workload (config.workload): BASELINE config 4 sharded the weak-scaling way -- every GPU samples the SAME batch of
-512 synthetic 2-ZARC spectra (shared frequency / tau grids => one A/L set in HBM) with 4 NUTS chains per spectrum
-(2048 units per GPU; rank r owns chain ids 4r..4r+3, so 8 GPUs = "32 chains total" per spectrum).  Model
+512 synthetic 2-ZARC spectra (shared frequency / tau grids => one A/L set in HBM) with 8 NUTS chains per spectrum
+(4096 units per GPU = 16 chains on each of the 256 CUs; rank r owns chain ids 8r..8r+7, so 4 GPUs = "32 chains
+total" per spectrum, 8 GPUs = 64).  `--chains 4` gives the 2048-unit variant (half of the CUs idle).  Model
 Series_pos, D = 331, sampling-mode hyper-parameters.  Each unit is a real NUTS chain (device-resident
 transitions, bdrt_nuts.hip); a "step" is one leapfrog round: every unit performs one log-posterior+gradient
 evaluation inside its current tree.  No data-path collective: units are independent.
@@ -30,7 +31,7 @@ FLOP_PER_EVAL = 4.27e5      # 4*(2Nf*K + 3K^2) + ~12k element-wise,
 BYTES_PER_EVAL = 8.39e5     # unique operand bytes when B = 1
 PEAK_F64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix peak; measured 78.05 by tools/mfma_probe (profiles/)
 NF, K = 81, 161
-N_SPECTRA, CHAINS_PER_SPECTRUM = 512, 4
+N_SPECTRA, CHAINS_PER_SPECTRUM = 512, 8
 ROUNDS_PER_LAUNCH = 50
 
 
