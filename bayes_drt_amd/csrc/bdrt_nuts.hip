@@ -112,30 +112,28 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     unsigned long long my_leaps = 0;
     double *TH = row(V_TH), *Pm = row(V_P), *G = row(V_G), *MI = row(V_MINV);
 
+    // half kick + drift of the first evaluation of a freshly created sampler (afterwards every loop body ends with the
+    // kick/drift of the NEXT evaluation, reusing p, g, Minv from registers: stage A' below)
+    if (!s.kicked) {
+        const int ph = s.phase;
+        const double e = ph == PH_EPS ? s.eps : (ph == PH_TREE ? s.dir * s.eps : 0.0);
+        if (ph == PH_INIT || ph == PH_EPS || ph == PH_TREE) {
+            for (int j = l32; j < D; j += 32) {
+                const double p = Pm[j] + 0.5 * e * G[j];
+                Pm[j] = p;
+                TH[j] += e * MI[j] * p;
+            }
+        }
+        s.kicked = 1;
+    }
+    __syncthreads();
+
     for (int round = 0; round < a.rounds; ++round) {
         const int ph0 = s.phase;
         const bool act = ph0 == PH_INIT || ph0 == PH_EPS || ph0 == PH_TREE;
         if (!__syncthreads_or(act)) break;
         const double e = ph0 == PH_EPS ? s.eps : (ph0 == PH_TREE ? s.dir * s.eps : 0.0);
         if (io.prof && tid == 0) tnp = clock64();
-
-        // ---- A: half kick + drift --------------------------------------------------------------------
-        if (act) {
-            double pa_[NJ], ga_[NJ], ma_[NJ], th_[NJ];
-#pragma unroll
-            for (int m = 0; m < NJ; ++m) {
-                const int j = l32 + 32 * m, jj = j;
-                pa_[m] = Pm[jj]; ga_[m] = G[jj]; ma_[m] = MI[jj]; th_[m] = TH[jj];
-            }
-#pragma unroll
-            for (int m = 0; m < NJ; ++m) {
-                const int j = l32 + 32 * m;
-                const double p = pa_[m] + 0.5 * e * ga_[m];
-                if (j < D) { Pm[j] = p; TH[j] = th_[m] + e * ma_[m] * p; }
-            }
-        }
-        __syncthreads();
-        BDRT_NUTS_PROF(10);
 
         // ---- B: log-posterior + gradient at the new point (MFMA tile) ------------------------------------
         logp_grad_tile<TOEP>(P, io, smem);
@@ -158,8 +156,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 const int j = l32 + 32 * m;
                 if (j < D) {
                     const double p = p_[m] + 0.5 * e * g_[m];
-                    p_[m] = p;
-                    Pm[j] = p;
+                    p_[m] = p;                            // written to memory by stage A' / E at the end of the body
                     kin += mi_[m] * p * p;
                     nonfin += isfinite(g_[m]) ? 0.0 : 1.0;
                 }
@@ -416,6 +413,21 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         }
         BDRT_NUTS_PROF(14);
 
+        // ---- A' (common case): the trajectory continues from the point just evaluated: half kick + drift of the NEXT
+        //      leapfrog with p, g, Minv still in registers (theta is the only vector read; p is written once per leapfrog)
+        if (act && next == 0 && s.phase == PH_TREE) {
+            const double e1 = s.dir * s.eps;
+            double th_[NJ];
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; th_[m] = TH[j]; }
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) {
+                const int j = l32 + 32 * m;
+                const double p = p_[m] + 0.5 * e1 * g_[m];
+                if (j < D) { Pm[j] = p; TH[j] = th_[m] + e1 * mi_[m] * p; }
+            }
+        }
+
         // ---- E: sample update, metric adaptation, draw output, preparation of the next leapfrog -----------------
         double kin0 = 0.0;
         if (upds || welf || wend || draw >= 0 || next) {
@@ -478,6 +490,26 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             }
         }
         BDRT_NUTS_PROF(16);
+
+        // ---- A' (other cases): a new start point was written by stage E, or the chain is initialising ----------------
+        if (!(act && next == 0 && ph0 == PH_TREE)) {
+            const int ph1 = s.phase;
+            const double e1 = ph1 == PH_EPS ? s.eps : (ph1 == PH_TREE ? s.dir * s.eps : 0.0);
+            if ((ph1 == PH_INIT || ph1 == PH_EPS || ph1 == PH_TREE) && e1 != 0.0) {
+                double pa_[NJ], ga_[NJ], ma_[NJ], th_[NJ];
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; pa_[m] = Pm[j]; ga_[m] = G[j]; ma_[m] = MI[j]; th_[m] = TH[j]; }
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) {
+                    const int j = l32 + 32 * m;
+                    const double p = pa_[m] + 0.5 * e1 * ga_[m];
+                    if (j < D) { Pm[j] = p; TH[j] = th_[m] + e1 * ma_[m] * p; }
+                }
+            }
+        }
+
+        __syncthreads();
+        BDRT_NUTS_PROF(10);
     }
 
     // ---- write the chain states back -----------------------------------------------------------------------------

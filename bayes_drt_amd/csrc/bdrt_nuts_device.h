@@ -89,7 +89,7 @@ struct ChainState {
     int init_buffer, term_buffer, base_window;
     int n_div, n_maxdepth, n_post;
     int spec, chain_id;
-    int pad_;
+    int kicked;           // the half kick + drift of the upcoming evaluation has already been applied
     double eps;           // nominal step size
     double H0, lsw, lsw_sub, lps, lpq, sum_metro;
     double da_sbar, da_xbar, da_mu;
