@@ -239,6 +239,9 @@ def gen_kats():
             out['info__%s__symmetry' % n] = np.array(str(info.get('symmetry', '')))
         # measured data, when the simulated file of the same name exists
         zf = os.path.join(REF, 'data/simulated/Z_%s.csv' % name)
+        exp = {'LIB_data_qtr': 'DRTtools_LIB_data_qtr.csv', 'LIB_data_qtr_DRT-TpDDT': 'DRTtools_LIB_data_qtr.csv'}
+        if name in exp:
+            zf = os.path.join(REF, 'data/experimental', exp[name])
         if os.path.exists(zf):
             f, Z = read_Z(zf)
             idx = np.argsort(f)[::-1]
