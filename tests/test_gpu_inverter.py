@@ -155,3 +155,35 @@ def test_series_parallel_fit_config5_family():
     assert inv._opt_report['lp'] >= lp_ref[0] - 1e-6
     assert np.sqrt(np.mean(np.abs(inv.predict_Z(f) - Z) ** 2)) < 0.02 * np.mean(np.abs(Z))
     assert inv.predict_Rp() > 0
+
+
+def test_config5_drt_ddt_outliers_K161():
+    """BASELINE config 5: DRT + transmissive planar DDT, both with the 161-point basis, outlier-robust error model
+    (Series-Parallel_pos_outliers, N = 2*Nf, D = 818), spectrum data/simulated/Z_DRT-2-TpDDT_uniform_0.25.csv with three
+    injected outliers: MAP, then a short NUTS run."""
+    from bayes_drt_amd.inversion import Inverter
+    d = load('kat_DRT-2-TpDDT_uniform_0.25')
+    f, Z = d['data_freq'], d['data_Z'].copy()
+    for i in (10, 40, 70):
+        Z[i] *= 1.5
+    bf = np.logspace(10, -6, 161)
+    dists = {'DRT': {'kernel': 'DRT'},
+             'TP-DDT': {'kernel': 'DDT', 'symmetry': 'planar', 'bc': 'transmissive', 'dist_type': 'parallel', 'x_scale': 0.8}}
+    inv = Inverter(basis_freq=bf, distributions=dists)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        inv.fit(f, Z, nonneg=True, outliers=True, mode='optimize', max_iter=2000)
+    assert inv.stan_model_name == 'Series-Parallel_pos_outliers_StanModel.pkl'
+    assert inv._opt_result['theta_unconstrained'].shape == (818,)
+    assert inv.error_fit['sigma_out'].shape == (162,)
+    so = inv.error_fit['sigma_out']
+    assert so[10] > 3 * np.median(so) or so[81 + 10] > 3 * np.median(so)
+    res = np.abs(inv.predict_Z(f) - Z)
+    ok = np.ones(81, bool); ok[[10, 40, 70]] = False
+    assert np.sqrt(np.mean(res[ok] ** 2)) < 0.05 * np.mean(np.abs(Z))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        inv.fit(f, Z, nonneg=True, outliers=True, mode='sample', warmup=30, samples=20, chains=2)
+    fit = inv._sample_result
+    assert fit['xs'].shape == (40, 161) and fit['xp'].shape == (40, 161) and fit['sigma_out'].shape == (40, 162)
+    assert np.all(np.isfinite(fit['Z_hat'])) and fit.n_leapfrog > 0

@@ -17,7 +17,7 @@ L = [gm.construct_L(bf, tau=tau, epsilon=eps, order=o) for o in (0, 1, 2)]
 prob = Problem([dict(A=A, L0=L[0], L1=L[1], L2=0.75 * L[2], nonneg=True)], Z, f, ups_alpha=1.0, ups_beta=0.1)
 ts = torch.cuda.Stream()           # a real (non-null) stream: the events below are recorded on it too
 stream = ts.cuda_stream
-for B in (16, 256, 2048, 4096, 16384, 65536):
+for B in (1, 4, 32, 512, 4096, 16384, 65536):
     th = torch.empty(B, prob.D, dtype=torch.float64, device='cuda').uniform_(-2, 2)
     g = torch.empty_like(th); lp = torch.empty(B, dtype=torch.float64, device='cuda')
     spec = torch.randint(0, 64, (B,), dtype=torch.int32, device='cuda')
