@@ -143,3 +143,20 @@ def test_x_sum_rejection_flag():
     p[lay['x'][0]:lay['x'][0] + prob.Ks[0]] = -10.0
     lp, g = prob.logp_grad(prob.unconstrain(p)[None], jacobian=True)
     assert lp[0] == -np.inf
+
+
+def test_structured_L_path_equals_dense_path(monkeypatch):
+    """The banded-Toeplitz convolution path (chosen automatically for log-uniform tau grids) and the dense MFMA path
+    (any grid; forced with BDRT_DENSE_L=1) evaluate the same density: lp and gradient agree to fp64 round-off."""
+    Problem, orc = _mods()
+    d, blk, kw = _bench_blocks('sample')
+    rng = np.random.default_rng(21)
+    thetas = rng.uniform(-2, 2, (19, 331))
+    fast = Problem([blk], d['Z'], d['freq'], **kw)
+    lp_f, g_f = fast.logp_grad(thetas, jacobian=True)
+    monkeypatch.setenv('BDRT_DENSE_L', '1')
+    dense = Problem([blk], d['Z'], d['freq'], **kw)
+    lp_d, g_d = dense.logp_grad(thetas, jacobian=True)
+    assert np.max(np.abs(lp_f - lp_d) / np.maximum(1.0, np.abs(lp_d))) < 1e-12
+    assert np.max(np.abs(g_f - g_d)) < 1e-11 * max(1.0, np.max(np.abs(g_d)))
+    assert not np.array_equal(g_f, g_d)          # really two different code paths
