@@ -9,6 +9,7 @@
 
 #include "../../include/bdrt.h"
 #include "bdrt_device.h"
+#include "bdrt_tile_s1.h"
 
 namespace bdrt {
 

@@ -198,6 +198,10 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
         for (int b = 0; b < dat->nblocks; ++b) D.blk[b].toep = all ? 1 : 0;
         D.toep_all = all ? 1 : 0;
         if (!all) D.LR = LR0;
+        // headline family on a log-uniform grid: half-wave-per-chain evaluator (bdrt_tile_s1.h)
+        D.fast_s1 = (all && dat->nblocks == 1 && !D.blk[0].is_parallel && D.outlier_mode == 0 && !D.use_x_sum &&
+                     D.blk[0].x_scale == 1.0 && nf <= 32 * UN && D.blk[0].K <= 32 * UK &&
+                     s1_lds_doubles(D) <= lds_doubles(D) && !getenv("BDRT_GENERIC_TILE")) ? 1 : 0;
     }
     if (const char *e = getenv("BDRT_DEBUG_SKIP")) D.dbg = atoi(e);
     P.lds_bytes = lds_doubles(D) * sizeof(double);
@@ -229,7 +233,8 @@ static int set_Z(Problem &P, const double *Z, int n_spectra)
     return P.sync_dev();
 }
 
-template <bool TOEP>
+// MODE 0: dense L path, 1: structured L path (generic tile), 2: fast S1 tile
+template <int MODE>
 __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restrict__ Pp, const double *theta, const int *spec, int B,
                                                        int jacobian, double *lp, double *grad, double *params,
                                                        double *Zhat, double *sig)
@@ -250,7 +255,9 @@ __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restr
     io.sigma_tot = sig ? sig + (size_t)c0 * 2 * P.nf : nullptr;
     io.params = params ? params + (size_t)c0 * P.D : nullptr;
     io.prof = nullptr;
-    if (TOEP) logp_grad_tile<true>(P, io, smem); else logp_grad_tile<false>(P, io, smem);
+    if (MODE == 2) logp_grad_tile_s1(P, io, smem);
+    else if (MODE == 1) logp_grad_tile<true>(P, io, smem);
+    else logp_grad_tile<false>(P, io, smem);
 }
 
 int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
@@ -259,18 +266,23 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
     if (B <= 0) return 0;
     static size_t attr_bytes = 0;
     if (p->lds_bytes > attr_bytes) {
-        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)p->lds_bytes));
-        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)p->lds_bytes));
+        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)p->lds_bytes));
         attr_bytes = p->lds_bytes;
     }
     const int grid = cdiv(B, NC);
-    if (p->dev.toep_all)
-        hipLaunchKernelGGL(logp_grad_kernel<true>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
+    if (p->dev.fast_s1)
+        hipLaunchKernelGGL(logp_grad_kernel<2>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
+                           d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
+    else if (p->dev.toep_all)
+        hipLaunchKernelGGL(logp_grad_kernel<1>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
                            d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
     else
-        hipLaunchKernelGGL(logp_grad_kernel<false>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
+        hipLaunchKernelGGL(logp_grad_kernel<0>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
                            d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
     BDRT_HIP(hipGetLastError());
     return 0;
@@ -346,6 +358,13 @@ static int check_spec(Problem &P, const int *spec, int B)
             set_error("spectrum index %d out of range [0,%d) at row %d", spec[i], P.dev.n_spectra, i);
             return -1;
         }
+    return 0;
+}
+
+// debug only: device buffer [workgroups][8 waves][16] that the S1 tile of the logp kernel fills with clock64() stamps
+int bdrt_debug_set_tile_trace(void *d_buf)
+{
+    BDRT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace), &d_buf, sizeof(void *)));
     return 0;
 }
 

@@ -65,7 +65,7 @@ struct NutsArgs {
 // NJ = elements of a D-vector per lane (D <= 32*NJ): compile-time so that every pass over a chain's vectors is fully
 // unrolled into a batch of independent loads followed by the arithmetic (one memory round trip per stage instead of one
 // per element -- the state vectors of 2048+ chains live in HBM/MALL, not in L2).
-template <int NJ, bool TOEP>
+template <int NJ, int MODE>   // MODE 0: dense L, 1: structured L (generic tile), 2: fast S1 tile
 __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -136,7 +136,8 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         if (io.prof && tid == 0) tnp = clock64();
 
         // ---- B: log-posterior + gradient at the new point (MFMA tile) ------------------------------------
-        logp_grad_tile<TOEP>(P, io, smem);
+        if (MODE == 2) logp_grad_tile_s1(P, io, smem);
+        else logp_grad_tile<MODE == 1>(P, io, smem);
         if (io.prof && tid == 0) tnp = clock64();
 
         // ---- C: second half kick, kinetic energy, finiteness of the gradient -----------------------------
@@ -661,10 +662,11 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     static size_t attr_bytes = 0;
     if (S.lds_bytes > attr_bytes) {
         hipError_t e = hipSuccess;
-        const void *fns[6] = {(const void *)nuts_kernel<11, true>, (const void *)nuts_kernel<11, false>,
-                              (const void *)nuts_kernel<16, true>, (const void *)nuts_kernel<16, false>,
-                              (const void *)nuts_kernel<27, true>, (const void *)nuts_kernel<27, false>};
-        for (int i = 0; i < 6 && e == hipSuccess; ++i)
+        const void *fns[8] = {(const void *)nuts_kernel<11, 1>, (const void *)nuts_kernel<11, 0>,
+                              (const void *)nuts_kernel<16, 1>, (const void *)nuts_kernel<16, 0>,
+                              (const void *)nuts_kernel<27, 1>, (const void *)nuts_kernel<27, 0>,
+                              (const void *)nuts_kernel<11, 2>, (const void *)nuts_kernel<16, 2>};
+        for (int i = 0; i < 8 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(nuts_kernel, %zu B dynamic LDS) failed: %s", S.lds_bytes, hipGetErrorString(e));
@@ -707,10 +709,14 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
         const bool tp = S.prob->dev.toep_all != 0;
 #define BDRT_LAUNCH_NUTS(NJV)                                                                                          \
         do {                                                                                                           \
-            if (tp) hipLaunchKernelGGL((nuts_kernel<NJV, true>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args); \
-            else hipLaunchKernelGGL((nuts_kernel<NJV, false>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);   \
+            if (tp) hipLaunchKernelGGL((nuts_kernel<NJV, 1>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args); \
+            else hipLaunchKernelGGL((nuts_kernel<NJV, 0>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);   \
         } while (0)
-        if (S.D <= 32 * 11) BDRT_LAUNCH_NUTS(11);
+        if (S.prob->dev.fast_s1 && S.D <= 32 * 11)
+            hipLaunchKernelGGL((nuts_kernel<11, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
+        else if (S.prob->dev.fast_s1)
+            hipLaunchKernelGGL((nuts_kernel<16, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
+        else if (S.D <= 32 * 11) BDRT_LAUNCH_NUTS(11);
         else if (S.D <= 32 * 16) BDRT_LAUNCH_NUTS(16);
         else BDRT_LAUNCH_NUTS(27);
 #undef BDRT_LAUNCH_NUTS

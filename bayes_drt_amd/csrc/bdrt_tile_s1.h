@@ -1,0 +1,464 @@
+// bdrt_tile_s1.h -- fast evaluator for the headline model family S1 (Series / Series_pos, one DRT block, no outlier
+// parameters) on log-uniform grids: Series_modelcode.txt / Series_pos_modelcode.txt.
+//
+// Differences from the generic tile (bdrt_device.h):
+//   * chain c of the workgroup is owned by ONE half-wave (wave c/2, lanes 32*(c%2)..+31): every per-chain reduction is
+//     a 5-step xor shuffle, every per-chain scalar lives in registers, the ups neighbour coupling is a lane shuffle.
+//     The only workgroup barriers left are the four around the two MFMA GEMMs (X ready, A.x ready, g_Zhat ready,
+//     A^T g ready) instead of ~24;
+//   * theta / gradient rows are read and written coalesced (lane = element index), which is also the layout of the
+//     device-resident NUTS state, so the sampler and the evaluator share the thread mapping;
+//   * L0, L1, L2 products are 17-tap convolutions on the chain's own LDS column (no cross-wave dependency at all);
+//   * LDS tiles are [row][16] with the column XOR-swizzled by (row & 15): conflict-free for the MFMA operand reads
+//     (16 lanes = one row), 2-way for the column walks of the element-wise code.
+// Numerics are the same formulas as the generic tile; parity is asserted against the oracle and against the generic
+// tile by the GPU tests.
+#pragma once
+#include "bdrt_device.h"
+
+namespace bdrt {
+
+// debug only (tools/tile_trace.py): per-wave timestamps of the phase boundaries, [workgroup][wave][16]
+static __device__ long long *g_tile_trace = nullptr;
+
+__device__ __forceinline__ int swz(int row, int col) { return row * NC + (col ^ (row & 15)); }
+
+__device__ __forceinline__ double hsum(double x)
+{
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 8);
+    x += __shfl_xor(x, 4);
+    x += __shfl_xor(x, 2);
+    x += __shfl_xor(x, 1);
+    return x;
+}
+
+// Orders the LDS traffic of one wave: lanes of a half-wave exchange data through the chain's private LDS row without a
+// workgroup barrier.  The hardware executes a wave's LDS instructions in order; this only stops the compiler from moving
+// a lane's loads/stores across the exchange point (to a single thread they look independent).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// value of lane (l32 + delta) of the same half-wave, for |delta| <= 2; callers handle the wrap to the neighbouring u
+__device__ __forceinline__ double hshift(double x, int delta)
+{
+    const int lane = threadIdx.x & 63;
+    const int src = (lane & 32) | ((lane + delta) & 31);
+    return __shfl(x, src);
+}
+
+// Os[(16 t + i)][c] = sum_k M[16 t + i][k] Bs[k][c] for the tiles t = wave, wave + 8, ... of this wave (swizzled LDS tiles).
+// The packed fragments (bdrt_model.hip::pack_fragments) stream from L2 through two register buffers of GPF operand pairs:
+// while the 2*GPF MFMAs of one chunk issue (~GPF * 128 cycles) the next chunk -- of this tile or of the wave's next tile --
+// is in flight.  The steady-state loop has no conditional loads, so the compiler's s_waitcnt vmcnt counts stay exact
+// (a conditional load forces vmcnt(0) at the merge point, which serialises the stream).
+constexpr int GPF = 7;
+__device__ __forceinline__ void gemm_sw(const double *__restrict__ Mp, int ntiles, int pairs, const double *Bs, double *Os,
+                                        int wave, int lane)
+{
+    typedef double dv2 __attribute__((ext_vector_type(2)));
+    // global (not flat) loads: a flat load also counts on lgkmcnt and would serialise with the LDS operand reads
+    typedef const __attribute__((address_space(1))) dv2 *gp2;
+    const int col = lane & 15, kq = lane >> 4;
+    wave = __builtin_amdgcn_readfirstlane(wave);          // uniform: scalar loop control and address arithmetic
+    if (wave >= ntiles) return;
+    const int nt = (ntiles - wave + NW - 1) / NW;
+    const int nchunk = pairs / GPF, rem = pairs - nchunk * GPF;
+    const int items = nt * nchunk;                       // chunks of this wave, tile-major
+    gp2 base = (gp2) reinterpret_cast<const dv2 *>(Mp) + lane;
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    int l_ti = 0, l_ch = 0;                              // position of the load stream
+    int c_ti = 0, c_ch = 0;                              // position of the compute stream
+    // LDS address of the B operand of operand pair p: rows 8p + kq and 8p + kq + 4, column col swizzled by (row & 15),
+    // which only depends on the parity of p: four lane-constant bases + p * 128 doubles
+    const double *bX[2], *bY[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        bX[e] = Bs + kq * NC + (col ^ (8 * e + kq));
+        bY[e] = Bs + (kq + 4) * NC + (col ^ (8 * e + kq + 4));
+    }
+    auto load = [&](dv2 (&buf)[GPF]) {
+        gp2 p = base + ((size_t)(wave + l_ti * NW) * pairs + (size_t)l_ch * GPF) * 64;
+#pragma unroll
+        for (int i = 0; i < GPF; ++i) buf[i] = p[(size_t)i * 64];
+        if (++l_ch == nchunk) { l_ch = 0; ++l_ti; }
+    };
+    // one chunk: B operands of the chunk from LDS, first MFMA pair, THEN the global loads of the next chunk, then the other
+    // MFMAs.  (The compiler waits with vmcnt(0) before the first MFMA that reads `cur`; issuing the next chunk's loads
+    // after that point keeps them in flight behind ~800 cycles of MFMA work instead of being waited for immediately.)
+    auto step = [&](const dv2 (&cur)[GPF], dv2 (&nxt)[GPF], bool prefetch) {
+        const int p0 = c_ch * GPF;
+        const bool odd = p0 & 1;
+        const double *x0 = (odd ? bX[1] : bX[0]) + p0 * (8 * NC), *x1 = (odd ? bX[0] : bX[1]) + p0 * (8 * NC);
+        const double *y0 = (odd ? bY[1] : bY[0]) + p0 * (8 * NC), *y1 = (odd ? bY[0] : bY[1]) + p0 * (8 * NC);
+        double bx[GPF], by[GPF];
+#pragma unroll
+        for (int i = 0; i < GPF; ++i) {
+            bx[i] = ((i & 1) ? x1 : x0)[i * (8 * NC)];
+            by[i] = ((i & 1) ? y1 : y0)[i * (8 * NC)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = mfma_f64(cur[0].x, bx[0], acc0);
+        acc1 = mfma_f64(cur[0].y, by[0], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (prefetch) load(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 1; i < GPF; ++i) {
+            acc0 = mfma_f64(cur[i].x, bx[i], acc0);
+            acc1 = mfma_f64(cur[i].y, by[i], acc1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (++c_ch == nchunk) {
+            const int t = wave + c_ti * NW;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { const int row = 16 * t + kq + 4 * rr; Os[swz(row, col)] = acc0[rr] + acc1[rr]; }
+            acc0 = d4{0.0, 0.0, 0.0, 0.0}; acc1 = d4{0.0, 0.0, 0.0, 0.0};
+            c_ch = 0; ++c_ti;
+        }
+    };
+    dv2 a[GPF], b[GPF];
+    if (items > 0) load(a);
+    for (int it = 0; it < items; it += 2) {
+        step(a, b, it + 1 < items);
+        if (it + 1 < items) step(b, a, it + 2 < items);
+    }
+    // operand pairs beyond the last full chunk (pairs % GPF; none for the 81 x 161 shape) and tiles narrower than a chunk
+    if (rem > 0) {
+        for (int ti = 0; ti < nt; ++ti) {
+            const int t = wave + ti * NW;
+            d4 r0a = {0.0, 0.0, 0.0, 0.0}, r1a = {0.0, 0.0, 0.0, 0.0};
+            for (int p = nchunk * GPF; p < pairs; ++p) {
+                const dv2 v = base[((size_t)t * pairs + p) * 64];
+                const int r0 = 8 * p + kq, r1 = r0 + 4;
+                r0a = mfma_f64(v.x, Bs[swz(r0, col)], r0a);
+                r1a = mfma_f64(v.y, Bs[swz(r1, col)], r1a);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = 16 * t + kq + 4 * rr;
+                const double prev = nchunk > 0 ? Os[swz(row, col)] : 0.0;
+                Os[swz(row, col)] = prev + r0a[rr] + r1a[rr];
+            }
+        }
+    }
+}
+
+constexpr int RW = 32 * UK + 2 * MAXBW;   // length of a chain's private LDS row (k = 0..191 plus the convolution halo)
+constexpr int NTAP = 2 * MAXBW + 1;
+constexpr int WIN = UK + NTAP - 1;        // 22 values feed the 17-tap convolution of six consecutive k
+
+// LDS: Xs [XR rows][16] | Zh [16*tilesA rows][16] | XRow [16 chains][RW] | WRow [16 chains][RW] | taps [64]
+__host__ __device__ inline size_t s1_lds_doubles(const DevProblem &P)
+{
+    const DevBlock &B = P.blk[0];
+    return (size_t)NC * (P.XR + 16 * B.tilesA) + (size_t)2 * NC * RW + 64;     // + the 3 x 17 convolution taps
+}
+
+// Two thread mappings of a chain's K-vectors inside its half-wave:
+//   M1  k = l32 + 32 u   (u < 6): coalesced global rows, the MFMA operand tile;
+//   M2  k = 6 l32 + u    (u < 6): six consecutive k per lane, so a 17-tap convolution needs one 22-value LDS window per
+//                                 lane instead of 102 reads, and the ups neighbours k-2..k+2 are mostly the lane's own registers.
+// A vector changes mapping through the chain's private LDS row (written in one mapping, read in the other); only the
+// owning half-wave touches that row, so no barrier is involved.  The whole prior chain x -> L x -> w -> L^T w is
+// independent of A x, so it is issued between the forward GEMM and the barrier that publishes A x: the VALU work of one
+// wave overlaps the MFMA work of the other wave on the same SIMD.
+//
+// All threads of the workgroup must call.  Ends with a __syncthreads().
+__device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, double *smem)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = 2 * wave + (lane >> 5);                  // chain owned by this half-wave
+    const int l32 = lane & 31, hb = lane & 32;
+    const DevBlock &B = P.blk[0];
+    const int nf = P.nf, N2 = 2 * nf, K = B.K, KP = 8 * B.kpairs;
+    const bool valid = c < io.nvalid;
+    const int cc = valid ? c : 0;
+    const double jac = io.jacobian ? 1.0 : 0.0;
+
+    double *Xs = smem;
+    double *Zh = Xs + (size_t)P.XR * NC;
+    double *xrow = Zh + (size_t)16 * B.tilesA * NC + (size_t)c * RW;
+    double *wrow = Zh + (size_t)16 * B.tilesA * NC + (size_t)(NC + c) * RW;
+    // convolution taps as LDS broadcast reads: 51 coefficients in scalar registers do not fit next to everything else
+    // (they were spilled to VGPR lanes: ~750 v_readlane/v_writelane per evaluation)
+    double *Tl = Zh + (size_t)16 * B.tilesA * NC + (size_t)2 * NC * RW;
+    if (tid < 3 * NTAP) Tl[tid] = B.T[tid / NTAP][tid % NTAP];
+
+    const double *th = io.theta + (long)cc * io.t_sc;
+    auto TH = [&](int j) -> double { return th[(long)j * io.t_sj]; };
+    double *gr = (io.grad && valid) ? io.grad + (long)cc * io.g_sc : nullptr;
+    auto GW = [&](int j, double v) { if (gr) gr[(long)j * io.g_sj] = v; };
+    double *pr = (io.params && valid) ? io.params + (size_t)cc * P.D : nullptr;
+    auto PW = [&](int j, double v) { if (pr) pr[j] = v; };
+
+    long long tprev = (io.prof && tid == 0) ? clock64() : 0;
+    long long *trc = g_tile_trace ? g_tile_trace + ((size_t)blockIdx.x * NW + wave) * 16 : nullptr;
+#define BDRT_S1_TRACE(slot) do { if (trc && (lane == 0)) trc[slot] = clock64(); } while (0)
+    BDRT_S1_TRACE(0);
+#define BDRT_S1_PROF(slot) do { if (io.prof && tid == 0) { const long long t_ = clock64(); io.prof[slot] += t_ - tprev; tprev = t_; } } while (0)
+
+    // ---- P1 (M1): parameters of this chain: scalars by lanes 0..8, x and ups rows coalesced -----------------------------
+    double sraw = 0.0, st = 0.0;
+    {
+        int j = -1;
+        if (l32 < 2) j = l32;
+        else if (l32 < 6) j = P.o_err + (l32 - 2);
+        else if (l32 < 9) j = B.o_d + (l32 - 6);
+        if (j >= 0) { st = TH(j); sraw = exp(st); PW(j, sraw); }
+    }
+    double lp = 0.0;
+    double x_[UK];
+    {
+        double tx_[UK], tu_[UK];
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+            const int k = l32 + 32 * u;
+            tx_[u] = k < K ? TH(B.o_x + k) : 0.0;
+            tu_[u] = k < K ? TH(B.o_ups + k) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+            const int k = l32 + 32 * u;
+            double xr = 0.0;
+            if (k < K) {
+                xr = B.is_pos ? exp(tx_[u]) : tx_[u];
+                if (B.is_pos) lp += jac * tx_[u];
+                PW(B.o_x + k, xr);
+            }
+            x_[u] = xr;
+            if (k < KP) Xs[swz(k, c)] = xr;
+            xrow[MAXBW + k] = xr;                          // zero beyond K: the convolution halo
+            wrow[MAXBW + k] = tu_[u];                      // theta_ups on its way to mapping M2
+        }
+        if (l32 < MAXBW) {
+            xrow[l32] = 0.0; xrow[MAXBW + 32 * UK + l32] = 0.0;
+            wrow[l32] = 0.0; wrow[MAXBW + 32 * UK + l32] = 0.0;
+        }
+    }
+    const double rinf_raw = __shfl(sraw, hb | 0), induc_raw = __shfl(sraw, hb | 1);
+    const double sres_raw = __shfl(sraw, hb | 2), ap_raw = __shfl(sraw, hb | 3);
+    const double ar_raw = __shfl(sraw, hb | 4), ai_raw = __shfl(sraw, hb | 5);
+    const double d0 = __shfl(sraw, hb | 6), d1 = __shfl(sraw, hb | 7), d2 = __shfl(sraw, hb | 8);
+    // priors of the 9 scalars (std_normal on the six raws, inv_gamma(5,5) on the d's) + log-Jacobian: lane j owns scalar j
+    if (l32 < 6) lp += -0.5 * sraw * sraw + jac * st;
+    else if (l32 < 9) lp += -6.0 * st - 5.0 / sraw + jac * st;
+    BDRT_S1_TRACE(1);
+    __syncthreads();                                                   // B1: X of all 16 chains in the operand tile
+    BDRT_S1_TRACE(2);
+    BDRT_S1_PROF(1);
+    // The two waves that share a SIMD (w and w + 4) take the MFMA part and the VALU part of this phase in opposite order,
+    // so the matrix pipe and the vector pipe of every SIMD are busy at the same time.
+#pragma unroll 1
+    for (int step = 0; step < 2; ++step) {
+    BDRT_S1_TRACE(3 + step);
+    if ((step == 0) == (wave < NW / 2)) {
+        if (!(P.dbg & 1)) gemm_sw(B.Af, B.tilesA, B.kpairs, Xs, Zh, wave, lane);        // Zh = A x  (pad rows come out as exact zeros)
+        continue;
+    }
+
+    // ---- P2 (M2): v_i = L_i x, q / ups / dups priors, w_i, sum_i L_i^T w_i -- all on this chain's private rows -------------
+    if (!(P.dbg & 4)) {
+        const int kb = 6 * l32;                                        // first k of this lane
+        double xw[WIN], tuc[UK];
+#pragma unroll
+        for (int j = 0; j < WIN; ++j) xw[j] = xrow[kb + j];            // x[kb + j - MAXBW]
+#pragma unroll
+        for (int u = 0; u < UK; ++u) tuc[u] = wrow[MAXBW + kb + u];
+        wave_sync();                                                   // every lane holds its x window and theta_ups
+        // v_i = L_i x: three independent 17-tap convolutions of the window (independent accumulators: the latency of one
+        // FMA chain hides behind the other two)
+        double v0_[UK], v1_[UK], v2_[UK];
+#pragma unroll
+        for (int u = 0; u < UK; ++u) { v0_[u] = 0.0; v1_[u] = 0.0; v2_[u] = 0.0; }
+        double tn0 = B.T[0][0], tn1 = B.T[1][0], tn2 = B.T[2][0];
+#pragma unroll
+        for (int d = 0; d < NTAP; ++d) {
+            const double t0 = tn0, t1 = tn1, t2 = tn2;
+            if (d + 1 < NTAP) { tn0 = B.T[0][d + 1]; tn1 = B.T[1][d + 1]; tn2 = B.T[2][d + 1]; }
+            __asm__ volatile("" ::: "memory");       // keeps the tap loads in program order (one tap ahead), not all 51 up front
+#pragma unroll
+            for (int u = 0; u < UK; ++u) { v0_[u] = fma(t0, xw[u + d], v0_[u]); v1_[u] = fma(t1, xw[u + d], v1_[u]); v2_[u] = fma(t2, xw[u + d], v2_[u]); }
+        }
+        // ups of k-2 .. k+7 around the lane's six k: own registers plus two values from each neighbouring lane
+        double ue[UK + 4], ie[UK + 2];                                 // ups of k-2..k+7, 1/ups of k-1..k+6
+#pragma unroll
+        for (int u = 0; u < UK; ++u) { ue[u + 2] = 0.15 * exp(tuc[u]); ie[u + 1] = 1.0 / ue[u + 2]; }
+        {
+            const int lo = hb | ((l32 + 31) & 31), hi = hb | ((l32 + 1) & 31);
+            ue[0] = __shfl(ue[UK], lo); ue[1] = __shfl(ue[UK + 1], lo);
+            ue[UK + 2] = __shfl(ue[2], hi); ue[UK + 3] = __shfl(ue[3], hi);
+            ie[0] = __shfl(ie[UK], lo); ie[UK + 1] = __shfl(ie[1], hi);
+        }
+        BDRT_S1_PROF(5);
+        double sv0 = 0, sv1 = 0, sv2 = 0;
+        double w0_[UK], w1_[UK], w2_[UK], gup[UK];
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+            const int k = kb + u;
+            w0_[u] = 0.0; w1_[u] = 0.0; w2_[u] = 0.0; gup[u] = 0.0;
+            if (k < K) {
+                const double um2 = ue[u], um1 = ue[u + 1], uu = ue[u + 2], up1 = ue[u + 3], up2 = ue[u + 4];
+                const double t = tuc[u];
+                const double iu = ie[u + 1], iu2 = iu * iu;
+                const double v0 = v0_[u], v1 = v1_[u], v2 = v2_[u];
+                const double q2 = d0 * v0 * v0 + d1 * v1 * v1 + d2 * v2 * v2;
+                const double ir = 0.15 * iu;                              // 1 / ups_raw
+                // q ~ normal(0, ups) evaluated on q^2; ups_raw ~ inv_gamma(alpha, beta); log transform
+                lp += -(t + LOG_015) - 0.5 * q2 * iu2 - (P.ups_alpha + 1.0) * t - P.ups_beta * ir + jac * t;
+                sv0 += v0 * v0 * iu2; sv1 += v1 * v1 * iu2; sv2 += v2 * v2 * iu2;
+                double gu = -iu + q2 * iu2 * iu;
+                // dups[k] = 0.5*(ups[k+1] - 0.5*(ups[k]+ups[k+2]))/ups[k+1] ~ std_normal()
+                if (k >= 1 && k + 1 < K) {
+                    const double du = 0.5 * (uu - 0.5 * (um1 + up1)) * iu;
+                    lp += -0.5 * du * du;
+                    gu += -du * 0.25 * (um1 + up1) * iu2;
+                }
+                if (k >= 2) {                                             // k is the right neighbour of centre k-1
+                    const double i0 = ie[u];
+                    const double du = 0.5 * (um1 - 0.5 * (um2 + uu)) * i0;
+                    gu += du * 0.25 * i0;
+                }
+                if (k + 2 < K) {                                          // k is the left neighbour of centre k+1
+                    const double i0 = ie[u + 2];
+                    const double du = 0.5 * (up1 - 0.5 * (uu + up2)) * i0;
+                    gu += du * 0.25 * i0;
+                }
+                gup[u] = uu * gu - (P.ups_alpha + 1.0) + P.ups_beta * ir + jac;
+                PW(B.o_ups + k, uu * (1.0 / 0.15));
+                w0_[u] = -d0 * v0 * iu2; w1_[u] = -d1 * v1 * iu2; w2_[u] = -d2 * v2 * iu2;
+            }
+        }
+        // (L_i^T w_i)[k] = sum_d T_i[d] w_i[k + MAXBW - d]: one window per i through the private row
+        double gl_[UK];
+#pragma unroll
+        for (int u = 0; u < UK; ++u) gl_[u] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int u = 0; u < UK; ++u) wrow[MAXBW + kb + u] = i == 0 ? w0_[u] : (i == 1 ? w1_[u] : w2_[u]);
+            wave_sync();
+            double ww[WIN];
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) ww[j] = wrow[kb + j];         // w_i[kb + j - MAXBW]
+            wave_sync();
+            double tn = B.T[i][0];
+#pragma unroll
+            for (int d = 0; d < NTAP; ++d) {
+                const double t = tn;
+                if (d + 1 < NTAP) tn = B.T[i][d + 1];
+                __asm__ volatile("" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < UK; ++u) gl_[u] = fma(t, ww[u + 2 * MAXBW - d], gl_[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UK; ++u) { xrow[MAXBW + kb + u] = gup[u]; wrow[MAXBW + kb + u] = gl_[u]; }   // back to M1 for the epilogue
+        sv0 = hsum(sv0); sv1 = hsum(sv1); sv2 = hsum(sv2);
+        if (l32 >= 6 && l32 < 9) {                                       // d_i gradients: lane 6+i
+            const double sv = l32 == 6 ? sv0 : (l32 == 7 ? sv1 : sv2);
+            GW(B.o_d + (l32 - 6), -0.5 * sraw * sv - 6.0 + 5.0 / sraw + jac);
+        }
+    }
+    }
+    // measured spectrum of this chain: issued before the barrier so that its latency hides behind the wait
+    double zre_[UN], zim_[UN], wn_[UN];
+    {
+        const int sp = io.spec ? io.spec[cc] : 0;
+        const double *Zm = P.Z + (size_t)sp * N2;
+#pragma unroll
+        for (int v = 0; v < UN; ++v) {
+            const int n = l32 + 32 * v, nn = n < nf ? n : 0;
+            zre_[v] = Zm[nn]; zim_[v] = Zm[nf + nn]; wn_[v] = P.w[nn];
+        }
+    }
+    BDRT_S1_TRACE(5);
+    __syncthreads();                                                   // B2: A x of all chains in Zh
+    BDRT_S1_TRACE(6);
+    BDRT_S1_PROF(7);
+
+    // ---- P3 (n = l32 + 32 v): likelihood Z ~ normal(Z_hat, sigma_tot); g_Zhat in place -------------------------------------
+    const double Rinf = 100.0 * rinf_raw, induc = induc_raw * P.induc_scale;
+    const double s_res = 0.05 * sres_raw, a_p = 0.05 * ap_raw, a_r = 0.05 * ar_raw, a_i = 0.05 * ai_raw;
+    if (!(P.dbg & 8)) {
+        const double c0 = P.sigma_min * P.sigma_min + s_res * s_res;
+        const double ap2 = a_p * a_p, ar2 = a_r * a_r, ai2 = a_i * a_i;
+        double sR = 0, sL = 0, sH = 0, sHz2 = 0, sHzr2 = 0, sHzi2 = 0;
+#pragma unroll
+        for (int v = 0; v < UN; ++v) {
+            const int n = l32 + 32 * v;
+            if (n >= nf) continue;
+            const double wn = wn_[v];
+            const double zr = Zh[swz(n, c)] + Rinf;
+            const double zi = Zh[swz(nf + n, c)] + induc * wn;
+            const double common = ar2 * zr * zr + ai2 * zi * zi;
+            const double s2_re = c0 + ap2 * zr * zr + common;
+            const double s2_im = c0 + ap2 * zi * zi + common;
+            const double e_re = zre_[v] - zr, e_im = zim_[v] - zi;
+            const double prod = s2_re * s2_im, ip = 1.0 / prod;       // one reciprocal and one logarithm per (re, im) pair
+            const double w_re = s2_im * ip, w_im = s2_re * ip;
+            lp += -0.5 * log(prod) - 0.5 * e_re * e_re * w_re - 0.5 * e_im * e_im * w_im;
+            const double h_re = -0.5 * w_re + 0.5 * e_re * e_re * w_re * w_re;
+            const double h_im = -0.5 * w_im + 0.5 * e_im * e_im * w_im * w_im;
+            const double gzr = e_re * w_re + 2.0 * zr * (h_re * (ap2 + ar2) + h_im * ar2);
+            const double gzi = e_im * w_im + 2.0 * zi * (h_im * (ap2 + ai2) + h_re * ai2);
+            Zh[swz(n, c)] = gzr;
+            Zh[swz(nf + n, c)] = gzi;
+            sR += gzr;
+            sL += gzi * wn;
+            sH += h_re + h_im;
+            sHz2 += h_re * zr * zr + h_im * zi * zi;
+            sHzr2 += (h_re + h_im) * zr * zr;
+            sHzi2 += (h_re + h_im) * zi * zi;
+            if (io.Z_hat && valid) { io.Z_hat[(size_t)c * N2 + n] = zr; io.Z_hat[(size_t)c * N2 + nf + n] = zi; }
+            if (io.sigma_tot && valid) {
+                io.sigma_tot[(size_t)c * N2 + n] = sqrt(s2_re);
+                io.sigma_tot[(size_t)c * N2 + nf + n] = sqrt(s2_im);
+            }
+        }
+        sR = hsum(sR); sL = hsum(sL); sH = hsum(sH); sHz2 = hsum(sHz2); sHzr2 = hsum(sHzr2); sHzi2 = hsum(sHzi2);
+        if (l32 < 6) {
+            // d lp / d(raw), likelihood part, of Rinf_raw, induc_raw, sigma_res_raw, alpha_prop/re/im_raw (lane j owns scalar j)
+            double dl;
+            if (l32 == 0) dl = 100.0 * sR;
+            else if (l32 == 1) dl = P.induc_scale * sL;
+            else if (l32 == 2) dl = 0.05 * 2.0 * s_res * sH;
+            else if (l32 == 3) dl = 0.05 * 2.0 * a_p * sHz2;
+            else if (l32 == 4) dl = 0.05 * 2.0 * a_r * sHzr2;
+            else dl = 0.05 * 2.0 * a_i * sHzi2;
+            const int j = l32 < 2 ? l32 : P.o_err + (l32 - 2);
+            GW(j, sraw * (dl - sraw) + jac);
+        }
+    }
+    BDRT_S1_TRACE(7);
+    __syncthreads();                                                   // B3: g_Zhat of all chains in Zh
+    BDRT_S1_TRACE(8);
+    BDRT_S1_PROF(4);
+    if (!(P.dbg & 2)) gemm_sw(B.BkA, B.tilesK, B.rpairsA, Zh, Xs, wave, lane);          // Xs = A^T g_Zhat
+    BDRT_S1_TRACE(9);
+    __syncthreads();                                                   // B4
+    BDRT_S1_TRACE(10);
+    BDRT_S1_PROF(8);
+
+    // ---- epilogue (M1): chain rule through x = exp(theta_x); coalesced gradient rows ----------------------------------------
+#pragma unroll
+    for (int u = 0; u < UK; ++u) {
+        const int k = l32 + 32 * u;
+        if (k < K) {
+            const double graw = Xs[swz(k, c)] + wrow[MAXBW + k];
+            GW(B.o_x + k, B.is_pos ? x_[u] * graw + jac : graw);
+            GW(B.o_ups + k, xrow[MAXBW + k]);
+        }
+    }
+    lp = hsum(lp);
+    if (l32 == 0 && io.lp && valid) io.lp[c] = lp;
+    BDRT_S1_PROF(9);
+    BDRT_S1_TRACE(11);
+    __syncthreads();
+}
+
+}  // namespace bdrt

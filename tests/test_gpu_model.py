@@ -160,3 +160,26 @@ def test_structured_L_path_equals_dense_path(monkeypatch):
     assert np.max(np.abs(lp_f - lp_d) / np.maximum(1.0, np.abs(lp_d))) < 1e-12
     assert np.max(np.abs(g_f - g_d)) < 1e-11 * max(1.0, np.max(np.abs(g_d)))
     assert not np.array_equal(g_f, g_d)          # really two different code paths
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('jacobian', [False, True])
+def test_fast_s1_tile_equals_generic_tile(monkeypatch, jacobian):
+    """The half-wave-per-chain evaluator of the headline family (bdrt_tile_s1.h) and the generic block evaluator
+    (forced with BDRT_GENERIC_TILE=1) are the same function: lp, gradient, constrained parameters, Z_hat, sigma_tot."""
+    Problem, orc = _mods()
+    d, blk, kw = _bench_blocks('sample')
+    rng = np.random.default_rng(22)
+    thetas = rng.uniform(-2, 2, (37, 331))          # 37: two full tiles + a ragged one
+    fast = Problem([blk], d['Z'], d['freq'], **kw)
+    lp_f, g_f = fast.logp_grad(thetas, jacobian=jacobian)
+    tr_f = fast.transformed(thetas)
+    monkeypatch.setenv('BDRT_GENERIC_TILE', '1')
+    gen = Problem([blk], d['Z'], d['freq'], **kw)
+    lp_g, g_g = gen.logp_grad(thetas, jacobian=jacobian)
+    tr_g = gen.transformed(thetas)
+    assert np.max(np.abs(lp_f - lp_g) / np.maximum(1.0, np.abs(lp_g))) < 1e-12
+    assert np.max(np.abs(g_f - g_g)) < 1e-11 * max(1.0, np.max(np.abs(g_g)))
+    for a, b in zip(tr_f, tr_g):
+        assert np.max(np.abs(a - b)) <= 1e-12 * max(1.0, np.max(np.abs(b)))
+    assert not np.array_equal(g_f, g_g)          # really two different code paths
