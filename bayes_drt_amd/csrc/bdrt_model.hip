@@ -255,7 +255,7 @@ __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restr
     io.sigma_tot = sig ? sig + (size_t)c0 * 2 * P.nf : nullptr;
     io.params = params ? params + (size_t)c0 * P.D : nullptr;
     io.prof = nullptr;
-    if (MODE == 2) logp_grad_tile_s1(P, io, smem);
+    if (MODE == 2) logp_grad_tile_s1<false>(P, io, smem);
     else if (MODE == 1) logp_grad_tile<true>(P, io, smem);
     else logp_grad_tile<false>(P, io, smem);
 }

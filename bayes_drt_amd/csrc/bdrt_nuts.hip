@@ -45,6 +45,15 @@ __device__ __forceinline__ double half_sum(double x)
     return x;
 }
 
+// compiler-level ordering of one wave's LDS traffic (lanes of a half-wave exchange data through LDS without a barrier;
+// the hardware executes a wave's LDS instructions in order)
+__device__ __forceinline__ void lds_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct NutsArgs {
     double *vecs;          // [n_wg][V_COUNT][16 chains][ds]  (one contiguous row per chain and vector)
     ChainState *states;    // [n_units]
@@ -79,9 +88,11 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     const int nvalid = min(NC, a.n_units - c0);
     const bool valid = c < nvalid;
 
-    // LDS carve-up: [tile region | lp of the 16 chains | chain states | spectrum ids]
-    const size_t tile_doubles = lds_doubles(P);
-    double *lpn = smem + tile_doubles;
+    // LDS carve-up: [tile region | (fast S1 path: theta rows of the 16 chains) | lp of the 16 chains | chain states | spectrum ids]
+    const size_t tile_doubles = MODE == 2 ? s1_lds_doubles(P) : lds_doubles(P);
+    constexpr int DSL = 32 * NJ;                    // LDS row stride of the theta rows
+    double *thl = smem + tile_doubles;
+    double *lpn = thl + (MODE == 2 ? (size_t)NC * DSL : 0);
     ChainState *sts = reinterpret_cast<ChainState *>(lpn + NC);
     int *spec = reinterpret_cast<int *>(sts + NC);
 
@@ -100,6 +111,12 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     TileIO io;
     io.theta = V + (size_t)V_TH * NC * DS; io.t_sc = DS; io.t_sj = 1;
     io.grad = V + (size_t)V_G * NC * DS; io.g_sc = DS; io.g_sj = 1;
+    if (MODE == 2) {
+        // fast S1 path: theta lives in LDS for the whole launch (read by the tile, updated in place by the leapfrog), and
+        // the tile leaves the gradient in the chain's private LDS row instead of storing it to HBM
+        io.theta = thl; io.t_sc = DSL;
+        io.grad = nullptr;
+    }
     io.lp = lpn;
     io.spec = spec;
     io.nvalid = NC;            // padded columns carry a DONE state and finite vectors
@@ -108,6 +125,9 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     io.prof = a.prof ? a.prof + (size_t)wg * 32 : nullptr;
     long long tnp = 0;
 #define BDRT_NUTS_PROF(slot) do { if (io.prof && tid == 0) { const long long t_ = clock64(); io.prof[slot] += t_ - tnp; tnp = t_; } } while (0)
+    // per-wave stage times (slots 17..24, summed over the 8 waves): where each wave spends the round, incl. the barrier wait
+    long long twv = 0;
+#define BDRT_WAVE_PROF(slot) do { if (io.prof && lane == 0) { const long long t_ = clock64(); atomicAdd((unsigned long long *)&io.prof[slot], (unsigned long long)(t_ - twv)); twv = t_; } } while (0)
 
     unsigned long long my_leaps = 0;
     double *TH = row(V_TH), *Pm = row(V_P), *G = row(V_G), *MI = row(V_MINV);
@@ -126,6 +146,12 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         }
         s.kicked = 1;
     }
+    if (MODE == 2) {
+        double *thr = thl + (size_t)c * DSL;
+        for (int j = l32; j < DSL; j += 32) thr[j] = j < D ? TH[j] : 0.0;
+        TH = thr;                                           // every later theta access of this launch is an LDS access
+        G = s1_grad_row(P, smem, c);                        // where the tile leaves d lp / d theta
+    }
     __syncthreads();
 
     for (int round = 0; round < a.rounds; ++round) {
@@ -134,11 +160,13 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         if (!__syncthreads_or(act)) break;
         const double e = ph0 == PH_EPS ? s.eps : (ph0 == PH_TREE ? s.dir * s.eps : 0.0);
         if (io.prof && tid == 0) tnp = clock64();
+        if (io.prof && lane == 0) twv = clock64();
 
         // ---- B: log-posterior + gradient at the new point (MFMA tile) ------------------------------------
-        if (MODE == 2) logp_grad_tile_s1(P, io, smem);
+        if (MODE == 2) logp_grad_tile_s1<true>(P, io, smem);
         else logp_grad_tile<MODE == 1>(P, io, smem);
         if (io.prof && tid == 0) tnp = clock64();
+        BDRT_WAVE_PROF(17);
 
         // ---- C: second half kick, kinetic energy, finiteness of the gradient -----------------------------
         // (p, g, Minv of this chain stay in registers from here to the end of stage D)
@@ -166,6 +194,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         kin = 0.5 * half_sum(kin);
         nonfin = half_sum(nonfin);
         BDRT_NUTS_PROF(11);
+        BDRT_WAVE_PROF(18);
 
         // ---- S1: per-chain scalar logic after the evaluation (redundant in the 32 lanes of the chain) --------
         bool copyq = false, cur2s = false, tree = false, even = false, last = false;
@@ -246,6 +275,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             }
         }
         BDRT_NUTS_PROF(12);
+        BDRT_WAVE_PROF(19);
 
         // ---- D: proposal copy, checkpoints, running rho, U-turn tests, subtree close ----------------------------
         if (copyq || cur2s) {
@@ -413,6 +443,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             }
         }
         BDRT_NUTS_PROF(14);
+        BDRT_WAVE_PROF(20);
 
         // ---- A' (common case): the trajectory continues from the point just evaluated: half kick + drift of the NEXT
         //      leapfrog with p, g, Minv still in registers (theta is the only vector read; p is written once per leapfrog)
@@ -429,92 +460,150 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             }
         }
 
-        // ---- E: sample update, metric adaptation, draw output, preparation of the next leapfrog -----------------
-        double kin0 = 0.0;
+        BDRT_WAVE_PROF(21);
+        // ---- E: sample update, metric adaptation, draw output, and the start of the next leapfrog when the trajectory does
+        //      not simply continue (new transition, next doubling, step-size search, re-initialisation).  One batch of
+        //      loads per case, everything else in registers, including the half kick + drift of the next evaluation.
         if (upds || welf || wend || draw >= 0 || next) {
             const uint32_t iter = (uint32_t)s.iter, trial = (uint32_t)s.eps_trials, att = (uint32_t)s.init_attempt;
-            const int dir = s.dir;
             double *THS = row(V_THS), *GS = row(V_GS);
-            const double *THQ = row(V_THQ), *GQ = row(V_GQ);
-            double *WM = row(V_WMEAN), *W2 = row(V_WM2);
-            double *dr = (draw >= 0 && valid) ? a.draws + ((size_t)(c0 + c) * np.n_draws + draw) * D : nullptr;
-            const double *ET = row(dir > 0 ? V_THP : V_THM), *EP = row(dir > 0 ? V_PP : V_PM), *EG = row(dir > 0 ? V_GP : V_GM);
-            for (int j = l32; j < D; j += 32) {
-                double ths = THS[j], gs = GS[j];
-                if (upds) { ths = THQ[j]; gs = GQ[j]; THS[j] = ths; GS[j] = gs; }
-                double mi = MI[j];
-                if (welf) {            // Welford (stan::math::welford_var_estimator)
-                    const double delta = ths - WM[j];
-                    const double mean = WM[j] + delta / wn;
-                    WM[j] = mean;
-                    W2[j] += (ths - mean) * delta;
-                }
-                if (wend) {            // var_adaptation::learn_variance
-                    const double var = wn > 1.0 ? W2[j] / (wn - 1.0) : 0.0;
-                    mi = (wn / (wn + 5.0)) * var + 1e-3 * (5.0 / (wn + 5.0));
-                    MI[j] = mi;
-                    WM[j] = 0.0; W2[j] = 0.0;
-                }
-                if (dr) dr[j] = ths;
-                if (next == 1 || next == 3) {
-                    // fresh momentum p ~ N(0, M), M = diag(1/Minv); restart from the current sample
-                    const double z = next == 1 ? rng_normal(rng, (uint32_t)j, RNG_MOMENTUM, 0, iter)
-                                               : rng_normal(rng, (uint32_t)j, RNG_EPS_MOMENTUM, trial, iter);
-                    const double p = z / sqrt(mi);
-                    Pm[j] = p; TH[j] = ths; G[j] = gs;
-                    kin0 += mi * p * p;
-                    if (next == 1) {
-                        row(V_THM)[j] = ths; row(V_THP)[j] = ths;
-                        row(V_PM)[j] = p; row(V_PP)[j] = p;
-                        row(V_GM)[j] = gs; row(V_GP)[j] = gs;
-                        row(V_RHO)[j] = p;
+            double ths_[NJ], gs_[NJ];
+            {
+                // current sample: the proposal of the tree if it was just accepted, else the stored sample
+                const double *ST = upds ? row(V_THQ) : THS, *SG = upds ? row(V_GQ) : GS;
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; ths_[m] = ST[j]; gs_[m] = SG[j]; }
+            }
+            if (upds) {
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; if (j < D) { THS[j] = ths_[m]; GS[j] = gs_[m]; } }
+            }
+            if (welf || wend) {
+                double *WM = row(V_WMEAN), *W2 = row(V_WM2);
+                double wm_[NJ], w2_[NJ];
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; wm_[m] = WM[j]; w2_[m] = W2[j]; }
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) {
+                    const int j = l32 + 32 * m;
+                    if (j < D) {
+                        double mean = wm_[m], m2 = w2_[m];
+                        if (welf) {            // Welford (stan::math::welford_var_estimator)
+                            const double delta = ths_[m] - mean;
+                            mean += delta / wn;
+                            m2 += (ths_[m] - mean) * delta;
+                        }
+                        if (wend) {            // var_adaptation::learn_variance
+                            const double var = wn > 1.0 ? m2 / (wn - 1.0) : 0.0;
+                            mi_[m] = (wn / (wn + 5.0)) * var + 1e-3 * (5.0 / (wn + 5.0));
+                            MI[j] = mi_[m];
+                            mean = 0.0; m2 = 0.0;
+                        }
+                        WM[j] = mean; W2[j] = m2;
                     }
-                } else if (next == 2) {
-                    // continue from the trajectory end in direction dir
-                    TH[j] = ET[j]; Pm[j] = EP[j]; G[j] = EG[j];
-                } else if (next == 4) {
-                    TH[j] = np.init_radius * (2.0 * rng_uniform(rng, (uint32_t)j, RNG_INIT, 0, att, 0) - 1.0);
-                    Pm[j] = 0.0; G[j] = 0.0;
+                }
+            }
+            if (draw >= 0 && valid) {
+                double *dr = a.draws + ((size_t)(c0 + c) * np.n_draws + draw) * D;
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; if (j < D) dr[j] = ths_[m]; }
+            }
+            if (next == 1 || next == 3) {
+                // fresh momentum p ~ N(0, M), M = diag(1/Minv).  Normals 2i and 2i+1 share one Philox block and one
+                // Box-Muller transform: a lane produces PAIRS and the chain's scratch row (its share of the idle tile
+                // LDS) turns them into the lane's own elements j = l32 + 32 m.
+                double *zrow = MODE == 2 ? s1_grad_row(P, smem, c) : smem + (size_t)c * (tile_doubles / NC);
+#pragma unroll
+                for (int mp = 0; mp < (NJ + 1) / 2; ++mp) {
+                    const int i = l32 + 32 * mp;
+                    if (2 * i < D) {
+                        double z0, z1;
+                        rng_normal_pair(rng, (uint32_t)i, next == 1 ? RNG_MOMENTUM : RNG_EPS_MOMENTUM, next == 1 ? 0u : trial, iter, z0, z1);
+                        zrow[2 * i] = z0; zrow[2 * i + 1] = z1;
+                    }
+                }
+                lds_wave_sync();
+                double kin0 = 0.0;
+                double pn_[NJ];
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) {
+                    const int j = l32 + 32 * m;
+                    const double p = j < D ? zrow[j] / sqrt(mi_[m]) : 0.0;
+                    pn_[m] = p;
+                    kin0 += mi_[m] * p * p;
+                }
+                lds_wave_sync();
+                // Hamiltonian at the start point; a new transition also resets the tree and draws its first direction
+                kin0 = half_sum(kin0);
+                s.H0 = -s.lps + 0.5 * kin0;
+                if (next == 1) {
+                    s.lsw = 0.0; s.lsw_sub = -INFINITY; s.depth = 0; s.leaf = 0; s.nleaves = 1;
+                    s.n_leap_iter = 0; s.sum_metro = 0.0;
+                    s.dir = rng_uniform(rng, 0, RNG_DIRECTION, 0, 0, (uint32_t)s.iter) > 0.5 ? 1 : -1;
+                }
+                const double e1 = next == 1 ? s.dir * s.eps : s.eps;
+                double *rTHM = row(V_THM), *rTHP = row(V_THP), *rPM = row(V_PM), *rPP = row(V_PP), *rGM = row(V_GM),
+                       *rGP = row(V_GP), *rRHO = row(V_RHO);
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) {
+                    const int j = l32 + 32 * m;
+                    if (j < D) {
+                        const double p = pn_[m];
+                        if (next == 1) {
+                            rTHM[j] = ths_[m]; rTHP[j] = ths_[m];
+                            rPM[j] = p; rPP[j] = p;
+                            rGM[j] = gs_[m]; rGP[j] = gs_[m];
+                            rRHO[j] = p;
+                        }
+                        const double pk = p + 0.5 * e1 * gs_[m];
+                        Pm[j] = pk;
+                        TH[j] = ths_[m] + e1 * mi_[m] * pk;
+                    }
+                }
+            } else if (next == 2) {
+                // continue from the trajectory end in the new direction
+                const int dir = s.dir;
+                const double e1 = dir * s.eps;
+                const double *ET = row(dir > 0 ? V_THP : V_THM), *EP = row(dir > 0 ? V_PP : V_PM), *EG = row(dir > 0 ? V_GP : V_GM);
+                double et_[NJ], ep_[NJ], eg_[NJ];
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; et_[m] = ET[j]; ep_[m] = EP[j]; eg_[m] = EG[j]; }
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) {
+                    const int j = l32 + 32 * m;
+                    if (j < D) {
+                        const double pk = ep_[m] + 0.5 * e1 * eg_[m];
+                        Pm[j] = pk;
+                        TH[j] = et_[m] + e1 * mi_[m] * pk;
+                    }
+                }
+            } else if (next == 4) {
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) {
+                    const int j = l32 + 32 * m;
+                    if (j < D) {
+                        TH[j] = np.init_radius * (2.0 * rng_uniform(rng, (uint32_t)j, RNG_INIT, 0, att, 0) - 1.0);
+                        Pm[j] = 0.0;
+                    }
                 }
             }
         }
         BDRT_NUTS_PROF(15);
-
-        // ---- S3: Hamiltonian at the start point ---------------------------------------------------------------------
-        if (next == 1 || next == 3) {
-            kin0 = half_sum(kin0);
-            s.H0 = -s.lps + 0.5 * kin0;
-            if (next == 1) {
-                s.lsw = 0.0; s.lsw_sub = -INFINITY; s.depth = 0; s.leaf = 0; s.nleaves = 1;
-                s.n_leap_iter = 0; s.sum_metro = 0.0;
-                s.dir = rng_uniform(rng, 0, RNG_DIRECTION, 0, 0, (uint32_t)s.iter) > 0.5 ? 1 : -1;
-            }
-        }
         BDRT_NUTS_PROF(16);
 
-        // ---- A' (other cases): a new start point was written by stage E, or the chain is initialising ----------------
-        if (!(act && next == 0 && ph0 == PH_TREE)) {
-            const int ph1 = s.phase;
-            const double e1 = ph1 == PH_EPS ? s.eps : (ph1 == PH_TREE ? s.dir * s.eps : 0.0);
-            if ((ph1 == PH_INIT || ph1 == PH_EPS || ph1 == PH_TREE) && e1 != 0.0) {
-                double pa_[NJ], ga_[NJ], ma_[NJ], th_[NJ];
-#pragma unroll
-                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; pa_[m] = Pm[j]; ga_[m] = G[j]; ma_[m] = MI[j]; th_[m] = TH[j]; }
-#pragma unroll
-                for (int m = 0; m < NJ; ++m) {
-                    const int j = l32 + 32 * m;
-                    const double p = pa_[m] + 0.5 * e1 * ga_[m];
-                    if (j < D) { Pm[j] = p; TH[j] = th_[m] + e1 * ma_[m] * p; }
-                }
-            }
-        }
-
+        BDRT_WAVE_PROF(22);
+        if (io.prof && lane == 0 && next) atomicAdd((unsigned long long *)&io.prof[24], 1ull);
         __syncthreads();
+        BDRT_WAVE_PROF(23);
         BDRT_NUTS_PROF(10);
     }
 
     // ---- write the chain states back -----------------------------------------------------------------------------
     __syncthreads();
+    if (MODE == 2) {
+        double *THg = row(V_TH);
+        for (int j = l32; j < D; j += 32) THg[j] = TH[j];
+    }
     if (l32 == 0 && valid) a.states[c0 + c] = s;
     {
         unsigned long long x = my_leaps;      // non-zero only in lane 0 of each half-wave
@@ -534,6 +623,7 @@ struct Sampler {
     NutsArgs args;
     int n_units = 0, n_wg = 0, D = 0;
     size_t lds_bytes = 0;
+    bool use_s1 = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double ms_total = 0.0;
@@ -545,9 +635,11 @@ struct Sampler {
     long long *d_prof = nullptr;
 };
 
-static size_t nuts_lds_bytes(const DevProblem &P)
+static size_t nuts_lds_bytes(const DevProblem &P, bool s1)
 {
-    return (lds_doubles(P) + (size_t)NC) * sizeof(double) + NC * sizeof(ChainState) + NC * sizeof(int) + 16;
+    const int nj = P.D <= 32 * 11 ? 11 : 16;
+    const size_t tile = s1 ? s1_lds_doubles(P) + (size_t)NC * 32 * nj : lds_doubles(P);   // s1: + theta rows
+    return (tile + (size_t)NC) * sizeof(double) + NC * sizeof(ChainState) + NC * sizeof(int) + 16;
 }
 
 }  // namespace bdrt
@@ -604,7 +696,9 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     S.np.init_radius = c.init_radius; S.np.max_deltaH = c.max_deltaH; S.np.stepsize0 = c.stepsize0;
     S.np.seed_lo = (uint32_t)seed; S.np.seed_hi = (uint32_t)(seed >> 32);
     S.np.has_init = init_theta != nullptr;
-    S.lds_bytes = nuts_lds_bytes(P.dev);
+    // the fast S1 kernel (theta rows resident in LDS) when the problem takes that path and the rows fit
+    S.use_s1 = P.dev.fast_s1 && P.dev.D <= 32 * 16 && nuts_lds_bytes(P.dev, true) <= 160 * 1024;
+    S.lds_bytes = nuts_lds_bytes(P.dev, S.use_s1);
     auto fail = [&](const char *msg) -> bdrt_sampler * { set_error("%s", msg); bdrt_sampler_destroy(s); return nullptr; };
     if (S.lds_bytes > 160 * 1024) return fail("bdrt_sampler_create: problem too large for the 160 KiB LDS budget");
     for (int u = 0; u < n_units; ++u)
@@ -712,9 +806,9 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             if (tp) hipLaunchKernelGGL((nuts_kernel<NJV, 1>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args); \
             else hipLaunchKernelGGL((nuts_kernel<NJV, 0>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);   \
         } while (0)
-        if (S.prob->dev.fast_s1 && S.D <= 32 * 11)
+        if (S.use_s1 && S.D <= 32 * 11)
             hipLaunchKernelGGL((nuts_kernel<11, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
-        else if (S.prob->dev.fast_s1)
+        else if (S.use_s1)
             hipLaunchKernelGGL((nuts_kernel<16, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
         else if (S.D <= 32 * 11) BDRT_LAUNCH_NUTS(11);
         else if (S.D <= 32 * 16) BDRT_LAUNCH_NUTS(16);

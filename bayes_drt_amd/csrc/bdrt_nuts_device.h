@@ -64,6 +64,22 @@ __host__ __device__ inline double rng_normal(const Philox &g, uint32_t j, uint32
     return (j & 1) ? r * sin(a) : r * cos(a);
 }
 
+#if defined(__HIPCC__)
+// normals 2i (cosine branch) and 2i+1 (sine branch) of a stream from ONE Philox block and one Box-Muller transform;
+// same values as rng_normal(2i), rng_normal(2i+1) up to the rounding of sin/cos(2 pi u) vs sinpi/cospi(2 u)
+__device__ inline void rng_normal_pair(const Philox &g, uint32_t i, uint32_t purpose, uint32_t trial, uint32_t iter,
+                                       double &z0, double &z1)
+{
+    double u0, u1;
+    rng_uniform2(g, i, purpose, 0, trial, iter, u0, u1);
+    const double r = sqrt(-2.0 * log(u0));
+    double sn, cs;
+    sincospi(2.0 * u1, &sn, &cs);
+    z0 = r * cs;
+    z1 = r * sn;
+}
+#endif
+
 __host__ __device__ inline double log_sum_exp2(double a, double b)
 {
     if (a == -INFINITY) return b;

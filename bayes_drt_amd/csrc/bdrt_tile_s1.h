@@ -148,6 +148,9 @@ __device__ __forceinline__ void gemm_sw(const double *__restrict__ Mp, int ntile
     }
 }
 
+// the chain's private row as seen by the sampler after a LDSIO evaluation: d lp / d theta in parameter order
+__device__ __forceinline__ double *s1_grad_row(const DevProblem &P, double *smem, int c);
+
 constexpr int RW = 32 * UK + 2 * MAXBW;   // length of a chain's private LDS row (k = 0..191 plus the convolution halo)
 constexpr int NTAP = 2 * MAXBW + 1;
 constexpr int WIN = UK + NTAP - 1;        // 22 values feed the 17-tap convolution of six consecutive k
@@ -168,7 +171,11 @@ __host__ __device__ inline size_t s1_lds_doubles(const DevProblem &P)
 // independent of A x, so it is issued between the forward GEMM and the barrier that publishes A x: the VALU work of one
 // wave overlaps the MFMA work of the other wave on the same SIMD.
 //
+// LDSIO (the NUTS kernel): io.theta points to LDS rows (the sampler keeps theta there) and the gradient is not stored to
+// io.grad but left, in parameter order, in the chain's private LDS row (s1_grad_row) for the sampler's next stage.
+//
 // All threads of the workgroup must call.  Ends with a __syncthreads().
+template <bool LDSIO>
 __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, double *smem)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -182,17 +189,19 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
 
     double *Xs = smem;
     double *Zh = Xs + (size_t)P.XR * NC;
-    double *xrow = Zh + (size_t)16 * B.tilesA * NC + (size_t)c * RW;
-    double *wrow = Zh + (size_t)16 * B.tilesA * NC + (size_t)(NC + c) * RW;
+    double *xrow = Zh + (size_t)16 * B.tilesA * NC + (size_t)c * (2 * RW);   // the chain's private row: 2 RW doubles
+    double *wrow = xrow + RW;
     // convolution taps as LDS broadcast reads: 51 coefficients in scalar registers do not fit next to everything else
     // (they were spilled to VGPR lanes: ~750 v_readlane/v_writelane per evaluation)
     double *Tl = Zh + (size_t)16 * B.tilesA * NC + (size_t)2 * NC * RW;
     if (tid < 3 * NTAP) Tl[tid] = B.T[tid / NTAP][tid % NTAP];
 
     const double *th = io.theta + (long)cc * io.t_sc;
-    auto TH = [&](int j) -> double { return th[(long)j * io.t_sj]; };
+    typedef const __attribute__((address_space(3))) double *lds_cptr;
+    auto TH = [&](int j) -> double { return LDSIO ? ((lds_cptr)th)[j] : th[(long)j * io.t_sj]; };
     double *gr = (io.grad && valid) ? io.grad + (long)cc * io.g_sc : nullptr;
-    auto GW = [&](int j, double v) { if (gr) gr[(long)j * io.g_sj] = v; };
+    auto GW = [&](int j, double v) { if (!LDSIO && gr) gr[(long)j * io.g_sj] = v; };
+    double gsc = 0.0;                                      // LDSIO: gradient of the scalar this lane owns (lanes 0..8)
     double *pr = (io.params && valid) ? io.params + (size_t)cc * P.D : nullptr;
     auto PW = [&](int j, double v) { if (pr) pr[j] = v; };
 
@@ -361,7 +370,8 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         sv0 = hsum(sv0); sv1 = hsum(sv1); sv2 = hsum(sv2);
         if (l32 >= 6 && l32 < 9) {                                       // d_i gradients: lane 6+i
             const double sv = l32 == 6 ? sv0 : (l32 == 7 ? sv1 : sv2);
-            GW(B.o_d + (l32 - 6), -0.5 * sraw * sv - 6.0 + 5.0 / sraw + jac);
+            gsc = -0.5 * sraw * sv - 6.0 + 5.0 / sraw + jac;
+            GW(B.o_d + (l32 - 6), gsc);
         }
     }
     }
@@ -431,7 +441,8 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             else if (l32 == 4) dl = 0.05 * 2.0 * a_r * sHzr2;
             else dl = 0.05 * 2.0 * a_i * sHzi2;
             const int j = l32 < 2 ? l32 : P.o_err + (l32 - 2);
-            GW(j, sraw * (dl - sraw) + jac);
+            gsc = sraw * (dl - sraw) + jac;
+            GW(j, gsc);
         }
     }
     BDRT_S1_TRACE(7);
@@ -445,20 +456,38 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     BDRT_S1_PROF(8);
 
     // ---- epilogue (M1): chain rule through x = exp(theta_x); coalesced gradient rows ----------------------------------------
+    double gx_[UK], gu_[UK];
 #pragma unroll
     for (int u = 0; u < UK; ++u) {
         const int k = l32 + 32 * u;
+        gx_[u] = 0.0; gu_[u] = 0.0;
         if (k < K) {
             const double graw = Xs[swz(k, c)] + wrow[MAXBW + k];
-            GW(B.o_x + k, B.is_pos ? x_[u] * graw + jac : graw);
-            GW(B.o_ups + k, xrow[MAXBW + k]);
+            gx_[u] = B.is_pos ? x_[u] * graw + jac : graw;
+            gu_[u] = xrow[MAXBW + k];
+            GW(B.o_x + k, gx_[u]);
+            GW(B.o_ups + k, gu_[u]);
         }
+    }
+    if (LDSIO) {
+        wave_sync();                                                   // all transit values are in registers
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+            const int k = l32 + 32 * u;
+            if (k < K) { xrow[B.o_x + k] = gx_[u]; xrow[B.o_ups + k] = gu_[u]; }
+        }
+        if (l32 < 9) xrow[l32 < 2 ? l32 : (l32 < 6 ? P.o_err + (l32 - 2) : B.o_d + (l32 - 6))] = gsc;
     }
     lp = hsum(lp);
     if (l32 == 0 && io.lp && valid) io.lp[c] = lp;
     BDRT_S1_PROF(9);
     BDRT_S1_TRACE(11);
     __syncthreads();
+}
+
+__device__ __forceinline__ double *s1_grad_row(const DevProblem &P, double *smem, int c)
+{
+    return smem + (size_t)NC * (P.XR + 16 * P.blk[0].tilesA) + (size_t)c * (2 * RW);
 }
 
 }  // namespace bdrt

@@ -200,6 +200,10 @@ def main():
         n_wg = (n_units + 15) // 16
         for k, nm in enumerate(names):
             print('PHASE %-20s %6.2f %%  %9.0f cycles/round' % (nm, 100 * cyc[k] / tot, cyc[k] / n_wg / args.steps), file=sys.stderr)
+        wnames = ['tile', 'C', 'S1', 'D', "A'", "E+S3+A''", 'end-of-round barrier wait']
+        for k, nm in enumerate(wnames):
+            print('WAVE-AVG %-26s %9.0f cycles/round' % (nm, cyc[17 + k] / n_wg / args.steps / 8), file=sys.stderr)
+        print('half-waves per round in stage E (new start point): %.2f of 16' % (cyc[24] / n_wg / args.steps * 2), file=sys.stderr)
     lib.bdrt_sampler_destroy(h)
 
     if world > 1:
