@@ -13,7 +13,7 @@
 //     subtree, uniform (multinomial) sampling inside the new subtree -- realised as weighted reservoir sampling
 //     over the leaves in generation order (same distribution as Stan's pairwise merging);
 //   * generalised U-turn criterion p#_left.rho > 0 && p#_right.rho > 0 on every completed sub-subtree; the
-//     sub-subtree rho's come from a running sum and <= max_depth checkpoints (stored at even leaves only);
+//     sub-subtree rho's are kept per level (binary counter over the leaf index), summed in the order of the recursion;
 //   * divergence when H - H0 > 1000; max tree depth 10;
 //   * warm-up: step-size heuristic + dual averaging (delta, gamma, t0, kappa), windowed diagonal metric
 //     (init_buffer 75 / base_window 25 doubling / term_buffer 50, regularised variance).
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevProblem &P = *Pp;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = 2 * wave + (lane >> 5);
-    const int l32 = lane & 31;
+    int c = 2 * wave + (lane >> 5);
+    int l32 = lane & 31;
     const int D = P.D, DS = a.ds;
     const int wg = blockIdx.x;
     const int c0 = wg * NC;
@@ -155,6 +155,8 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     __syncthreads();
 
     for (int round = 0; round < a.rounds; ++round) {
+        // keep per-lane address arithmetic inside the loop (see the note in bdrt_tile_s1.h): hoisted, it is spilled
+        __asm__ volatile("" : "+v"(c), "+v"(l32));
         const int ph0 = s.phase;
         const bool act = ph0 == PH_INIT || ph0 == PH_EPS || ph0 == PH_TREE;
         if (!__syncthreads_or(act)) break;
@@ -163,23 +165,29 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         if (io.prof && lane == 0) twv = clock64();
 
         // ---- B: log-posterior + gradient at the new point (MFMA tile) ------------------------------------
-        if (MODE == 2) logp_grad_tile_s1<true>(P, io, smem);
-        else logp_grad_tile<MODE == 1>(P, io, smem);
+        // state of this chain that the stages after the evaluation need: momentum, inverse metric, and (odd leaves) the
+        // momentum of the previous leaf.  The fast path issues these loads from inside the evaluation, right before its
+        // backward GEMM; otherwise stage C loads them.
+        double p_[NJ], g_[NJ], mi_[NJ];
+#pragma unroll
+        for (int m = 0; m < NJ; ++m) { p_[m] = 0.0; g_[m] = 0.0; mi_[m] = 1.0; }
+        auto load_state = [&]() {
+            if (act) {
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; p_[m] = Pm[j]; mi_[m] = MI[j]; }
+            }
+        };
+        if (MODE == 2) { logp_grad_tile_s1<true>(P, io, smem); load_state(); }
+        else { logp_grad_tile<MODE == 1>(P, io, smem); load_state(); }
         if (io.prof && tid == 0) tnp = clock64();
         BDRT_WAVE_PROF(17);
 
         // ---- C: second half kick, kinetic energy, finiteness of the gradient -----------------------------
         // (p, g, Minv of this chain stay in registers from here to the end of stage D)
         double kin = 0.0, nonfin = 0.0;
-        double p_[NJ], g_[NJ], mi_[NJ];
-#pragma unroll
-        for (int m = 0; m < NJ; ++m) { p_[m] = 0.0; g_[m] = 0.0; mi_[m] = 1.0; }
         if (act) {
 #pragma unroll
-            for (int m = 0; m < NJ; ++m) {
-                const int j = l32 + 32 * m, jj = j;
-                p_[m] = Pm[jj]; g_[m] = G[jj]; mi_[m] = MI[jj];
-            }
+            for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; g_[m] = G[j]; }
 #pragma unroll
             for (int m = 0; m < NJ; ++m) {
                 const int j = l32 + 32 * m;
@@ -197,9 +205,9 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         BDRT_WAVE_PROF(18);
 
         // ---- S1: per-chain scalar logic after the evaluation (redundant in the 32 lanes of the chain) --------
-        bool copyq = false, cur2s = false, tree = false, even = false, last = false;
+        bool copyq = false, cur2s = false, tree = false, last = false;
         bool upds = false, welf = false, wend = false;
-        int nm = 0, ck = 0, endt = 0, next = 0, draw = -1;
+        int nm = 0, endt = 0, next = 0, draw = -1;
         double wn = 0.0;
         const int dir_now = s.dir;
         const int leaf_now = s.leaf;
@@ -267,9 +275,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     if (leaf_now == 0 || u < exp(w - lsw_new)) { copyq = true; s.lpq = lp; }
                     s.lsw_sub = lsw_new;
                     tree = true;
-                    ck = __popc((unsigned)(leaf_now >> 1));
-                    if ((leaf_now & 1) == 0) even = true;
-                    else { while ((leaf_now >> nm) & 1) ++nm; }     // trailing ones = sub-subtrees ending here
+                    while ((leaf_now >> nm) & 1) ++nm;              // trailing ones = sub-subtrees ending here
                     last = leaf_now == s.nleaves - 1;
                 }
             }
@@ -293,42 +299,50 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             }
         }
         if (tree) {
-            double *RHOC = row(V_RHOC);
-            double rc_[NJ];
-            // running sum of the momenta of the new subtree; checkpoint (sum before, p) at even leaves
-            if (leaf_now == 0) {
+            // Binary-counter bookkeeping of the new subtree (leaves arrive in time order): level l of the checkpoint rows
+            // holds the completed left sub-subtree of 2^l leaves that still waits for its sibling -- rho (sum of momenta,
+            // V_CKC + l) and the momentum of its first leaf (V_CKP + l; at level 0 the two coincide and only V_CKP is used).
+            // A leaf with nm trailing one bits closes nm sub-subtrees: each merge is one generalised U-turn test
+            // (Stan 2.19 base_nuts::build_tree: compute_criterion(p_sharp_left, p_sharp_right, rho_subtree)).  The sums
+            // associate exactly like the recursion does.
+            double rc_[NJ], cpl_[NJ];                  // rho / first momentum of the sub-subtree that ends at this leaf
 #pragma unroll
-                for (int m = 0; m < NJ; ++m) rc_[m] = 0.0;
-            } else {
-#pragma unroll
-                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; rc_[m] = RHOC[j]; }
-            }
-            if (even) {
-                double *CKC = row(V_CKC + ck), *CKP = row(V_CKP + ck);
-#pragma unroll
-                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; if (j < D) { CKC[j] = rc_[m]; CKP[j] = p_[m]; } }
-            }
-#pragma unroll
-            for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; rc_[m] += p_[m]; if (j < D) RHOC[j] = rc_[m]; }
-            // generalised U-turn test of every sub-subtree that ends at this (odd) leaf
+            for (int m = 0; m < NJ; ++m) { rc_[m] = p_[m]; cpl_[m] = p_[m]; }
             bool ok = true;
             for (int l = 0; l < nm; ++l) {
-                const double *CKC = row(V_CKC + ck - l), *CKP = row(V_CKP + ck - l);
-                double cc_[NJ], cp_[NJ];
+                double lr_[NJ], lp_[NJ];
+                if (l == 0) {
+                    const double *PL = row(V_CKP);
 #pragma unroll
-                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m, jj = j; cc_[m] = CKC[jj]; cp_[m] = CKP[jj]; }
+                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; lp_[m] = PL[j]; lr_[m] = lp_[m]; }
+                } else {
+                    const double *RL = row(V_CKC + l), *PL = row(V_CKP + l);
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; lr_[m] = RL[j]; lp_[m] = PL[j]; }
+                }
                 double a0 = 0.0, a1 = 0.0;
 #pragma unroll
                 for (int m = 0; m < NJ; ++m) {
                     const int j = l32 + 32 * m;
                     if (j < D) {
-                        const double rho = rc_[m] - cc_[m];
-                        a0 += mi_[m] * cp_[m] * rho;
+                        const double rho = lr_[m] + rc_[m];
+                        a0 += mi_[m] * lp_[m] * rho;
                         a1 += mi_[m] * p_[m] * rho;
+                        rc_[m] = rho;
+                        cpl_[m] = lp_[m];
                     }
                 }
                 a0 = half_sum(a0); a1 = half_sum(a1);
                 ok = ok && (a0 > 0.0) && (a1 > 0.0);
+            }
+            if (ok && !last) {
+                // the sub-subtree of 2^nm leaves that ends here becomes the waiting left sibling of level nm
+                double *PLn = row(V_CKP + nm), *RLn = row(V_CKC + nm);
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) {
+                    const int j = l32 + 32 * m;
+                    if (j < D) { PLn[j] = cpl_[m]; if (nm > 0) RLn[j] = rc_[m]; }
+                }
             }
             if (!ok) {
                 endt = 1;                                   // U-turn inside the new subtree: discard it, stop

@@ -175,10 +175,19 @@ __host__ __device__ inline size_t s1_lds_doubles(const DevProblem &P)
 // io.grad but left, in parameter order, in the chain's private LDS row (s1_grad_row) for the sampler's next stage.
 //
 // All threads of the workgroup must call.  Ends with a __syncthreads().
-template <bool LDSIO>
-__device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, double *smem)
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `before_backward` runs right before the backward GEMM (the last ~10 k cycles of the evaluation): the sampler uses it to
+// issue the global loads of the state it needs next, so that their latency hides behind the MFMA work.
+template <bool LDSIO, class Hook = NoHook>
+__device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, double *smem, Hook before_backward = Hook())
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x;
+    // Opaque to the optimiser: inside the sampler's round loop everything derived from the thread index is loop invariant,
+    // gets hoisted out of the loop by the hundreds (LDS addresses, swizzle offsets, row pointers) and is then spilled to
+    // scratch and reloaded every round.  Recomputing a few integer ops per evaluation is far cheaper.
+    __asm__ volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int c = 2 * wave + (lane >> 5);                  // chain owned by this half-wave
     const int l32 = lane & 31, hb = lane & 32;
     const DevBlock &B = P.blk[0];
@@ -249,9 +258,6 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             wrow[l32] = 0.0; wrow[MAXBW + 32 * UK + l32] = 0.0;
         }
     }
-    const double rinf_raw = __shfl(sraw, hb | 0), induc_raw = __shfl(sraw, hb | 1);
-    const double sres_raw = __shfl(sraw, hb | 2), ap_raw = __shfl(sraw, hb | 3);
-    const double ar_raw = __shfl(sraw, hb | 4), ai_raw = __shfl(sraw, hb | 5);
     const double d0 = __shfl(sraw, hb | 6), d1 = __shfl(sraw, hb | 7), d2 = __shfl(sraw, hb | 8);
     // priors of the 9 scalars (std_normal on the six raws, inv_gamma(5,5) on the d's) + log-Jacobian: lane j owns scalar j
     if (l32 < 6) lp += -0.5 * sraw * sraw + jac * st;
@@ -341,6 +347,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
                 PW(B.o_ups + k, uu * (1.0 / 0.15));
                 w0_[u] = -d0 * v0 * iu2; w1_[u] = -d1 * v1 * iu2; w2_[u] = -d2 * v2 * iu2;
             }
+            __builtin_amdgcn_sched_barrier(0);     // one k at a time: interleaving all six only inflates the register peak
         }
         // (L_i^T w_i)[k] = sum_d T_i[d] w_i[k + MAXBW - d]: one window per i through the private row
         double gl_[UK];
@@ -392,8 +399,10 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     BDRT_S1_PROF(7);
 
     // ---- P3 (n = l32 + 32 v): likelihood Z ~ normal(Z_hat, sigma_tot); g_Zhat in place -------------------------------------
-    const double Rinf = 100.0 * rinf_raw, induc = induc_raw * P.induc_scale;
-    const double s_res = 0.05 * sres_raw, a_p = 0.05 * ap_raw, a_r = 0.05 * ar_raw, a_i = 0.05 * ai_raw;
+    // the six scalar parameters of this chain, broadcast from the lanes that own them (lane j holds scalar j in sraw)
+    const double Rinf = 100.0 * __shfl(sraw, hb | 0), induc = __shfl(sraw, hb | 1) * P.induc_scale;
+    const double s_res = 0.05 * __shfl(sraw, hb | 2), a_p = 0.05 * __shfl(sraw, hb | 3), a_r = 0.05 * __shfl(sraw, hb | 4),
+                 a_i = 0.05 * __shfl(sraw, hb | 5);
     if (!(P.dbg & 8)) {
         const double c0 = P.sigma_min * P.sigma_min + s_res * s_res;
         const double ap2 = a_p * a_p, ar2 = a_r * a_r, ai2 = a_i * a_i;
@@ -449,6 +458,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     __syncthreads();                                                   // B3: g_Zhat of all chains in Zh
     BDRT_S1_TRACE(8);
     BDRT_S1_PROF(4);
+    before_backward();
     if (!(P.dbg & 2)) gemm_sw(B.BkA, B.tilesK, B.rpairsA, Zh, Xs, wave, lane);          // Xs = A^T g_Zhat
     BDRT_S1_TRACE(9);
     __syncthreads();                                                   // B4
