@@ -210,7 +210,11 @@ constexpr int UN = 3;      // ... in the Nf-loops (Nf <= 96 -> one batch)
 template <bool TOEP>
 __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, double *smem)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x;
+    // opaque to the optimiser: inside the sampler's round loop everything derived from the thread index is loop
+    // invariant, gets hoisted by the hundreds (addresses, offsets) and is then spilled and reloaded every round
+    __asm__ volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int c = tid & (NC - 1), g = tid >> 4;          // chain column, row group
     const int nf = P.nf, N2 = 2 * nf;
     const bool valid = c < io.nvalid;
