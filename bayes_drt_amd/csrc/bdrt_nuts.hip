@@ -152,14 +152,19 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         TH = thr;                                           // every later theta access of this launch is an LDS access
         G = s1_grad_row(P, smem, c);                        // where the tile leaves d lp / d theta
     }
-    __syncthreads();
+    // one barrier per round boundary that also votes on whether any chain of the workgroup is still running
+    int any_act;
+    {
+        const int ph = s.phase;
+        any_act = __syncthreads_or(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE);
+    }
 
     for (int round = 0; round < a.rounds; ++round) {
         // keep per-lane address arithmetic inside the loop (see the note in bdrt_tile_s1.h): hoisted, it is spilled
         __asm__ volatile("" : "+v"(c), "+v"(l32));
         const int ph0 = s.phase;
         const bool act = ph0 == PH_INIT || ph0 == PH_EPS || ph0 == PH_TREE;
-        if (!__syncthreads_or(act)) break;
+        if (!any_act) break;
         const double e = ph0 == PH_EPS ? s.eps : (ph0 == PH_TREE ? s.dir * s.eps : 0.0);
         if (io.prof && tid == 0) tnp = clock64();
         if (io.prof && lane == 0) twv = clock64();
@@ -607,7 +612,10 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 
         BDRT_WAVE_PROF(22);
         if (io.prof && lane == 0 && next) atomicAdd((unsigned long long *)&io.prof[24], 1ull);
-        __syncthreads();
+        {
+            const int ph = s.phase;
+            any_act = __syncthreads_or(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE);
+        }
         BDRT_WAVE_PROF(23);
         BDRT_NUTS_PROF(10);
     }

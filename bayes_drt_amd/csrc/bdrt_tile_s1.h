@@ -492,7 +492,8 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     if (l32 == 0 && io.lp && valid) io.lp[c] = lp;
     BDRT_S1_PROF(9);
     BDRT_S1_TRACE(11);
-    __syncthreads();
+    // LDSIO: what follows in the sampler only touches this chain's own rows; its end-of-round barrier closes the round
+    if (LDSIO) wave_sync(); else __syncthreads();
 }
 
 __device__ __forceinline__ double *s1_grad_row(const DevProblem &P, double *smem, int c)
