@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_EVAL = 4.27e5      # 4*(2Nf*K + 3K^2) + ~12k element-wise, Nf=81, K=161
 BYTES_PER_EVAL = 8.39e5     # unique operand bytes when B = 1
+# what the structured path really executes per evaluation on a log-uniform grid: A GEMMs on padded 176 x 168 tiles
+# (2 * 462 MFMA * 2048 flop / 16 chains = 1.18e5) + six 17-tap convolutions (3.3e4) + ~1.5e4 element-wise
+FLOP_PER_EVAL_EXECUTED = 1.66e5
 PEAK_F64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix peak; measured 78.05 by tools/mfma_probe (profiles/)
 NF, K = 81, 161
 N_SPECTRA, CHAINS_PER_SPECTRUM = 512, 8
@@ -239,7 +242,8 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F64_MFMA_TFLOPS, 'traffic': traffic,
                          'kernel': 'nuts_kernel', 'avg_launch_ms': avg_ms, 'launches': launches,
-                         'hbm_frac_B1_accounting': value / args.gpus * BYTES_PER_EVAL / 8e12},
+                         'hbm_frac_B1_accounting': value / args.gpus * BYTES_PER_EVAL / 8e12,
+                         'executed_tflops_structured_path': achieved * FLOP_PER_EVAL_EXECUTED / FLOP_PER_EVAL},
         }
         if cpu is not None:
             line['cpu_baseline'] = cpu
