@@ -67,6 +67,7 @@ SYMBOLS = [
     'bdrt_sampler_phase_profile',
     'bdrt_sample',
     'bdrt_gram', 'bdrt_qp_box',
+    'bdrt_percentiles', 'bdrt_sampler_percentiles',
     'bdrt_last_error', 'bdrt_device_count', 'bdrt_set_device', 'bdrt_version',
 ]
 
@@ -123,6 +124,8 @@ def load_library():
                                 vp]
     lib.bdrt_gram.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.bdrt_qp_box.argtypes = [vp, vp, vp, C.c_int, vp, vp]
+    lib.bdrt_percentiles.argtypes = [vp, C.c_int, C.c_int, C.c_long, vp, C.c_int, vp, vp, C.c_int, vp]
+    lib.bdrt_sampler_percentiles.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
     lib.bdrt_set_device.argtypes = [C.c_int]
     _LIB = lib
     return lib

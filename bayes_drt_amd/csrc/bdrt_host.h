@@ -48,6 +48,10 @@ struct Problem {
 int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
                      double *d_grad, double *d_params, double *d_Zhat, double *d_sig, hipStream_t stream);
 
+// percentiles of X Phi^T + bias (Phi == nullptr: of X itself) over the rows of a DEVICE matrix X; Phi, bias, q, out: host
+int post_percentiles_device(const double *dX, int rows, int K, long ldx, const double *Phi, int M, const double *bias,
+                            const double *q, int nq, double *out);
+
 }  // namespace bdrt
 
 struct bdrt_problem {

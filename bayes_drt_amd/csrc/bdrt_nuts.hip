@@ -945,6 +945,23 @@ int bdrt_sampler_phase_profile(bdrt_sampler *s, int enable, long long *cycles32)
     return 0;
 }
 
+int bdrt_sampler_percentiles(bdrt_sampler *s, int unit_lo, int unit_hi, int col0, int ncols, const double *Phi, int M,
+                             const double *bias, const double *q, int nq, double *out)
+{
+    if (!s || !q || nq < 1 || !out) { set_error("bdrt_sampler_percentiles: null argument"); return -1; }
+    Sampler &S = s->impl;
+    if (unit_lo < 0 || unit_hi > S.n_units || unit_lo >= unit_hi || col0 < 0 || ncols < 1 || col0 + ncols > S.D ||
+        (Phi && M < 1) || S.np.n_draws < 1) {
+        set_error("bdrt_sampler_percentiles: bad unit / column range");
+        return -1;
+    }
+    BDRT_HIP(hipStreamSynchronize(S.stream));
+    const long rows = (long)(unit_hi - unit_lo) * S.np.n_draws;
+    if (rows > (1L << 30)) { set_error("bdrt_sampler_percentiles: too many rows"); return -1; }
+    const double *dX = S.args.draws + (size_t)unit_lo * S.np.n_draws * S.D + col0;
+    return post_percentiles_device(dX, (int)rows, ncols, (long)S.D, Phi, M, bias, q, nq, out);
+}
+
 int bdrt_sample(bdrt_problem *p, int n_units, const int *spec, const int *chain_id, int warmup, int n_draws,
                 uint64_t seed, const double *init_theta, const bdrt_nuts_control *ctrl, double *draws, double *lp,
                 bdrt_chain_diag *diag)

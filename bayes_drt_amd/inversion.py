@@ -16,7 +16,7 @@ from copy import deepcopy
 
 import numpy as np
 
-from . import _lib
+from . import _lib, post
 from ._lib import f64, ptr
 from .matrices import construct_A, construct_L, construct_M
 from .stan_models import load_pickle
@@ -771,7 +771,7 @@ class Inverter:
         """Percentile of each coefficient over the draws (then rescaled) -- per coefficient, as the reference does (:2547-2566, H6)."""
         if self.fit_type != 'bayes':
             raise ValueError('Percentile prediction is only available for bayes_fit')
-        coef = np.percentile(self._sample_result[self._get_stan_coef_name(distribution_name)], percentile, axis=0)
+        coef = post.percentile(self._sample_result[self._get_stan_coef_name(distribution_name)], percentile, axis=0)
         return self._rescale_coef(coef, self.distributions[distribution_name]['dist_type'])
 
     # ================================================================== prediction (reference :2571-3311)
@@ -856,12 +856,28 @@ class Inverter:
                 warnings.warn('If percentile is specified, all distributions and offsets should be included for meaningful results')
             ft = np.asarray(self.f_train, dtype=float)
             if full and len(ft) == len(frequencies) and bool(np.min(rel_round(ft, 10) == rel_round(frequencies, 10))):
-                Zp = np.percentile(self._sample_result['Z_hat'], percentile, axis=0) * self._Z_scale
+                Zp = post.percentile(self._sample_result['Z_hat'], percentile, axis=0) * self._Z_scale
                 return Zp[:len(frequencies)] + 1j * Zp[len(frequencies):]
+            if (full and len(distributions) == 1 and self.distributions[distributions[0]]['dist_type'] == 'series'
+                    and len(self._sample_result['Rinf']) <= post.MAX_ROWS):
+                # one series distribution: Z of a draw is affine in (Rinf, induc, coef): project and reduce on the GPU
+                name = distributions[0]
+                mat = self._get_prediction_matrices(frequencies, distributions)[name]
+                cm = self._rescale_coef(self._sample_result[self._get_stan_coef_name(name)], 'series')
+                X = np.column_stack([self._rescale_coef(self._sample_result['Rinf'], 'series'),
+                                     self._rescale_coef(self._sample_result['induc'], 'series'), cm])
+                nfq = len(frequencies)
+                Phi = np.zeros((2 * nfq, X.shape[1]))
+                Phi[:nfq, 0] = 1.0
+                Phi[nfq:, 1] = 2 * np.pi * frequencies
+                Phi[:nfq, 2:] = mat['A_re']
+                Phi[nfq:, 2:] = mat['A_im']
+                Zq = post.project_percentile(X, Phi, None, percentile)
+                return Zq[..., :nfq] + 1j * Zq[..., nfq:]
             with warnings.catch_warnings():
                 warnings.simplefilter('ignore')
                 Zm = self.predict_Z_distribution(frequencies, distributions, include_offsets)
-            return np.percentile(Zm.real, percentile, axis=0) + 1j * np.percentile(Zm.imag, percentile, axis=0)
+            return post.percentile(Zm.real, percentile, axis=0) + 1j * post.percentile(Zm.imag, percentile, axis=0)
         pm = self._get_prediction_matrices(frequencies, distributions)
         Zp = np.zeros(len(frequencies), dtype=complex)
         for name, mat in pm.items():
@@ -884,7 +900,7 @@ class Inverter:
             with warnings.catch_warnings():
                 warnings.simplefilter('ignore')
                 Zm = self.predict_Z_distribution(ends, distributions=distributions)
-            return np.percentile(np.real(Zm[:, 1] - Zm[:, 0]), percentile)
+            return post.percentile(np.real(Zm[:, 1] - Zm[:, 0]), percentile)
         info = self.distributions[distributions[0]]
         if info['kernel'] == 'DRT' and 'coef' in self.distribution_fits[distributions[0]]:
             if percentile is None:                         # area under the DRT
@@ -892,7 +908,7 @@ class Inverter:
             if self.fit_type != 'bayes':
                 raise ValueError('Percentile prediction is only available for bayes_fit results')
             cm = self._rescale_coef(self._sample_result[self._get_stan_coef_name(distributions[0])], 'series')
-            return np.percentile(np.sum(cm, axis=1) * np.pi ** 0.5 / info['epsilon'], percentile)
+            return post.percentile(np.sum(cm, axis=1) * np.pi ** 0.5 / info['epsilon'], percentile)
         ends = np.array([1e20, 1e-20])
         if percentile is None:
             Zr = self.predict_Z(ends, distributions=distributions)
@@ -900,7 +916,7 @@ class Inverter:
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             Zm = self.predict_Z_distribution(ends, distributions=distributions)
-        return np.percentile(np.real(Zm[:, 1] - Zm[:, 0]), percentile)
+        return post.percentile(np.real(Zm[:, 1] - Zm[:, 0]), percentile)
 
     def predict_sigma(self, frequencies, percentile=None, times=None):
         """Error scale (sigma_re, sigma_im) of the fitted error model (reference :3089-3139)."""
@@ -913,15 +929,15 @@ class Inverter:
         nf = len(ft)
         if nf == len(frequencies) and bool(np.min(rel_round(ft, 10) == rel_round(frequencies, 10))):
             if self.fit_type == 'bayes' and percentile is not None:
-                st = np.percentile(self._sample_result['sigma_tot'], percentile, axis=0) * self._Z_scale
+                st = post.percentile(self._sample_result['sigma_tot'], percentile, axis=0) * self._Z_scale
             else:
                 st = self.error_fit['sigma_tot']
             return st[:nf].copy(), st[nf:].copy()
         if self.fit_type == 'bayes' and percentile is not None:
-            sres = np.percentile(self._sample_result['sigma_res'], percentile) * self._Z_scale
-            ap, ar, ai = [np.percentile(self._sample_result[k], percentile) for k in ('alpha_prop', 'alpha_re', 'alpha_im')]
+            sres = post.percentile(self._sample_result['sigma_res'], percentile) * self._Z_scale
+            ap, ar, ai = [post.percentile(self._sample_result[k], percentile) for k in ('alpha_prop', 'alpha_re', 'alpha_im')]
             try:
-                sout = np.percentile(self._sample_result['sigma_out'], percentile, axis=0) * self._Z_scale
+                sout = post.percentile(self._sample_result['sigma_out'], percentile, axis=0) * self._Z_scale
             except (ValueError, KeyError):
                 sout = np.zeros(2 * nf)
         else:

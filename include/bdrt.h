@@ -193,6 +193,23 @@ int bdrt_gram(const double *WA, const double *WZ, int nrows, int n, const double
  * tolerances (abstol 1e-7, reltol 1e-6, feastol 1e-7).  Returns iterations (>=0) or <0. */
 int bdrt_qp_box(const double *P, const double *q, const double *lo, int n, double *x, double *primal_objective);
 
+/* ---- (4) posterior post-processing on the device ------------------------------------
+ * Replaces the numpy reductions applied to the HMC draws right after `sampling`:
+ *   np.percentile(samples, q, axis=0)            reference bayes_drt/inversion.py:2560 (coef_percentile), :2702
+ *                                                (predict_Z from Z_hat), :3068/:3085 (predict_Rp), :3096-3113 (predict_sigma)
+ *   np.percentile(x_samples @ A.T + offsets, ..) reference inversion.py:2716-2735 (predict_Z on new frequencies)
+ *
+ * out[nq x ncols] (row-major) = percentile q[t] (0..100, numpy's default 'linear' rule, same lerp formula) over the
+ * `rows` samples of every column of Y, where Y = X (Phi == NULL, ncols = K) or Y = X Phi^T + bias (Phi is [M x K]
+ * row-major, bias [M] or NULL, ncols = M).  X is [rows x K] with row stride ldx >= K (doubles).  A column that
+ * contains a NaN yields NaN (numpy behaviour).  rows <= 16384 per call (one column is sorted in LDS). */
+int bdrt_percentiles(const double *X, int rows, int K, long ldx, const double *Phi, int M, const double *bias,
+                     const double *q, int nq, double *out);
+/* The same on the draws a sampler holds on the device (unconstrained parameters theta): samples = all draws of units
+ * [unit_lo, unit_hi), columns [col0, col0 + ncols) of theta.  The draws are not copied to the host. */
+int bdrt_sampler_percentiles(bdrt_sampler *s, int unit_lo, int unit_hi, int col0, int ncols, const double *Phi, int M,
+                             const double *bias, const double *q, int nq, double *out);
+
 /* ---- misc ----------------------------------------------------------------------------------------- */
 const char *bdrt_last_error(void);
 int bdrt_device_count(void);

@@ -87,6 +87,18 @@ def test_fit_sample_2zarc_within_reference_mc_error():
     Zp = inv.predict_Z(f, percentile=50)
     assert np.sqrt(np.mean(np.abs(Zp - Z) ** 2)) < 0.02
     assert fit.n_divergent < 40
+    # posterior summaries are reduced on the GPU (post.py): same numbers as the reference's numpy reductions on the draws
+    assert np.array_equal(inv.coef_percentile('DRT', 97.5),
+                          inv._rescale_coef(np.percentile(fit['x'], 97.5, axis=0), 'series'))
+    f_new = f[3:-3] * 0.7                                  # other frequencies: draws-times-basis on the GPU, then percentiles
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Zm = inv.predict_Z_distribution(f_new)
+    want = np.percentile(Zm.real, 2.5, axis=0) + 1j * np.percentile(Zm.imag, 2.5, axis=0)
+    got = inv.predict_Z(f_new, percentile=2.5)
+    assert np.max(np.abs(got - want)) < 1e-12 * np.max(np.abs(want))
+    s_re, s_im = inv.predict_sigma(f, percentile=97.5)
+    assert np.array_equal(np.concatenate([s_re, s_im]), np.percentile(fit['sigma_tot'], 97.5, axis=0) * inv._Z_scale)
 
 
 def test_ridge_fit_and_cv():
