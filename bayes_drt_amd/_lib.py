@@ -66,7 +66,7 @@ SYMBOLS = [
     'bdrt_sampler_run', 'bdrt_sampler_results', 'bdrt_sampler_total_leapfrogs', 'bdrt_sampler_kernel_time',
     'bdrt_sampler_phase_profile',
     'bdrt_sample',
-    'bdrt_gram', 'bdrt_qp_box',
+    'bdrt_gram', 'bdrt_qp_box', 'bdrt_qp_box_batch',
     'bdrt_percentiles', 'bdrt_sampler_percentiles',
     'bdrt_last_error', 'bdrt_device_count', 'bdrt_set_device', 'bdrt_version',
 ]
@@ -124,6 +124,7 @@ def load_library():
                                 vp]
     lib.bdrt_gram.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.bdrt_qp_box.argtypes = [vp, vp, vp, C.c_int, vp, vp]
+    lib.bdrt_qp_box_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     lib.bdrt_percentiles.argtypes = [vp, C.c_int, C.c_int, C.c_long, vp, C.c_int, vp, vp, C.c_int, vp]
     lib.bdrt_sampler_percentiles.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
     lib.bdrt_set_device.argtypes = [C.c_int]

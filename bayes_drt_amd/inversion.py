@@ -5,7 +5,7 @@ and error behaviour as the reference, so that notebooks written for `bayes_drt.i
 with `from bayes_drt_amd.inversion import Inverter`.  What runs where:
   * A / L / M matrices          -> GPU (matrices.py -> bdrt_build_A/_L/_M)
   * `fit` MAP / HMC             -> GPU (stan_models.py -> engine.StanModel -> bdrt_optimize / bdrt_sampler_*)
-  * `ridge_fit` Gram + QP       -> bdrt_gram (MFMA) + bdrt_qp_box (interior point, replaces cvxopt)
+  * `ridge_fit` Gram + QP       -> bdrt_gram (MFMA) + bdrt_qp_box_batch (interior point on the GPU, replaces cvxopt)
   * scaling, weights, Stan data dict, prediction algebra: numpy on the host (not hot: microseconds)
 Out of scope (drift fits, MultiDist, fitY/SA, peak fitting, plotting, file loaders) raise
 NotImplementedError instead of silently doing something else.
@@ -39,6 +39,55 @@ def _gaussian(y, epsilon):
 
 class _QPResult(dict):
     """Mapping with the two keys the reference reads from cvxopt's result ('x', 'primal objective')."""
+
+
+
+def _qp_batch(P, q, lo):
+    """min 1/2 x'Px + q'x s.t. x >= lo for a stack of problems: one GPU launch (bdrt_qp.hip)."""
+    lib = _lib.require_gpu()
+    P = np.ascontiguousarray(P, dtype=np.float64); q = np.ascontiguousarray(q, dtype=np.float64)
+    nb, n = q.shape
+    x = np.empty((nb, n)); obj = np.empty(nb)
+    _lib.check(lib.bdrt_qp_box_batch(ptr(P), ptr(q), ptr(np.ascontiguousarray(lo, dtype=np.float64)), n, nb, ptr(x),
+                                     ptr(obj), None), 'bdrt_qp_box_batch')
+    return x, obj
+
+
+class _QPBatcher(object):
+    """Rendezvous of the independent ridge fits of a Re-Im cross-validation: each fit (one thread) hands in its QP and
+    waits; when every fit still running has handed one in, the last arrival solves them all in one batched launch."""
+
+    def __init__(self, n_workers):
+        import threading
+        self.cv = threading.Condition()
+        self.alive = n_workers
+        self.pending = []            # [P, q, lo, slot]
+        self.generation = 0
+
+    def _flush(self):
+        items, self.pending = self.pending, []
+        x, obj = _qp_batch(np.stack([it[0] for it in items]), np.stack([it[1] for it in items]), items[0][2])
+        for k, it in enumerate(items):
+            it[3]['x'], it[3]['obj'] = x[k], obj[k]
+        self.generation += 1
+        self.cv.notify_all()
+
+    def solve(self, P, q, lo):
+        slot = {}
+        with self.cv:
+            self.pending.append([P, q, lo, slot])
+            if len(self.pending) == self.alive:
+                self._flush()
+            else:
+                while 'x' not in slot:
+                    self.cv.wait()
+        return slot['x'], slot['obj']
+
+    def leave(self):
+        with self.cv:
+            self.alive -= 1
+            if self.pending and len(self.pending) == self.alive:
+                self._flush()
 
 
 class Inverter:
@@ -260,11 +309,15 @@ class Inverter:
             return G, -g                                   # bdrt_gram returns q = -(WA^T WT)
 
         def solve(G, g, L2_mat):
-            lib = _lib.load_library()
+            """cvxopt.solvers.qp(P, q, -I, -lo) of the reference (:1043-1067): interior point on the GPU (bdrt_qp.hip)."""
             P = np.ascontiguousarray(G + L2_mat); q = np.ascontiguousarray(-g + L1_vec)
-            x = np.empty(n); obj = np.zeros(1)
-            _lib.check(lib.bdrt_qp_box(ptr(P), ptr(q), ptr(np.ascontiguousarray(lo)), n, ptr(x), ptr(obj)), 'bdrt_qp_box')
-            return _QPResult({'x': x, 'primal objective': float(obj[0])}), P, q
+            batcher = getattr(self, '_qp_batcher', None)
+            if batcher is not None:                        # Re-Im cross-validation: all fits solve in one launch
+                x, obj = batcher.solve(P, q, lo)
+            else:
+                x, obj = _qp_batch(P[None], q[None], lo)
+                x, obj = x[0], obj[0]
+            return _QPResult({'x': x, 'primal objective': float(obj)}), P, q
 
         def penalty_matrix(lams, dz):
             D = 1.0 / dz
@@ -388,15 +441,57 @@ class Inverter:
         self.fit_type = 'ridge'
 
     def ridge_ReImCV(self, frequencies, Z, lambdas=np.logspace(-10, 5, 31), **kw):
-        """Re-Im cross-validation for lambda_0 (reference :902-945)."""
+        """Re-Im cross-validation for lambda_0 (reference :902-945).
+
+        The reference runs the 2 x len(lambdas) hierarchical ridge fits one after the other; they are independent, so here
+        they advance in lock step and every hyper-lambda iteration solves all their QPs in ONE batched GPU launch
+        (bdrt_qp_box_batch, one workgroup per fit).  Each fit performs exactly the arithmetic of a stand-alone
+        `ridge_fit(part=..., lambda_0=...)`: same numbers as the sequential loop (`BDRT_SEQUENTIAL_CV=1` runs that loop)."""
         frequencies, Z = np.asarray(frequencies), np.asarray(Z)
+        lambdas = np.asarray(lambdas, dtype=float)
         recv, imcv = np.zeros_like(lambdas), np.zeros_like(lambdas)
-        for i, lam in enumerate(lambdas):
-            self.ridge_fit(frequencies, Z, part='real', lambda_0=lam, **kw)
-            Zi = np.imag(self.predict_Z(frequencies))
-            self.ridge_fit(frequencies, Z, part='imag', lambda_0=lam, **kw)
-            Zr = np.real(self.predict_Z(frequencies))
-            recv[i], imcv[i] = np.sum((Z.real - Zr) ** 2), np.sum((Z.imag - Zi) ** 2)
+        if os.environ.get('BDRT_SEQUENTIAL_CV'):
+            for i, lam in enumerate(lambdas):
+                self.ridge_fit(frequencies, Z, part='real', lambda_0=lam, **kw)
+                Zi = np.imag(self.predict_Z(frequencies))
+                self.ridge_fit(frequencies, Z, part='imag', lambda_0=lam, **kw)
+                Zr = np.real(self.predict_Z(frequencies))
+                recv[i], imcv[i] = np.sum((Z.real - Zr) ** 2), np.sum((Z.imag - Zi) ** 2)
+        else:
+            import threading
+            jobs = [(i, part, lam) for i, lam in enumerate(lambdas) for part in ('real', 'imag')]
+            batcher = _QPBatcher(len(jobs))
+            workers = [deepcopy(self) for _ in jobs]
+            preds, errors = [None] * len(jobs), []
+
+            def run(j):
+                i, part, lam = jobs[j]
+                w = workers[j]
+                w._qp_batcher = batcher
+                try:
+                    with warnings.catch_warnings():
+                        warnings.simplefilter('ignore')
+                        w.ridge_fit(frequencies, Z, part=part, lambda_0=lam, **kw)
+                    preds[j] = w.predict_Z(frequencies)
+                except BaseException as e:               # noqa: BLE001 -- re-raised in the caller's thread
+                    errors.append(e)
+                finally:
+                    w._qp_batcher = None
+                    batcher.leave()
+            threads = [threading.Thread(target=run, args=(j,)) for j in range(len(jobs))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+            for j, (i, part, lam) in enumerate(jobs):
+                if part == 'real':
+                    imcv[i] = np.sum((Z.imag - np.imag(preds[j])) ** 2)
+                else:
+                    recv[i] = np.sum((Z.real - np.real(preds[j])) ** 2)
+            last = workers[-1]                            # the reference leaves the last fit (imag part, last lambda) in place
+            self.__dict__.update({k: v for k, v in last.__dict__.items() if k != '_qp_batcher'})
         tot = recv + imcv
         best = lambdas[np.argmin(tot)]
         if best == np.min(lambdas) or best == np.max(lambdas):

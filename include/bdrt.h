@@ -192,6 +192,13 @@ int bdrt_gram(const double *WA, const double *WZ, int nrows, int n, const double
 /* min 1/2 x^T P x + q^T x  s.t. x >= lo (lo[i] = -inf allowed): primal-dual interior point with cvxopt-like
  * tolerances (abstol 1e-7, reltol 1e-6, feastol 1e-7).  Returns iterations (>=0) or <0. */
 int bdrt_qp_box(const double *P, const double *q, const double *lo, int n, double *x, double *primal_objective);
+/* The same solver on the GPU for a batch of nb problems that share n and lo (one workgroup per problem, KKT matrix
+ * factored in LDS): P [nb][n][n], q [nb][n], x [nb][n], primal_objective [nb] or NULL, iterations [nb] or NULL.
+ * This is what Inverter.ridge_fit / ridge_ReImCV call (reference inversion.py:1043-1067 inside the loops at :560-740 and
+ * :902-945); bdrt_qp_box above is the host implementation of the identical algorithm, kept as the checker.
+ * Returns 0, or <0 (-3: a KKT matrix was not positive definite, -4: iteration limit). */
+int bdrt_qp_box_batch(const double *P, const double *q, const double *lo, int n, int nb, double *x,
+                      double *primal_objective, int *iterations);
 
 /* ---- (4) posterior post-processing on the device ------------------------------------
  * Replaces the numpy reductions applied to the HMC draws right after `sampling`:
