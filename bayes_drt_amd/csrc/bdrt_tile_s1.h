@@ -266,12 +266,11 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     __syncthreads();                                                   // B1: X of all 16 chains in the operand tile
     BDRT_S1_TRACE(2);
     BDRT_S1_PROF(1);
-    // The two waves that share a SIMD (w and w + 4) take the MFMA part and the VALU part of this phase in opposite order,
-    // so the matrix pipe and the vector pipe of every SIMD are busy at the same time.
+    // MFMA part, then the VALU part of this phase (the prior chain does not depend on A x, so no barrier in between).
 #pragma unroll 1
     for (int step = 0; step < 2; ++step) {
     BDRT_S1_TRACE(3 + step);
-    if ((step == 0) == (wave < NW / 2)) {
+    if (step == 0) {   // (swapping the order between the two waves of a SIMD was measured: no gain -- MFMA f64 and VALU f64 share the pipe)
         if (!(P.dbg & 1)) gemm_sw(B.Af, B.tilesA, B.kpairs, Xs, Zh, wave, lane);        // Zh = A x  (pad rows come out as exact zeros)
         continue;
     }
