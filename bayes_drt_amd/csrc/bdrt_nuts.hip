@@ -32,7 +32,7 @@ static_assert(NW * NQ_CHK * NC <= MIN_LR * NC, "Lr buffer too small for the NUTS
 
 // state vectors per workgroup, each [D][16]
 enum { V_TH = 0, V_P, V_G, V_THM, V_PM, V_GM, V_THP, V_PP, V_GP, V_THS, V_GS, V_THQ, V_GQ, V_RHO, V_RHOC, V_MINV,
-       V_WMEAN, V_WM2, V_CKC /* MAXD */, V_CKP = V_CKC + MAXD /* MAXD */, V_COUNT = V_CKP + MAXD };
+       V_WMEAN, V_WM2, V_ZN /* normals of the next transition's momentum, produced ahead of time */, V_CKC /* MAXD */, V_CKP = V_CKC + MAXD /* MAXD */, V_COUNT = V_CKP + MAXD };
 
 // sum over the 32 lanes of a half-wave (one chain), fixed order => deterministic; every lane gets the result
 __device__ __forceinline__ double half_sum(double x)
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     double *lpn = thl + (MODE == 2 ? (size_t)NC * DSL : 0);
     ChainState *sts = reinterpret_cast<ChainState *>(lpn + NC);
     int *spec = reinterpret_cast<int *>(sts + NC);
+    volatile int *slow = spec + NC;     // set by a chain that is about to do something long this round (see stage Z)
 
     double *V = a.vecs + (size_t)wg * V_COUNT * NC * DS;
     auto row = [&](int v) -> double * { return V + ((size_t)v * NC + c) * DS; };   // this chain's row of vector v
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     for (int round = 0; round < a.rounds; ++round) {
         // keep per-lane address arithmetic inside the loop (see the note in bdrt_tile_s1.h): hoisted, it is spilled
         __asm__ volatile("" : "+v"(c), "+v"(l32));
+        if (tid == 0) *slow = 0;
         const int ph0 = s.phase;
         const bool act = ph0 == PH_INIT || ph0 == PH_EPS || ph0 == PH_TREE;
         if (!any_act) break;
@@ -282,6 +284,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     tree = true;
                     while ((leaf_now >> nm) & 1) ++nm;              // trailing ones = sub-subtrees ending here
                     last = leaf_now == s.nleaves - 1;
+                    if (last) *slow = 1;                            // closing a subtree (and maybe the transition): a long round
                 }
             }
         }
@@ -479,6 +482,29 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             }
         }
 
+        // ---- Z: momentum normals of the NEXT transition, ahead of time.  When some chain of the workgroup closes a subtree
+        //      or a transition this round, every other wave would only wait for it at the round barrier; a wave whose own
+        //      two chains are on the plain path uses that time to draw the 2*ceil(D/2) normals its chains need at their
+        //      next start point (Philox counters depend on (seed, chain, iteration) only, so the values are the same
+        //      whenever they are computed).  Takes the RNG (the largest part of a new start point) off the critical path.
+        {
+            const bool heavy = !act || ph0 != PH_TREE || last || endt != 0 || next != 0;
+            const bool wave_heavy = __builtin_amdgcn_ballot_w64(heavy) != 0;
+            if (!wave_heavy && *slow && s.z_iter != s.iter + 1) {
+                double *ZN = row(V_ZN);
+                const uint32_t it1 = (uint32_t)(s.iter + 1);
+#pragma unroll
+                for (int mp = 0; mp < (NJ + 1) / 2; ++mp) {
+                    const int i = l32 + 32 * mp;
+                    if (2 * i < D) {
+                        double z0, z1;
+                        rng_normal_pair(rng, (uint32_t)i, RNG_MOMENTUM, 0u, it1, z0, z1);
+                        *reinterpret_cast<double2 *>(ZN + 2 * i) = make_double2(z0, z1);
+                    }
+                }
+                s.z_iter = (int)it1;
+            }
+        }
         BDRT_WAVE_PROF(21);
         // ---- E: sample update, metric adaptation, draw output, and the start of the next leapfrog when the trajectory does
         //      not simply continue (new transition, next doubling, step-size search, re-initialisation).  One batch of
@@ -532,26 +558,36 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 // Box-Muller transform: a lane produces PAIRS and the chain's scratch row (its share of the idle tile
                 // LDS) turns them into the lane's own elements j = l32 + 32 m.
                 double *zrow = MODE == 2 ? s1_grad_row(P, smem, c) : smem + (size_t)c * (tile_doubles / NC);
+                const bool have_z = next == 1 && s.z_iter == (int)iter;      // stage Z of an earlier round did the work
+                double z_[NJ];
+                if (have_z) {
+                    const double *ZN = row(V_ZN);
 #pragma unroll
-                for (int mp = 0; mp < (NJ + 1) / 2; ++mp) {
-                    const int i = l32 + 32 * mp;
-                    if (2 * i < D) {
-                        double z0, z1;
-                        rng_normal_pair(rng, (uint32_t)i, next == 1 ? RNG_MOMENTUM : RNG_EPS_MOMENTUM, next == 1 ? 0u : trial, iter, z0, z1);
-                        zrow[2 * i] = z0; zrow[2 * i + 1] = z1;
+                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; z_[m] = ZN[j]; }
+                } else {
+#pragma unroll
+                    for (int mp = 0; mp < (NJ + 1) / 2; ++mp) {
+                        const int i = l32 + 32 * mp;
+                        if (2 * i < D) {
+                            double z0, z1;
+                            rng_normal_pair(rng, (uint32_t)i, next == 1 ? RNG_MOMENTUM : RNG_EPS_MOMENTUM, next == 1 ? 0u : trial, iter, z0, z1);
+                            zrow[2 * i] = z0; zrow[2 * i + 1] = z1;
+                        }
                     }
+                    lds_wave_sync();
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; z_[m] = j < D ? zrow[j] : 0.0; }
+                    lds_wave_sync();
                 }
-                lds_wave_sync();
                 double kin0 = 0.0;
                 double pn_[NJ];
 #pragma unroll
                 for (int m = 0; m < NJ; ++m) {
                     const int j = l32 + 32 * m;
-                    const double p = j < D ? zrow[j] / sqrt(mi_[m]) : 0.0;
+                    const double p = j < D ? z_[m] / sqrt(mi_[m]) : 0.0;
                     pn_[m] = p;
                     kin0 += mi_[m] * p * p;
                 }
-                lds_wave_sync();
                 // Hamiltonian at the start point; a new transition also resets the tree and draws its first direction
                 kin0 = half_sum(kin0);
                 s.H0 = -s.lps + 0.5 * kin0;
@@ -736,6 +772,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         ChainState &st = hs[u];
         memset(&st, 0, sizeof(st));
         st.phase = PH_INIT;
+        st.z_iter = -1;
         st.spec = spec ? spec[u] : 0;
         st.chain_id = chain_id ? chain_id[u] : u;
         st.eps = c.stepsize0;
