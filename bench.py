@@ -128,7 +128,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product has no CPU path')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BDRT_BENCH_FORCE_DIST=1: take the RCCL code path with a single rank too (lets a 1-GPU box exercise it)
+    use_dist = world > 1 or (bool(os.environ.get('BDRT_BENCH_FORCE_DIST')) and 'RANK' in os.environ)
+    if use_dist:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from bayes_drt_amd import _lib, matrices as gm
@@ -170,7 +172,7 @@ def main():
     def sync_all():
         check(lib.bdrt_sampler_sync(h), 'bdrt_sampler_sync')
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     advance(args.warmup)
@@ -186,7 +188,7 @@ def main():
     check(lib.bdrt_sampler_sync(h), 'bdrt_sampler_sync')
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = t1 - t0
     n1 = lib.bdrt_sampler_total_leapfrogs(h)
@@ -209,7 +211,7 @@ def main():
         print('half-waves per round in stage E (new start point): %.2f of 16' % (cyc[24] / n_wg / args.steps * 2), file=sys.stderr)
     lib.bdrt_sampler_destroy(h)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         e = torch.tensor([evals], dtype=torch.float64, device='cuda')
@@ -248,7 +250,7 @@ def main():
         if cpu is not None:
             line['cpu_baseline'] = cpu
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
