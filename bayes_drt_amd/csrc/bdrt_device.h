@@ -83,45 +83,68 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
 // Y[(16 t + i)][c] = sum_k M[16 t + i][k] X[k][c] for the tiles of this wave.
 // Fragment order (host packing in bdrt_model.hip::pack_forward): element (tile t, pair p, lane l, h) =
 // M[16 t + (l & 15)][8 p + 4 h + (l >> 4)].
-constexpr int PF = 4;   // operand pairs prefetched ahead of the MFMAs (register double buffer)
-
-// one chunk of PF operand pairs: 2*PF MFMAs fed from registers (a) and LDS (xb rows 8p, 8p+4)
-__device__ __forceinline__ void mfma_chunk(const double2 (&a)[PF], const double *xb, int p0, d4 &acc0, d4 &acc1)
-{
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-        acc0 = mfma_f64(a[i].x, xb[(8 * (p0 + i)) * NC], acc0);
-        acc1 = mfma_f64(a[i].y, xb[(8 * (p0 + i) + 4) * NC], acc1);
-    }
-}
+constexpr int PF = 7;   // operand pairs per chunk (two register buffers of PF fragments)
 
 // acc += sum over `pairs` operand pairs of M-fragments (global/L2, stride 64 double2 per pair) times LDS rows.
-// Software pipelined: the loads of chunk i+1 are in flight while the MFMAs of chunk i issue.
-__device__ __forceinline__ void mfma_stream(const double2 *__restrict__ mp, int pairs, const double *xb, d4 &acc0,
+// Chunks of PF pairs, two register buffers.  Per chunk: all 2*PF LDS B-operands first, the first MFMA pair, THEN the
+// global loads of the next chunk, then the other MFMAs back to back (sched_barriers pin that order).  Left to itself the
+// compiler emitted `ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma` per instruction (~180 cycles per MFMA instead of 64) and
+// waited with vmcnt(0) for the prefetch it had just issued (measured with tools/tile_trace.py on the S1 evaluator, which
+// uses the same scheme).  The last chunk may be partial: its loads are clamped, its MFMAs guarded (uniform branches).
+__device__ __forceinline__ void mfma_stream(const double2 *__restrict__ mp_, int pairs, const double *xb, d4 &acc0,
                                             d4 &acc1)
 {
-    const int nchunk = pairs / PF;
-    double2 a[PF], b[PF];
-    if (nchunk > 0) {
+    typedef double dv2 __attribute__((ext_vector_type(2)));
+    // global (not flat) loads: a flat load also counts on lgkmcnt and would serialise with the LDS operand reads
+    typedef const __attribute__((address_space(1))) dv2 *gp2;
+    gp2 mp = (gp2) reinterpret_cast<const dv2 *>(mp_);
+    const int nchunk = (pairs + PF - 1) / PF;
+    auto load = [&](dv2 (&buf)[PF], int ch) {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) a[i] = mp[(size_t)i * 64];
-    }
-    int c = 0;
-    for (; c + 1 < nchunk; c += 2) {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) b[i] = mp[(size_t)((c + 1) * PF + i) * 64];
-        mfma_chunk(a, xb, c * PF, acc0, acc1);
-        if (c + 2 < nchunk) {
-#pragma unroll
-            for (int i = 0; i < PF; ++i) a[i] = mp[(size_t)((c + 2) * PF + i) * 64];
+        for (int i = 0; i < PF; ++i) {
+            int p = ch * PF + i;
+            p = p < pairs ? p : pairs - 1;
+            buf[i] = mp[(size_t)p * 64];
         }
-        mfma_chunk(b, xb, (c + 1) * PF, acc0, acc1);
-    }
-    if (c < nchunk) mfma_chunk(a, xb, c * PF, acc0, acc1);
-    for (int p = nchunk * PF; p < pairs; ++p) {
-        const double2 v = mp[(size_t)p * 64];
-        acc0 = mfma_f64(v.x, xb[(8 * p) * NC], acc0);
-        acc1 = mfma_f64(v.y, xb[(8 * p + 4) * NC], acc1);
+    };
+    auto step = [&](const dv2 (&cur)[PF], dv2 (&nxt)[PF], int ch, bool prefetch) {
+        const int p0 = ch * PF;
+        const double *x0 = xb + (size_t)(8 * p0) * NC;
+        double bx[PF], by[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int pi = p0 + i < pairs ? i : 0;                  // rows of a partial chunk's missing pairs: re-read pair 0
+            bx[i] = x0[(8 * pi) * NC];
+            by[i] = x0[(8 * pi + 4) * NC];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = mfma_f64(cur[0].x, bx[0], acc0);
+        acc1 = mfma_f64(cur[0].y, by[0], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (prefetch) load(nxt, ch + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p0 + PF <= pairs) {
+#pragma unroll
+            for (int i = 1; i < PF; ++i) {
+                acc0 = mfma_f64(cur[i].x, bx[i], acc0);
+                acc1 = mfma_f64(cur[i].y, by[i], acc1);
+            }
+        } else {
+#pragma unroll
+            for (int i = 1; i < PF; ++i) {
+                if (p0 + i < pairs) {
+                    acc0 = mfma_f64(cur[i].x, bx[i], acc0);
+                    acc1 = mfma_f64(cur[i].y, by[i], acc1);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    dv2 a[PF], b[PF];
+    if (nchunk > 0) load(a, 0);
+    for (int ch = 0; ch < nchunk; ch += 2) {
+        step(a, b, ch, ch + 1 < nchunk);
+        if (ch + 1 < nchunk) step(b, a, ch + 1, ch + 2 < nchunk);
     }
 }
 

@@ -1,0 +1,48 @@
+"""GPU box: throughput of the GENERIC block evaluator inside the sampler on BASELINE config 5 (DRT + transmissive planar DDT,
+2 x 161 basis functions, outlier error model, D = 818) and, for comparison, the headline S1 family through the generic path
+(BDRT_GENERIC_TILE=1).  Real NUTS rounds, n units resident, evaluations per second."""
+import ctypes as C, os, sys, time, warnings
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.helpers import load
+from bayes_drt_amd.inversion import Inverter
+from bayes_drt_amd import stan_models
+from bayes_drt_amd._lib import NutsControl, check, ptr
+
+d = load('kat_DRT-2-TpDDT_uniform_0.25')
+f, Z = d['data_freq'], d['data_Z'].copy()
+for i in (10, 40, 70):
+    Z[i] *= 1.5
+bf = np.logspace(10, -6, 161)
+dists = {'DRT': {'kernel': 'DRT'},
+         'TP-DDT': {'kernel': 'DDT', 'symmetry': 'planar', 'bc': 'transmissive', 'dist_type': 'parallel', 'x_scale': 0.8}}
+inv = Inverter(basis_freq=bf, distributions=dists)
+with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    inv.fit(f, Z, nonneg=True, outliers=True, mode='sample', warmup=5, samples=5, chains=1)
+model = stan_models.load_pickle(inv.stan_model_name)
+prob = model._prepare(inv._stan_input)
+lib = prob._lib
+n_units = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4096
+ctrl = NutsControl(); lib.bdrt_nuts_defaults(C.byref(ctrl)); ctrl.adapt_delta, ctrl.adapt_t0 = 0.9, 10.0
+h = lib.bdrt_sampler_create(prob.handle, n_units, None, None, 1000000, 1, C.c_uint64(7), None, C.byref(ctrl))
+assert h, lib.bdrt_last_error()
+def adv(r):
+    while r > 0:
+        k = min(50, r); check(lib.bdrt_sampler_advance(h, k, None), 'advance'); r -= k
+adv(300); check(lib.bdrt_sampler_sync(h), 'sync')
+prof = '--phase-profile' in sys.argv
+if prof: check(lib.bdrt_sampler_phase_profile(h, 1, None), 'prof')
+n0 = lib.bdrt_sampler_total_leapfrogs(h); t0 = time.perf_counter()
+adv(600); check(lib.bdrt_sampler_sync(h), 'sync')
+t1 = time.perf_counter(); n1 = lib.bdrt_sampler_total_leapfrogs(h)
+print('config 5 (%s, D=%d, %d units): %.2f M evals/s, %.1f us per round' % (inv.stan_model_name, prob.D, n_units,
+      (n1 - n0) / (t1 - t0) / 1e6, (t1 - t0) / 600 * 1e6))
+if prof:
+    cyc = (C.c_longlong * 32)(); check(lib.bdrt_sampler_phase_profile(h, 0, cyc), 'prof')
+    names = ['tile:scalars', 'tile:x', 'tile:gemmA', 'tile:Zacc', 'tile:likelihood', 'tile:x2', 'tile:gemmL', 'tile:prior',
+             'tile:gemmBwd', 'tile:epilogue', 'nuts:wait', 'nuts:C', 'nuts:S1', 'nuts:D', 'nuts:S2', 'nuts:E', 'nuts:S3']
+    nwg = (n_units + 15) // 16
+    for k, nm in enumerate(names): print('PHASE %-18s %9.0f cycles/round' % (nm, cyc[k] / nwg / 600))
+    for k, nm in enumerate(['tile', 'C', 'S1', 'D', "A'", 'E', 'wait']): print('WAVE-AVG %-6s %9.0f' % (nm, cyc[17 + k] / nwg / 600 / 8))
+lib.bdrt_sampler_destroy(h)
