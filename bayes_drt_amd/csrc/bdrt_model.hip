@@ -260,6 +260,30 @@ __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restr
     else logp_grad_tile<false>(P, io, smem);
 }
 
+// the S1 evaluator with a whole wavefront per chain: 1024 threads = 16 waves = 4 per SIMD (<= 128 VGPRs)
+__global__ __launch_bounds__(1024) void logp_grad_kernel_wide(const DevProblem *__restrict__ Pp, const double *theta, const int *spec,
+                                                              int B, int jacobian, double *lp, double *grad, double *params,
+                                                              double *Zhat, double *sig)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const DevProblem &P = *Pp;
+    const int c0 = blockIdx.x * NC;
+    TileIO io;
+    io.theta = theta + (size_t)c0 * P.D;
+    io.t_sc = P.D; io.t_sj = 1;
+    io.grad = grad ? grad + (size_t)c0 * P.D : nullptr;
+    io.g_sc = P.D; io.g_sj = 1;
+    io.lp = lp ? lp + c0 : nullptr;
+    io.spec = spec ? spec + c0 : nullptr;
+    io.nvalid = min(NC, B - c0);
+    io.jacobian = jacobian;
+    io.Z_hat = Zhat ? Zhat + (size_t)c0 * 2 * P.nf : nullptr;
+    io.sigma_tot = sig ? sig + (size_t)c0 * 2 * P.nf : nullptr;
+    io.params = params ? params + (size_t)c0 * P.D : nullptr;
+    io.prof = nullptr;
+    logp_grad_tile_s1<false, 64>(P, io, smem);
+}
+
 int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
                      double *d_grad, double *d_params, double *d_Zhat, double *d_sig, hipStream_t stream)
 {
@@ -272,10 +296,16 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
                                      (int)p->lds_bytes));
         BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)p->lds_bytes));
+        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)p->lds_bytes));
         attr_bytes = p->lds_bytes;
     }
     const int grid = cdiv(B, NC);
-    if (p->dev.fast_s1)
+    static const bool wide = getenv("BDRT_S1_WIDE") != nullptr;
+    if (p->dev.fast_s1 && wide && p->dev.nf <= 128)
+        hipLaunchKernelGGL(logp_grad_kernel_wide, dim3(grid), dim3(1024), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
+                           d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
+    else if (p->dev.fast_s1)
         hipLaunchKernelGGL(logp_grad_kernel<2>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
                            d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
     else if (p->dev.toep_all)

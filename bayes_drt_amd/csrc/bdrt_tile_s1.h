@@ -23,8 +23,11 @@ static __device__ long long *g_tile_trace = nullptr;
 
 __device__ __forceinline__ int swz(int row, int col) { return row * NC + (col ^ (row & 15)); }
 
+// sum over the LPC lanes (32: half-wave, 64: wave) that own one chain
+template <int LPC>
 __device__ __forceinline__ double hsum(double x)
 {
+    if (LPC == 64) x += __shfl_xor(x, 32);
     x += __shfl_xor(x, 16);
     x += __shfl_xor(x, 8);
     x += __shfl_xor(x, 4);
@@ -56,7 +59,7 @@ __device__ __forceinline__ double hshift(double x, int delta)
 // while the 2*GPF MFMAs of one chunk issue (~GPF * 128 cycles) the next chunk -- of this tile or of the wave's next tile --
 // is in flight.  The steady-state loop has no conditional loads, so the compiler's s_waitcnt vmcnt counts stay exact
 // (a conditional load forces vmcnt(0) at the merge point, which serialises the stream).
-constexpr int GPF = 7;
+template <int NWV, int GPF>
 __device__ __forceinline__ void gemm_sw(const double *__restrict__ Mp, int ntiles, int pairs, const double *Bs, double *Os,
                                         int wave, int lane)
 {
@@ -66,7 +69,7 @@ __device__ __forceinline__ void gemm_sw(const double *__restrict__ Mp, int ntile
     const int col = lane & 15, kq = lane >> 4;
     wave = __builtin_amdgcn_readfirstlane(wave);          // uniform: scalar loop control and address arithmetic
     if (wave >= ntiles) return;
-    const int nt = (ntiles - wave + NW - 1) / NW;
+    const int nt = (ntiles - wave + NWV - 1) / NWV;
     const int nchunk = pairs / GPF, rem = pairs - nchunk * GPF;
     const int items = nt * nchunk;                       // chunks of this wave, tile-major
     gp2 base = (gp2) reinterpret_cast<const dv2 *>(Mp) + lane;
@@ -82,7 +85,7 @@ __device__ __forceinline__ void gemm_sw(const double *__restrict__ Mp, int ntile
         bY[e] = Bs + (kq + 4) * NC + (col ^ (8 * e + kq + 4));
     }
     auto load = [&](dv2 (&buf)[GPF]) {
-        gp2 p = base + ((size_t)(wave + l_ti * NW) * pairs + (size_t)l_ch * GPF) * 64;
+        gp2 p = base + ((size_t)(wave + l_ti * NWV) * pairs + (size_t)l_ch * GPF) * 64;
 #pragma unroll
         for (int i = 0; i < GPF; ++i) buf[i] = p[(size_t)i * 64];
         if (++l_ch == nchunk) { l_ch = 0; ++l_ti; }
@@ -114,7 +117,7 @@ __device__ __forceinline__ void gemm_sw(const double *__restrict__ Mp, int ntile
         }
         __builtin_amdgcn_sched_barrier(0);
         if (++c_ch == nchunk) {
-            const int t = wave + c_ti * NW;
+            const int t = wave + c_ti * NWV;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) { const int row = 16 * t + kq + 4 * rr; Os[swz(row, col)] = acc0[rr] + acc1[rr]; }
             acc0 = d4{0.0, 0.0, 0.0, 0.0}; acc1 = d4{0.0, 0.0, 0.0, 0.0};
@@ -130,7 +133,7 @@ __device__ __forceinline__ void gemm_sw(const double *__restrict__ Mp, int ntile
     // operand pairs beyond the last full chunk (pairs % GPF; none for the 81 x 161 shape) and tiles narrower than a chunk
     if (rem > 0) {
         for (int ti = 0; ti < nt; ++ti) {
-            const int t = wave + ti * NW;
+            const int t = wave + ti * NWV;
             d4 r0a = {0.0, 0.0, 0.0, 0.0}, r1a = {0.0, 0.0, 0.0, 0.0};
             for (int p = nchunk * GPF; p < pairs; ++p) {
                 const dv2 v = base[((size_t)t * pairs + p) * 64];
@@ -179,7 +182,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // `before_backward` runs right before the backward GEMM (the last ~10 k cycles of the evaluation): the sampler uses it to
 // issue the global loads of the state it needs next, so that their latency hides behind the MFMA work.
-template <bool LDSIO, class Hook = NoHook>
+template <bool LDSIO, int LPC = 32, class Hook = NoHook>
 __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, double *smem, Hook before_backward = Hook())
 {
     int tid = threadIdx.x;
@@ -187,9 +190,13 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     // gets hoisted out of the loop by the hundreds (LDS addresses, swizzle offsets, row pointers) and is then spilled to
     // scratch and reloaded every round.  Recomputing a few integer ops per evaluation is far cheaper.
     __asm__ volatile("" : "+v"(tid));
+    // LPC lanes own one chain: 32 (half-wave, 512 threads, 2 waves per SIMD) or 64 (wave, 1024 threads, 4 waves per SIMD,
+    // half the per-lane work and registers)
+    constexpr int UKV = 192 / LPC, UNV = LPC == 32 ? 3 : 2, WINV = UKV + NTAP - 1, NWV = 16 * LPC / 64;
+    constexpr int GPFV = LPC == 32 ? 7 : 3;
     const int lane = tid & 63, wave = tid >> 6;
-    const int c = 2 * wave + (lane >> 5);                  // chain owned by this half-wave
-    const int l32 = lane & 31, hb = lane & 32;
+    const int c = tid / LPC;                               // chain owned by this group of LPC lanes
+    const int l32 = tid % LPC, hb = lane & (64 - LPC);     // lane within the group, first lane of the group in the wave
     const DevBlock &B = P.blk[0];
     const int nf = P.nf, N2 = 2 * nf, K = B.K, KP = 8 * B.kpairs;
     const bool valid = c < io.nvalid;
@@ -215,7 +222,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     auto PW = [&](int j, double v) { if (pr) pr[j] = v; };
 
     long long tprev = (io.prof && tid == 0) ? clock64() : 0;
-    long long *trc = g_tile_trace ? g_tile_trace + ((size_t)blockIdx.x * NW + wave) * 16 : nullptr;
+    long long *trc = g_tile_trace ? g_tile_trace + ((size_t)blockIdx.x * NWV + wave) * 16 : nullptr;
 #define BDRT_S1_TRACE(slot) do { if (trc && (lane == 0)) trc[slot] = clock64(); } while (0)
     BDRT_S1_TRACE(0);
 #define BDRT_S1_PROF(slot) do { if (io.prof && tid == 0) { const long long t_ = clock64(); io.prof[slot] += t_ - tprev; tprev = t_; } } while (0)
@@ -230,18 +237,18 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         if (j >= 0) { st = TH(j); sraw = exp(st); PW(j, sraw); }
     }
     double lp = 0.0;
-    double x_[UK];
+    double x_[UKV];
     {
-        double tx_[UK], tu_[UK];
+        double tx_[UKV], tu_[UKV];
 #pragma unroll
-        for (int u = 0; u < UK; ++u) {
-            const int k = l32 + 32 * u;
+        for (int u = 0; u < UKV; ++u) {
+            const int k = l32 + LPC * u;
             tx_[u] = k < K ? TH(B.o_x + k) : 0.0;
             tu_[u] = k < K ? TH(B.o_ups + k) : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < UK; ++u) {
-            const int k = l32 + 32 * u;
+        for (int u = 0; u < UKV; ++u) {
+            const int k = l32 + LPC * u;
             double xr = 0.0;
             if (k < K) {
                 xr = B.is_pos ? exp(tx_[u]) : tx_[u];
@@ -254,8 +261,8 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             wrow[MAXBW + k] = tu_[u];                      // theta_ups on its way to mapping M2
         }
         if (l32 < MAXBW) {
-            xrow[l32] = 0.0; xrow[MAXBW + 32 * UK + l32] = 0.0;
-            wrow[l32] = 0.0; wrow[MAXBW + 32 * UK + l32] = 0.0;
+            xrow[l32] = 0.0; xrow[MAXBW + LPC * UKV + l32] = 0.0;
+            wrow[l32] = 0.0; wrow[MAXBW + LPC * UKV + l32] = 0.0;
         }
     }
     const double d0 = __shfl(sraw, hb | 6), d1 = __shfl(sraw, hb | 7), d2 = __shfl(sraw, hb | 8);
@@ -271,24 +278,24 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     for (int step = 0; step < 2; ++step) {
     BDRT_S1_TRACE(3 + step);
     if (step == 0) {   // (swapping the order between the two waves of a SIMD was measured: no gain -- MFMA f64 and VALU f64 share the pipe)
-        if (!(P.dbg & 1)) gemm_sw(B.Af, B.tilesA, B.kpairs, Xs, Zh, wave, lane);        // Zh = A x  (pad rows come out as exact zeros)
+        if (!(P.dbg & 1)) gemm_sw<NWV, GPFV>(B.Af, B.tilesA, B.kpairs, Xs, Zh, wave, lane);        // Zh = A x  (pad rows come out as exact zeros)
         continue;
     }
 
     // ---- P2 (M2): v_i = L_i x, q / ups / dups priors, w_i, sum_i L_i^T w_i -- all on this chain's private rows -------------
     if (!(P.dbg & 4)) {
-        const int kb = 6 * l32;                                        // first k of this lane
-        double xw[WIN], tuc[UK];
+        const int kb = UKV * l32;                                        // first k of this lane
+        double xw[WINV], tuc[UKV];
 #pragma unroll
-        for (int j = 0; j < WIN; ++j) xw[j] = xrow[kb + j];            // x[kb + j - MAXBW]
+        for (int j = 0; j < WINV; ++j) xw[j] = xrow[kb + j];            // x[kb + j - MAXBW]
 #pragma unroll
-        for (int u = 0; u < UK; ++u) tuc[u] = wrow[MAXBW + kb + u];
+        for (int u = 0; u < UKV; ++u) tuc[u] = wrow[MAXBW + kb + u];
         wave_sync();                                                   // every lane holds its x window and theta_ups
         // v_i = L_i x: three independent 17-tap convolutions of the window (independent accumulators: the latency of one
         // FMA chain hides behind the other two)
-        double v0_[UK], v1_[UK], v2_[UK];
+        double v0_[UKV], v1_[UKV], v2_[UKV];
 #pragma unroll
-        for (int u = 0; u < UK; ++u) { v0_[u] = 0.0; v1_[u] = 0.0; v2_[u] = 0.0; }
+        for (int u = 0; u < UKV; ++u) { v0_[u] = 0.0; v1_[u] = 0.0; v2_[u] = 0.0; }
         double tn0 = B.T[0][0], tn1 = B.T[1][0], tn2 = B.T[2][0];
 #pragma unroll
         for (int d = 0; d < NTAP; ++d) {
@@ -296,23 +303,23 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             if (d + 1 < NTAP) { tn0 = B.T[0][d + 1]; tn1 = B.T[1][d + 1]; tn2 = B.T[2][d + 1]; }
             __asm__ volatile("" ::: "memory");       // keeps the tap loads in program order (one tap ahead), not all 51 up front
 #pragma unroll
-            for (int u = 0; u < UK; ++u) { v0_[u] = fma(t0, xw[u + d], v0_[u]); v1_[u] = fma(t1, xw[u + d], v1_[u]); v2_[u] = fma(t2, xw[u + d], v2_[u]); }
+            for (int u = 0; u < UKV; ++u) { v0_[u] = fma(t0, xw[u + d], v0_[u]); v1_[u] = fma(t1, xw[u + d], v1_[u]); v2_[u] = fma(t2, xw[u + d], v2_[u]); }
         }
         // ups of k-2 .. k+7 around the lane's six k: own registers plus two values from each neighbouring lane
-        double ue[UK + 4], ie[UK + 2];                                 // ups of k-2..k+7, 1/ups of k-1..k+6
+        double ue[UKV + 4], ie[UKV + 2];                                 // ups of k-2..k+7, 1/ups of k-1..k+6
 #pragma unroll
-        for (int u = 0; u < UK; ++u) { ue[u + 2] = 0.15 * exp(tuc[u]); ie[u + 1] = 1.0 / ue[u + 2]; }
+        for (int u = 0; u < UKV; ++u) { ue[u + 2] = 0.15 * exp(tuc[u]); ie[u + 1] = 1.0 / ue[u + 2]; }
         {
-            const int lo = hb | ((l32 + 31) & 31), hi = hb | ((l32 + 1) & 31);
-            ue[0] = __shfl(ue[UK], lo); ue[1] = __shfl(ue[UK + 1], lo);
-            ue[UK + 2] = __shfl(ue[2], hi); ue[UK + 3] = __shfl(ue[3], hi);
-            ie[0] = __shfl(ie[UK], lo); ie[UK + 1] = __shfl(ie[1], hi);
+            const int lo = hb | ((l32 + LPC - 1) & (LPC - 1)), hi = hb | ((l32 + 1) & (LPC - 1));
+            ue[0] = __shfl(ue[UKV], lo); ue[1] = __shfl(ue[UKV + 1], lo);
+            ue[UKV + 2] = __shfl(ue[2], hi); ue[UKV + 3] = __shfl(ue[3], hi);
+            ie[0] = __shfl(ie[UKV], lo); ie[UKV + 1] = __shfl(ie[1], hi);
         }
         BDRT_S1_PROF(5);
         double sv0 = 0, sv1 = 0, sv2 = 0;
-        double w0_[UK], w1_[UK], w2_[UK], gup[UK];
+        double w0_[UKV], w1_[UKV], w2_[UKV], gup[UKV];
 #pragma unroll
-        for (int u = 0; u < UK; ++u) {
+        for (int u = 0; u < UKV; ++u) {
             const int k = kb + u;
             w0_[u] = 0.0; w1_[u] = 0.0; w2_[u] = 0.0; gup[u] = 0.0;
             if (k < K) {
@@ -349,17 +356,17 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             __builtin_amdgcn_sched_barrier(0);     // one k at a time: interleaving all six only inflates the register peak
         }
         // (L_i^T w_i)[k] = sum_d T_i[d] w_i[k + MAXBW - d]: one window per i through the private row
-        double gl_[UK];
+        double gl_[UKV];
 #pragma unroll
-        for (int u = 0; u < UK; ++u) gl_[u] = 0.0;
+        for (int u = 0; u < UKV; ++u) gl_[u] = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
-            for (int u = 0; u < UK; ++u) wrow[MAXBW + kb + u] = i == 0 ? w0_[u] : (i == 1 ? w1_[u] : w2_[u]);
+            for (int u = 0; u < UKV; ++u) wrow[MAXBW + kb + u] = i == 0 ? w0_[u] : (i == 1 ? w1_[u] : w2_[u]);
             wave_sync();
-            double ww[WIN];
+            double ww[WINV];
 #pragma unroll
-            for (int j = 0; j < WIN; ++j) ww[j] = wrow[kb + j];         // w_i[kb + j - MAXBW]
+            for (int j = 0; j < WINV; ++j) ww[j] = wrow[kb + j];         // w_i[kb + j - MAXBW]
             wave_sync();
             double tn = B.T[i][0];
 #pragma unroll
@@ -368,12 +375,12 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
                 if (d + 1 < NTAP) tn = B.T[i][d + 1];
                 __asm__ volatile("" ::: "memory");
 #pragma unroll
-                for (int u = 0; u < UK; ++u) gl_[u] = fma(t, ww[u + 2 * MAXBW - d], gl_[u]);
+                for (int u = 0; u < UKV; ++u) gl_[u] = fma(t, ww[u + 2 * MAXBW - d], gl_[u]);
             }
         }
 #pragma unroll
-        for (int u = 0; u < UK; ++u) { xrow[MAXBW + kb + u] = gup[u]; wrow[MAXBW + kb + u] = gl_[u]; }   // back to M1 for the epilogue
-        sv0 = hsum(sv0); sv1 = hsum(sv1); sv2 = hsum(sv2);
+        for (int u = 0; u < UKV; ++u) { xrow[MAXBW + kb + u] = gup[u]; wrow[MAXBW + kb + u] = gl_[u]; }   // back to M1 for the epilogue
+        sv0 = hsum<LPC>(sv0); sv1 = hsum<LPC>(sv1); sv2 = hsum<LPC>(sv2);
         if (l32 >= 6 && l32 < 9) {                                       // d_i gradients: lane 6+i
             const double sv = l32 == 6 ? sv0 : (l32 == 7 ? sv1 : sv2);
             gsc = -0.5 * sraw * sv - 6.0 + 5.0 / sraw + jac;
@@ -382,13 +389,13 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     }
     }
     // measured spectrum of this chain: issued before the barrier so that its latency hides behind the wait
-    double zre_[UN], zim_[UN], wn_[UN];
+    double zre_[UNV], zim_[UNV], wn_[UNV];
     {
         const int sp = io.spec ? io.spec[cc] : 0;
         const double *Zm = P.Z + (size_t)sp * N2;
 #pragma unroll
-        for (int v = 0; v < UN; ++v) {
-            const int n = l32 + 32 * v, nn = n < nf ? n : 0;
+        for (int v = 0; v < UNV; ++v) {
+            const int n = l32 + LPC * v, nn = n < nf ? n : 0;
             zre_[v] = Zm[nn]; zim_[v] = Zm[nf + nn]; wn_[v] = P.w[nn];
         }
     }
@@ -407,8 +414,8 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         const double ap2 = a_p * a_p, ar2 = a_r * a_r, ai2 = a_i * a_i;
         double sR = 0, sL = 0, sH = 0, sHz2 = 0, sHzr2 = 0, sHzi2 = 0;
 #pragma unroll
-        for (int v = 0; v < UN; ++v) {
-            const int n = l32 + 32 * v;
+        for (int v = 0; v < UNV; ++v) {
+            const int n = l32 + LPC * v;
             if (n >= nf) continue;
             const double wn = wn_[v];
             const double zr = Zh[swz(n, c)] + Rinf;
@@ -438,7 +445,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
                 io.sigma_tot[(size_t)c * N2 + nf + n] = sqrt(s2_im);
             }
         }
-        sR = hsum(sR); sL = hsum(sL); sH = hsum(sH); sHz2 = hsum(sHz2); sHzr2 = hsum(sHzr2); sHzi2 = hsum(sHzi2);
+        sR = hsum<LPC>(sR); sL = hsum<LPC>(sL); sH = hsum<LPC>(sH); sHz2 = hsum<LPC>(sHz2); sHzr2 = hsum<LPC>(sHzr2); sHzi2 = hsum<LPC>(sHzi2);
         if (l32 < 6) {
             // d lp / d(raw), likelihood part, of Rinf_raw, induc_raw, sigma_res_raw, alpha_prop/re/im_raw (lane j owns scalar j)
             double dl;
@@ -458,17 +465,17 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     BDRT_S1_TRACE(8);
     BDRT_S1_PROF(4);
     before_backward();
-    if (!(P.dbg & 2)) gemm_sw(B.BkA, B.tilesK, B.rpairsA, Zh, Xs, wave, lane);          // Xs = A^T g_Zhat
+    if (!(P.dbg & 2)) gemm_sw<NWV, GPFV>(B.BkA, B.tilesK, B.rpairsA, Zh, Xs, wave, lane);          // Xs = A^T g_Zhat
     BDRT_S1_TRACE(9);
     __syncthreads();                                                   // B4
     BDRT_S1_TRACE(10);
     BDRT_S1_PROF(8);
 
     // ---- epilogue (M1): chain rule through x = exp(theta_x); coalesced gradient rows ----------------------------------------
-    double gx_[UK], gu_[UK];
+    double gx_[UKV], gu_[UKV];
 #pragma unroll
-    for (int u = 0; u < UK; ++u) {
-        const int k = l32 + 32 * u;
+    for (int u = 0; u < UKV; ++u) {
+        const int k = l32 + LPC * u;
         gx_[u] = 0.0; gu_[u] = 0.0;
         if (k < K) {
             const double graw = Xs[swz(k, c)] + wrow[MAXBW + k];
@@ -481,13 +488,13 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     if (LDSIO) {
         wave_sync();                                                   // all transit values are in registers
 #pragma unroll
-        for (int u = 0; u < UK; ++u) {
-            const int k = l32 + 32 * u;
+        for (int u = 0; u < UKV; ++u) {
+            const int k = l32 + LPC * u;
             if (k < K) { xrow[B.o_x + k] = gx_[u]; xrow[B.o_ups + k] = gu_[u]; }
         }
         if (l32 < 9) xrow[l32 < 2 ? l32 : (l32 < 6 ? P.o_err + (l32 - 2) : B.o_d + (l32 - 6))] = gsc;
     }
-    lp = hsum(lp);
+    lp = hsum<LPC>(lp);
     if (l32 == 0 && io.lp && valid) io.lp[c] = lp;
     BDRT_S1_PROF(9);
     BDRT_S1_TRACE(11);
