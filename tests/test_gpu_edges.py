@@ -1,0 +1,88 @@
+"""GPU tests (-m gpu): edges of the evaluator's domain -- empty and ragged batches, the largest problem the fast S1 evaluator
+takes (K = 192, Nf = 96), the first size beyond it (generic evaluator), a problem that does not fit the 160 KiB LDS budget
+(loud error, no fallback), extreme parameter values (overflow -> non-finite lp, never a crash)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(nf, K, seed=0):
+    from bayes_drt_amd import matrices as gm
+    f = np.logspace(6, -2, nf)
+    bf = np.logspace(8, -4, K)
+    tau = 1 / (2 * np.pi * bf)
+    eps = 1 / np.mean(np.diff(np.log(tau)))
+    A = np.vstack([gm.construct_A(f, 'real', tau=tau, epsilon=eps), gm.construct_A(f, 'imag', tau=tau, epsilon=eps)])
+    L = [gm.construct_L(bf, tau=tau, epsilon=eps, order=o) for o in (0, 1, 2)]
+    blk = dict(A=A, L0=L[0], L1=L[1], L2=0.75 * L[2], nonneg=True)
+    rng = np.random.default_rng(seed)
+    x = np.exp(-0.5 * ((np.log(tau) + 6) / 1.5) ** 2)
+    Z = A @ x + np.concatenate([np.full(nf, 0.5), np.zeros(nf)])
+    Z = Z / np.std(np.hypot(Z[:nf], Z[nf:])) + 0.01 * rng.standard_normal(2 * nf)
+    kw = dict(sigma_min=0.002, ups_alpha=1.0, ups_beta=0.1, induc_scale=1.0)
+    return blk, Z, f, kw
+
+
+def _check_vs_oracle(nf, K, n_pts, expect_fast):
+    from bayes_drt_amd.model import Problem
+    from oracle import oracle as orc
+    blk, Z, f, kw = _problem(nf, K)
+    prob = Problem([blk], Z, f, **kw)
+    om = orc.OracleModel([blk], Z, f, **kw)
+    rng = np.random.default_rng(K)
+    th = rng.uniform(-2, 2, (n_pts, prob.D))
+    for jac in (False, True):
+        lp, g = prob.logp_grad(th, jacobian=jac)
+        for i in range(n_pts):
+            lr, gr = om.logp_grad(th[i], jacobian=jac)
+            assert abs(lp[i] - lr) <= 1e-10 * max(1.0, abs(lr))
+            assert np.max(np.abs(g[i] - gr)) <= 1e-10 * max(1.0, np.max(np.abs(gr)))
+    return prob
+
+
+def test_largest_fast_path_problem_K192_Nf96():
+    prob = _check_vs_oracle(96, 192, 21, True)
+    assert prob.D == 2 * 192 + 9
+
+
+def test_first_size_beyond_the_fast_path_uses_the_generic_evaluator():
+    _check_vs_oracle(81, 200, 5, False)
+    _check_vs_oracle(100, 120, 5, False)          # Nf > 96: generic evaluator as well
+
+
+def test_problem_beyond_the_lds_budget_fails_loudly():
+    from bayes_drt_amd.model import Problem
+    from bayes_drt_amd._lib import BdrtError
+    blk, Z, f, kw = _problem(81, 420)
+    with pytest.raises(BdrtError) as e:
+        Problem([blk], Z, f, **kw)
+    assert 'LDS' in str(e.value)
+
+
+def test_empty_single_and_ragged_batches():
+    from bayes_drt_amd.model import Problem
+    blk, Z, f, kw = _problem(40, 60)
+    prob = Problem([blk], Z, f, **kw)
+    lp, g = prob.logp_grad(np.empty((0, prob.D)))
+    assert lp.shape == (0,) and g.shape == (0, prob.D)
+    rng = np.random.default_rng(3)
+    th = rng.uniform(-2, 2, (33, prob.D))
+    lp_all, g_all = prob.logp_grad(th)
+    for B in (1, 15, 16, 17):                      # evaluations do not depend on how the batch is tiled (16 per workgroup)
+        lp_b, g_b = prob.logp_grad(th[:B])
+        assert np.array_equal(lp_b, lp_all[:B]) and np.array_equal(g_b, g_all[:B])
+
+
+def test_extreme_parameters_give_non_finite_lp_not_a_crash():
+    from bayes_drt_amd.model import Problem
+    blk, Z, f, kw = _problem(81, 161)
+    prob = Problem([blk], Z, f, **kw)
+    th = np.zeros((4, prob.D))
+    th[0, 2:50] = 800.0          # exp overflow in x
+    th[1, :] = -800.0            # everything underflows
+    th[2, 5] = np.nan
+    lp, g = prob.logp_grad(th, jacobian=True)
+    assert not np.isfinite(lp[0]) and not np.isfinite(lp[2])
+    assert np.isfinite(lp[3]) and np.all(np.isfinite(g[3]))
+    assert lp.shape == (4,)
