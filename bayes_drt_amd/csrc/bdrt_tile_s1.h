@@ -46,14 +46,6 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// value of lane (l32 + delta) of the same half-wave, for |delta| <= 2; callers handle the wrap to the neighbouring u
-__device__ __forceinline__ double hshift(double x, int delta)
-{
-    const int lane = threadIdx.x & 63;
-    const int src = (lane & 32) | ((lane + delta) & 31);
-    return __shfl(x, src);
-}
-
 // Os[(16 t + i)][c] = sum_k M[16 t + i][k] Bs[k][c] for the tiles t = wave, wave + 8, ... of this wave (swizzled LDS tiles).
 // The packed fragments (bdrt_model.hip::pack_fragments) stream from L2 through two register buffers of GPF operand pairs:
 // while the 2*GPF MFMAs of one chunk issue (~GPF * 128 cycles) the next chunk -- of this tile or of the wave's next tile --
@@ -158,11 +150,11 @@ constexpr int RW = 32 * UK + 2 * MAXBW;   // length of a chain's private LDS row
 constexpr int NTAP = 2 * MAXBW + 1;
 constexpr int WIN = UK + NTAP - 1;        // 22 values feed the 17-tap convolution of six consecutive k
 
-// LDS: Xs [XR rows][16] | Zh [16*tilesA rows][16] | XRow [16 chains][RW] | WRow [16 chains][RW] | taps [64]
+// LDS: Xs [XR rows][16] | Zh [16*tilesA rows][16] | private rows [16 chains][2 RW]
 __host__ __device__ inline size_t s1_lds_doubles(const DevProblem &P)
 {
     const DevBlock &B = P.blk[0];
-    return (size_t)NC * (P.XR + 16 * B.tilesA) + (size_t)2 * NC * RW + 64;     // + the 3 x 17 convolution taps
+    return (size_t)NC * (P.XR + 16 * B.tilesA) + (size_t)2 * NC * RW;
 }
 
 // Two thread mappings of a chain's K-vectors inside its half-wave:
@@ -207,10 +199,6 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     double *Zh = Xs + (size_t)P.XR * NC;
     double *xrow = Zh + (size_t)16 * B.tilesA * NC + (size_t)c * (2 * RW);   // the chain's private row: 2 RW doubles
     double *wrow = xrow + RW;
-    // convolution taps as LDS broadcast reads: 51 coefficients in scalar registers do not fit next to everything else
-    // (they were spilled to VGPR lanes: ~750 v_readlane/v_writelane per evaluation)
-    double *Tl = Zh + (size_t)16 * B.tilesA * NC + (size_t)2 * NC * RW;
-    if (tid < 3 * NTAP) Tl[tid] = B.T[tid / NTAP][tid % NTAP];
 
     const double *th = io.theta + (long)cc * io.t_sc;
     typedef const __attribute__((address_space(3))) double *lds_cptr;

@@ -16,6 +16,8 @@ for i in (10, 40, 70):
 bf = np.logspace(10, -6, 161)
 dists = {'DRT': {'kernel': 'DRT'},
          'TP-DDT': {'kernel': 'DDT', 'symmetry': 'planar', 'bc': 'transmissive', 'dist_type': 'parallel', 'x_scale': 0.8}}
+if '--series-outliers' in sys.argv:          # single DRT with the outlier error model: D = 2*161 + 9 + 2*81 = 493
+    dists = {'DRT': {'kernel': 'DRT'}}
 inv = Inverter(basis_freq=bf, distributions=dists)
 with warnings.catch_warnings():
     warnings.simplefilter('ignore')
