@@ -513,7 +513,9 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             const uint32_t iter = (uint32_t)s.iter, trial = (uint32_t)s.eps_trials, att = (uint32_t)s.init_attempt;
             double *THS = row(V_THS), *GS = row(V_GS);
             double ths_[NJ], gs_[NJ];
-            {
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) { ths_[m] = 0.0; gs_[m] = 0.0; }
+            if (upds || welf || wend || draw >= 0 || next == 1 || next == 3) {     // (a plain doubling needs none of it)
                 // current sample: the proposal of the tree if it was just accepted, else the stored sample
                 const double *ST = upds ? row(V_THQ) : THS, *SG = upds ? row(V_GQ) : GS;
 #pragma unroll
@@ -619,10 +621,16 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 // continue from the trajectory end in the new direction
                 const int dir = s.dir;
                 const double e1 = dir * s.eps;
-                const double *ET = row(dir > 0 ? V_THP : V_THM), *EP = row(dir > 0 ? V_PP : V_PM), *EG = row(dir > 0 ? V_GP : V_GM);
                 double et_[NJ], ep_[NJ], eg_[NJ];
+                if (dir == dir_now) {
+                    // same direction again: that end of the trajectory is the point just evaluated (theta, p, grad are here)
 #pragma unroll
-                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; et_[m] = ET[j]; ep_[m] = EP[j]; eg_[m] = EG[j]; }
+                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; et_[m] = TH[j]; ep_[m] = p_[m]; eg_[m] = g_[m]; }
+                } else {
+                    const double *ET = row(dir > 0 ? V_THP : V_THM), *EP = row(dir > 0 ? V_PP : V_PM), *EG = row(dir > 0 ? V_GP : V_GM);
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; et_[m] = ET[j]; ep_[m] = EP[j]; eg_[m] = EG[j]; }
+                }
 #pragma unroll
                 for (int m = 0; m < NJ; ++m) {
                     const int j = l32 + 32 * m;
