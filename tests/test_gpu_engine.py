@@ -203,3 +203,36 @@ def test_batched_optimize_equals_single_fits():
     for i in range(3):
         one, r1 = optimize_batch(prob, th0[i][None], spec=[i], max_iter=300, newton_max_iter=15)
         assert np.array_equal(one[0], both[i]) and r1[0]['iterations'] == rb[i]['iterations']
+
+
+@pytest.mark.parametrize('family', ['series_outliers_K161', 'series_parallel_2block'])
+def test_nuts_matches_oracle_on_the_wide_parameter_vectors(family):
+    """The sampler kernels for 352 < D <= 512 and D > 512 (outlier error model: D = 493; two blocks of 161: D = 656) against the
+    recursive oracle: identical tree shapes, draws equal to summation-order noise (short runs)."""
+    from bayes_drt_amd.model import Problem
+    from bayes_drt_amd.engine import sample_units
+    from oracle import oracle as orc
+    from tests.helpers import kat_to_model
+    if family == 'series_outliers_K161':
+        blk, Z, f, kw, d = _bench_problem('sample', 'K161')
+        so = load('dat_sample_outlier_scalars')
+        kw = dict(kw, outlier_mode=1, so_lambda=float(so['sigma_out_lambda']), so_alpha=float(so['sigma_out_alpha']),
+                  so_beta=float(so['sigma_out_beta']))
+        args = dict(blocks=[blk], Z=Z, freq=f, **kw)
+    else:
+        from bayes_drt_amd.engine import blocks_from_dat
+        dd = load('dat_sample_DRT-TpDDT_plain')
+        blocks, kw2, _ = blocks_from_dat('Series-Parallel_pos_StanModel.pkl', {k: dd[k] for k in dd.files})
+        args = dict(blocks=blocks, Z=dd['Z'], freq=dd['freq'], **kw2)
+    prob = Problem(**args)
+    om = orc.OracleModel(**args)
+    assert prob.D > 352
+    warm, nd, n_units = 6, 4, 3
+    ctrl = _ctrl(prob._lib, max_treedepth=5)
+    draws, lp, diag = sample_units(prob, n_units, warm, nd, 99, ctrl)
+    for c in range(n_units):
+        ref, lpr, dr = orc.nuts_sample(om, c, 99, warm, nd, control=orc.nuts_control(max_treedepth=5))
+        assert dr['n_leapfrog'] == diag[c]['n_leapfrog'], (c, dr, diag[c])
+        assert dr['n_divergent'] == diag[c]['n_divergent']
+        err = np.max(np.abs(draws[c] - ref), axis=1) / np.max(np.abs(ref))
+        assert np.all(err < 1e-6), err
