@@ -175,13 +175,23 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         // state of this chain that the stages after the evaluation need: momentum, inverse metric, and (odd leaves) the
         // momentum of the previous leaf.  The fast path issues these loads from inside the evaluation, right before its
         // backward GEMM; otherwise stage C loads them.
-        double p_[NJ], g_[NJ], mi_[NJ];
+        // Wide parameter vectors (NJ > 11: outlier error model, several distributions) do not fit in registers next to
+        // the evaluator: for them every stage below streams the chain's rows in chunks of MB elements per lane and keeps
+        // nothing in registers between stages (the momentum is stored back after the second half kick, the running
+        // sub-tree sum lives in the V_RHOC row).  Same arithmetic, element by element, as the register version.
+        constexpr bool CHUNKED = NJ > 11;
+        constexpr int NA = CHUNKED ? 1 : NJ;
+        constexpr int MB = NJ <= 11 ? NJ : (NJ % 8 == 0 ? 8 : 9);
+        static_assert(NJ % MB == 0, "chunk size must divide NJ");
+        double p_[NA], g_[NA], mi_[NA];
 #pragma unroll
-        for (int m = 0; m < NJ; ++m) { p_[m] = 0.0; g_[m] = 0.0; mi_[m] = 1.0; }
+        for (int m = 0; m < NA; ++m) { p_[m] = 0.0; g_[m] = 0.0; mi_[m] = 1.0; }
         auto load_state = [&]() {
-            if (act) {
+            if constexpr (!CHUNKED) {
+                if (act) {
 #pragma unroll
-                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; p_[m] = Pm[j]; mi_[m] = MI[j]; }
+                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; p_[m] = Pm[j]; mi_[m] = MI[j]; }
+                }
             }
         };
         if (MODE == 2) { logp_grad_tile_s1<true>(P, io, smem); load_state(); }
@@ -192,7 +202,26 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         // ---- C: second half kick, kinetic energy, finiteness of the gradient -----------------------------
         // (p, g, Minv of this chain stay in registers from here to the end of stage D)
         double kin = 0.0, nonfin = 0.0;
-        if (act) {
+        if constexpr (CHUNKED) {
+            if (act) {
+#pragma unroll 1
+                for (int mb = 0; mb < NJ; mb += MB) {
+                    double a_[MB], b_[MB], c_[MB];
+#pragma unroll
+                    for (int mm = 0; mm < MB; ++mm) { const int j = l32 + 32 * (mb + mm); a_[mm] = Pm[j]; b_[mm] = G[j]; c_[mm] = MI[j]; }
+#pragma unroll
+                    for (int mm = 0; mm < MB; ++mm) {
+                        const int j = l32 + 32 * (mb + mm);
+                        if (j < D) {
+                            const double p = a_[mm] + 0.5 * e * b_[mm];
+                            Pm[j] = p;                        // from here on the row holds the momentum after the full step
+                            kin += c_[mm] * p * p;
+                            nonfin += isfinite(b_[mm]) ? 0.0 : 1.0;
+                        }
+                    }
+                }
+            }
+        } else if (act) {
 #pragma unroll
             for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; g_[m] = G[j]; }
 #pragma unroll
@@ -294,15 +323,32 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         // ---- D: proposal copy, checkpoints, running rho, U-turn tests, subtree close ----------------------------
         if (copyq || cur2s) {
             double *THQ = row(V_THQ), *GQ = row(V_GQ), *THS = row(V_THS), *GS = row(V_GS);
-            double th_[NJ];
+            if constexpr (CHUNKED) {
+#pragma unroll 1
+                for (int mb = 0; mb < NJ; mb += MB) {
+                    double a_[MB], b_[MB];
 #pragma unroll
-            for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; th_[m] = TH[j]; }
+                    for (int mm = 0; mm < MB; ++mm) { const int j = l32 + 32 * (mb + mm); a_[mm] = TH[j]; b_[mm] = G[j]; }
 #pragma unroll
-            for (int m = 0; m < NJ; ++m) {
-                const int j = l32 + 32 * m;
-                if (j < D) {
-                    if (copyq) { THQ[j] = th_[m]; GQ[j] = g_[m]; }
-                    if (cur2s) { THS[j] = th_[m]; GS[j] = g_[m]; }
+                    for (int mm = 0; mm < MB; ++mm) {
+                        const int j = l32 + 32 * (mb + mm);
+                        if (j < D) {
+                            if (copyq) { THQ[j] = a_[mm]; GQ[j] = b_[mm]; }
+                            if (cur2s) { THS[j] = a_[mm]; GS[j] = b_[mm]; }
+                        }
+                    }
+                }
+            } else {
+                double th_[NJ];
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; th_[m] = TH[j]; }
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) {
+                    const int j = l32 + 32 * m;
+                    if (j < D) {
+                        if (copyq) { THQ[j] = th_[m]; GQ[j] = g_[m]; }
+                        if (cur2s) { THS[j] = th_[m]; GS[j] = g_[m]; }
+                    }
                 }
             }
         }
@@ -313,43 +359,91 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             // A leaf with nm trailing one bits closes nm sub-subtrees: each merge is one generalised U-turn test
             // (Stan 2.19 base_nuts::build_tree: compute_criterion(p_sharp_left, p_sharp_right, rho_subtree)).  The sums
             // associate exactly like the recursion does.
-            double rc_[NJ], cpl_[NJ];                  // rho / first momentum of the sub-subtree that ends at this leaf
-#pragma unroll
-            for (int m = 0; m < NJ; ++m) { rc_[m] = p_[m]; cpl_[m] = p_[m]; }
+            double rc_[NA], cpl_[NA];                  // rho / first momentum of the sub-subtree that ends at this leaf
             bool ok = true;
-            for (int l = 0; l < nm; ++l) {
-                double lr_[NJ], lp_[NJ];
-                if (l == 0) {
-                    const double *PL = row(V_CKP);
+            if constexpr (CHUNKED) {
+                // running sum of the merged sub-subtree in the V_RHOC row (level 0 merges read the momentum row itself)
+                double *RC = row(V_RHOC);
+                for (int l = 0; l < nm; ++l) {
+                    const double *RL = l == 0 ? row(V_CKP) : row(V_CKC + l), *PL = row(V_CKP + l);
+                    const double *RCs = l == 0 ? Pm : RC;
+                    double a0 = 0.0, a1 = 0.0;
+#pragma unroll 1
+                    for (int mb = 0; mb < NJ; mb += MB) {
+                        double lr_[MB], lp_[MB], rr_[MB], pp_[MB], mm_[MB];
 #pragma unroll
-                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; lp_[m] = PL[j]; lr_[m] = lp_[m]; }
-                } else {
-                    const double *RL = row(V_CKC + l), *PL = row(V_CKP + l);
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            lr_[mm] = RL[j]; lp_[mm] = PL[j]; rr_[mm] = RCs[j]; pp_[mm] = Pm[j]; mm_[mm] = MI[j];
+                        }
 #pragma unroll
-                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; lr_[m] = RL[j]; lp_[m] = PL[j]; }
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            if (j < D) {
+                                const double rho = lr_[mm] + rr_[mm];
+                                a0 += mm_[mm] * lp_[mm] * rho;
+                                a1 += mm_[mm] * pp_[mm] * rho;
+                                RC[j] = rho;
+                            }
+                        }
+                    }
+                    a0 = half_sum(a0); a1 = half_sum(a1);
+                    ok = ok && (a0 > 0.0) && (a1 > 0.0);
                 }
-                double a0 = 0.0, a1 = 0.0;
+                if (ok && !last) {
+                    // the sub-subtree of 2^nm leaves that ends here becomes the waiting left sibling of level nm; its first
+                    // momentum is the one of the last level merged (or this leaf's own)
+                    double *PLn = row(V_CKP + nm), *RLn = row(V_CKC + nm);
+                    const double *SRC = nm == 0 ? Pm : row(V_CKP + nm - 1);
+#pragma unroll 1
+                    for (int mb = 0; mb < NJ; mb += MB) {
+                        double a_[MB], b_[MB];
 #pragma unroll
-                for (int m = 0; m < NJ; ++m) {
-                    const int j = l32 + 32 * m;
-                    if (j < D) {
-                        const double rho = lr_[m] + rc_[m];
-                        a0 += mi_[m] * lp_[m] * rho;
-                        a1 += mi_[m] * p_[m] * rho;
-                        rc_[m] = rho;
-                        cpl_[m] = lp_[m];
+                        for (int mm = 0; mm < MB; ++mm) { const int j = l32 + 32 * (mb + mm); a_[mm] = SRC[j]; b_[mm] = nm > 0 ? RC[j] : 0.0; }
+#pragma unroll
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            if (j < D) { PLn[j] = a_[mm]; if (nm > 0) RLn[j] = b_[mm]; }
+                        }
                     }
                 }
-                a0 = half_sum(a0); a1 = half_sum(a1);
-                ok = ok && (a0 > 0.0) && (a1 > 0.0);
-            }
-            if (ok && !last) {
-                // the sub-subtree of 2^nm leaves that ends here becomes the waiting left sibling of level nm
-                double *PLn = row(V_CKP + nm), *RLn = row(V_CKC + nm);
+            } else {
 #pragma unroll
-                for (int m = 0; m < NJ; ++m) {
-                    const int j = l32 + 32 * m;
-                    if (j < D) { PLn[j] = cpl_[m]; if (nm > 0) RLn[j] = rc_[m]; }
+                for (int m = 0; m < NJ; ++m) { rc_[m] = p_[m]; cpl_[m] = p_[m]; }
+                for (int l = 0; l < nm; ++l) {
+                    double lr_[NJ], lp_[NJ];
+                    if (l == 0) {
+                        const double *PL = row(V_CKP);
+#pragma unroll
+                        for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; lp_[m] = PL[j]; lr_[m] = lp_[m]; }
+                    } else {
+                        const double *RL = row(V_CKC + l), *PL = row(V_CKP + l);
+#pragma unroll
+                        for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; lr_[m] = RL[j]; lp_[m] = PL[j]; }
+                    }
+                    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) {
+                        const int j = l32 + 32 * m;
+                        if (j < D) {
+                            const double rho = lr_[m] + rc_[m];
+                            a0 += mi_[m] * lp_[m] * rho;
+                            a1 += mi_[m] * p_[m] * rho;
+                            rc_[m] = rho;
+                            cpl_[m] = lp_[m];
+                        }
+                    }
+                    a0 = half_sum(a0); a1 = half_sum(a1);
+                    ok = ok && (a0 > 0.0) && (a1 > 0.0);
+                }
+                if (ok && !last) {
+                    // the sub-subtree of 2^nm leaves that ends here becomes the waiting left sibling of level nm
+                    double *PLn = row(V_CKP + nm), *RLn = row(V_CKC + nm);
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) {
+                        const int j = l32 + 32 * m;
+                        if (j < D) { PLn[j] = cpl_[m]; if (nm > 0) RLn[j] = rc_[m]; }
+                    }
                 }
             }
             if (!ok) {
@@ -360,22 +454,47 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 double *THE = row(dir_now > 0 ? V_THP : V_THM), *PE = row(dir_now > 0 ? V_PP : V_PM);
                 double *GE = row(dir_now > 0 ? V_GP : V_GM);
                 const double *PO = row(dir_now > 0 ? V_PM : V_PP);     // momentum at the other end
-                double rt_[NJ], po_[NJ], th_[NJ];
-#pragma unroll
-                for (int m = 0; m < NJ; ++m) {
-                    const int j = l32 + 32 * m, jj = j;
-                    rt_[m] = RHO[jj]; po_[m] = PO[jj]; th_[m] = TH[jj];
-                }
                 double t0 = 0.0, t1 = 0.0;
+                if constexpr (CHUNKED) {
+                    const double *SUB = nm > 0 ? row(V_RHOC) : Pm;     // rho of the completed subtree
+#pragma unroll 1
+                    for (int mb = 0; mb < NJ; mb += MB) {
+                        double r0_[MB], po_[MB], th_[MB], pp_[MB], gg_[MB], mm_[MB], rs_[MB];
 #pragma unroll
-                for (int m = 0; m < NJ; ++m) {
-                    const int j = l32 + 32 * m;
-                    if (j < D) {
-                        const double rt = rt_[m] + rc_[m];
-                        RHO[j] = rt;
-                        THE[j] = th_[m]; PE[j] = p_[m]; GE[j] = g_[m];
-                        t0 += mi_[m] * po_[m] * rt;
-                        t1 += mi_[m] * p_[m] * rt;
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            r0_[mm] = RHO[j]; po_[mm] = PO[j]; th_[mm] = TH[j]; pp_[mm] = Pm[j]; gg_[mm] = G[j]; mm_[mm] = MI[j];
+                            rs_[mm] = SUB[j];
+                        }
+#pragma unroll
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            if (j < D) {
+                                const double rt = r0_[mm] + rs_[mm];
+                                RHO[j] = rt;
+                                THE[j] = th_[mm]; PE[j] = pp_[mm]; GE[j] = gg_[mm];
+                                t0 += mm_[mm] * po_[mm] * rt;
+                                t1 += mm_[mm] * pp_[mm] * rt;
+                            }
+                        }
+                    }
+                } else {
+                    double rt_[NJ], po_[NJ], th_[NJ];
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) {
+                        const int j = l32 + 32 * m, jj = j;
+                        rt_[m] = RHO[jj]; po_[m] = PO[jj]; th_[m] = TH[jj];
+                    }
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) {
+                        const int j = l32 + 32 * m;
+                        if (j < D) {
+                            const double rt = rt_[m] + rc_[m];
+                            RHO[j] = rt;
+                            THE[j] = th_[m]; PE[j] = p_[m]; GE[j] = g_[m];
+                            t0 += mi_[m] * po_[m] * rt;
+                            t1 += mi_[m] * p_[m] * rt;
+                        }
                     }
                 }
                 t0 = half_sum(t0); t1 = half_sum(t1);
@@ -471,14 +590,32 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         //      leapfrog with p, g, Minv still in registers (theta is the only vector read; p is written once per leapfrog)
         if (act && next == 0 && s.phase == PH_TREE) {
             const double e1 = s.dir * s.eps;
-            double th_[NJ];
+            if constexpr (CHUNKED) {
+#pragma unroll 1
+                for (int mb = 0; mb < NJ; mb += MB) {
+                    double pp_[MB], gg_[MB], mm_[MB], th_[MB];
 #pragma unroll
-            for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; th_[m] = TH[j]; }
+                    for (int mm = 0; mm < MB; ++mm) {
+                        const int j = l32 + 32 * (mb + mm);
+                        pp_[mm] = Pm[j]; gg_[mm] = G[j]; mm_[mm] = MI[j]; th_[mm] = TH[j];
+                    }
 #pragma unroll
-            for (int m = 0; m < NJ; ++m) {
-                const int j = l32 + 32 * m;
-                const double p = p_[m] + 0.5 * e1 * g_[m];
-                if (j < D) { Pm[j] = p; TH[j] = th_[m] + e1 * mi_[m] * p; }
+                    for (int mm = 0; mm < MB; ++mm) {
+                        const int j = l32 + 32 * (mb + mm);
+                        const double p = pp_[mm] + 0.5 * e1 * gg_[mm];
+                        if (j < D) { Pm[j] = p; TH[j] = th_[mm] + e1 * mm_[mm] * p; }
+                    }
+                }
+            } else {
+                double th_[NJ];
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; th_[m] = TH[j]; }
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) {
+                    const int j = l32 + 32 * m;
+                    const double p = p_[m] + 0.5 * e1 * g_[m];
+                    if (j < D) { Pm[j] = p; TH[j] = th_[m] + e1 * mi_[m] * p; }
+                }
             }
         }
 
@@ -509,144 +646,294 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         // ---- E: sample update, metric adaptation, draw output, and the start of the next leapfrog when the trajectory does
         //      not simply continue (new transition, next doubling, step-size search, re-initialisation).  One batch of
         //      loads per case, everything else in registers, including the half kick + drift of the next evaluation.
-        if (upds || welf || wend || draw >= 0 || next) {
-            const uint32_t iter = (uint32_t)s.iter, trial = (uint32_t)s.eps_trials, att = (uint32_t)s.init_attempt;
-            double *THS = row(V_THS), *GS = row(V_GS);
-            double ths_[NJ], gs_[NJ];
+        if constexpr (CHUNKED) {
+            if (upds || welf || wend || draw >= 0 || next) {
+                const uint32_t iter = (uint32_t)s.iter, trial = (uint32_t)s.eps_trials, att = (uint32_t)s.init_attempt;
+                double *THS = row(V_THS), *GS = row(V_GS);
+                // pass 1: the current sample (accepted proposal or stored sample): bookkeeping, Welford, metric, draw output
+                if (upds || welf || wend || draw >= 0) {
+                    const double *ST = upds ? row(V_THQ) : THS, *SG = upds ? row(V_GQ) : GS;
+                    double *WM = row(V_WMEAN), *W2 = row(V_WM2);
+                    double *dr = (draw >= 0 && valid) ? a.draws + ((size_t)(c0 + c) * np.n_draws + draw) * D : nullptr;
+#pragma unroll 1
+                    for (int mb = 0; mb < NJ; mb += MB) {
+                        double ts_[MB], gs_[MB], wm_[MB], w2_[MB];
 #pragma unroll
-            for (int m = 0; m < NJ; ++m) { ths_[m] = 0.0; gs_[m] = 0.0; }
-            if (upds || welf || wend || draw >= 0 || next == 1 || next == 3) {     // (a plain doubling needs none of it)
-                // current sample: the proposal of the tree if it was just accepted, else the stored sample
-                const double *ST = upds ? row(V_THQ) : THS, *SG = upds ? row(V_GQ) : GS;
-#pragma unroll
-                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; ths_[m] = ST[j]; gs_[m] = SG[j]; }
-            }
-            if (upds) {
-#pragma unroll
-                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; if (j < D) { THS[j] = ths_[m]; GS[j] = gs_[m]; } }
-            }
-            if (welf || wend) {
-                double *WM = row(V_WMEAN), *W2 = row(V_WM2);
-                double wm_[NJ], w2_[NJ];
-#pragma unroll
-                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; wm_[m] = WM[j]; w2_[m] = W2[j]; }
-#pragma unroll
-                for (int m = 0; m < NJ; ++m) {
-                    const int j = l32 + 32 * m;
-                    if (j < D) {
-                        double mean = wm_[m], m2 = w2_[m];
-                        if (welf) {            // Welford (stan::math::welford_var_estimator)
-                            const double delta = ths_[m] - mean;
-                            mean += delta / wn;
-                            m2 += (ths_[m] - mean) * delta;
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            ts_[mm] = ST[j]; gs_[mm] = SG[j];
+                            wm_[mm] = 0.0; w2_[mm] = 0.0;
+                            if (welf || wend) { wm_[mm] = WM[j]; w2_[mm] = W2[j]; }
                         }
-                        if (wend) {            // var_adaptation::learn_variance
-                            const double var = wn > 1.0 ? m2 / (wn - 1.0) : 0.0;
-                            mi_[m] = (wn / (wn + 5.0)) * var + 1e-3 * (5.0 / (wn + 5.0));
-                            MI[j] = mi_[m];
-                            mean = 0.0; m2 = 0.0;
+#pragma unroll
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            if (j < D) {
+                                if (upds) { THS[j] = ts_[mm]; GS[j] = gs_[mm]; }
+                                if (welf || wend) {
+                                    double mean = wm_[mm], m2 = w2_[mm];
+                                    if (welf) {            // Welford (stan::math::welford_var_estimator)
+                                        const double delta = ts_[mm] - mean;
+                                        mean += delta / wn;
+                                        m2 += (ts_[mm] - mean) * delta;
+                                    }
+                                    if (wend) {            // var_adaptation::learn_variance
+                                        const double var = wn > 1.0 ? m2 / (wn - 1.0) : 0.0;
+                                        MI[j] = (wn / (wn + 5.0)) * var + 1e-3 * (5.0 / (wn + 5.0));
+                                        mean = 0.0; m2 = 0.0;
+                                    }
+                                    WM[j] = mean; W2[j] = m2;
+                                }
+                                if (dr) dr[j] = ts_[mm];
+                            }
                         }
-                        WM[j] = mean; W2[j] = m2;
                     }
                 }
-            }
-            if (draw >= 0 && valid) {
-                double *dr = a.draws + ((size_t)(c0 + c) * np.n_draws + draw) * D;
+                if (next == 1 || next == 3) {
+                    // fresh momentum (see the register version below for the scheme); the current sample is in THS / GS now
+                    // unless it was not touched by pass 1, in which case it is there anyway
+                    double *zrow = smem + (size_t)c * (tile_doubles / NC);
+                    const bool have_z = next == 1 && s.z_iter == (int)iter;
+                    const double *ZS = have_z ? row(V_ZN) : zrow;
+                    if (!have_z) {
+#pragma unroll 1
+                        for (int mp = 0; mp < (NJ + 1) / 2; ++mp) {
+                            const int i = l32 + 32 * mp;
+                            if (2 * i < D) {
+                                double z0, z1;
+                                rng_normal_pair(rng, (uint32_t)i, next == 1 ? RNG_MOMENTUM : RNG_EPS_MOMENTUM, next == 1 ? 0u : trial, iter, z0, z1);
+                                zrow[2 * i] = z0; zrow[2 * i + 1] = z1;
+                            }
+                        }
+                        lds_wave_sync();
+                    }
+                    double kin0 = 0.0;
+#pragma unroll 1
+                    for (int mb = 0; mb < NJ; mb += MB) {
+                        double z_[MB], mm_[MB];
 #pragma unroll
-                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; if (j < D) dr[j] = ths_[m]; }
-            }
-            if (next == 1 || next == 3) {
-                // fresh momentum p ~ N(0, M), M = diag(1/Minv).  Normals 2i and 2i+1 share one Philox block and one
-                // Box-Muller transform: a lane produces PAIRS and the chain's scratch row (its share of the idle tile
-                // LDS) turns them into the lane's own elements j = l32 + 32 m.
-                double *zrow = MODE == 2 ? s1_grad_row(P, smem, c) : smem + (size_t)c * (tile_doubles / NC);
-                const bool have_z = next == 1 && s.z_iter == (int)iter;      // stage Z of an earlier round did the work
-                double z_[NJ];
-                if (have_z) {
-                    const double *ZN = row(V_ZN);
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            z_[mm] = j < D ? ZS[j] : 0.0; mm_[mm] = MI[j];
+                        }
 #pragma unroll
-                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; z_[m] = ZN[j]; }
-                } else {
-#pragma unroll
-                    for (int mp = 0; mp < (NJ + 1) / 2; ++mp) {
-                        const int i = l32 + 32 * mp;
-                        if (2 * i < D) {
-                            double z0, z1;
-                            rng_normal_pair(rng, (uint32_t)i, next == 1 ? RNG_MOMENTUM : RNG_EPS_MOMENTUM, next == 1 ? 0u : trial, iter, z0, z1);
-                            zrow[2 * i] = z0; zrow[2 * i + 1] = z1;
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            if (j < D) {
+                                const double p = z_[mm] / sqrt(mm_[mm]);
+                                Pm[j] = p;                    // start momentum; kicked in the last pass
+                                kin0 += mm_[mm] * p * p;
+                            }
                         }
                     }
                     lds_wave_sync();
+                    kin0 = half_sum(kin0);
+                    s.H0 = -s.lps + 0.5 * kin0;
+                    if (next == 1) {
+                        s.lsw = 0.0; s.lsw_sub = -INFINITY; s.depth = 0; s.leaf = 0; s.nleaves = 1;
+                        s.n_leap_iter = 0; s.sum_metro = 0.0;
+                        s.dir = rng_uniform(rng, 0, RNG_DIRECTION, 0, 0, (uint32_t)s.iter) > 0.5 ? 1 : -1;
+                    }
+                    const double e1 = next == 1 ? s.dir * s.eps : s.eps;
+                    const double *ST = upds ? row(V_THQ) : THS, *SG = upds ? row(V_GQ) : GS;
+                    double *rTHM = row(V_THM), *rTHP = row(V_THP), *rPM = row(V_PM), *rPP = row(V_PP), *rGM = row(V_GM),
+                           *rGP = row(V_GP), *rRHO = row(V_RHO);
+#pragma unroll 1
+                    for (int mb = 0; mb < NJ; mb += MB) {
+                        double pp_[MB], ts_[MB], gs_[MB], mm_[MB];
 #pragma unroll
-                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; z_[m] = j < D ? zrow[j] : 0.0; }
-                    lds_wave_sync();
-                }
-                double kin0 = 0.0;
-                double pn_[NJ];
-#pragma unroll
-                for (int m = 0; m < NJ; ++m) {
-                    const int j = l32 + 32 * m;
-                    const double p = j < D ? z_[m] / sqrt(mi_[m]) : 0.0;
-                    pn_[m] = p;
-                    kin0 += mi_[m] * p * p;
-                }
-                // Hamiltonian at the start point; a new transition also resets the tree and draws its first direction
-                kin0 = half_sum(kin0);
-                s.H0 = -s.lps + 0.5 * kin0;
-                if (next == 1) {
-                    s.lsw = 0.0; s.lsw_sub = -INFINITY; s.depth = 0; s.leaf = 0; s.nleaves = 1;
-                    s.n_leap_iter = 0; s.sum_metro = 0.0;
-                    s.dir = rng_uniform(rng, 0, RNG_DIRECTION, 0, 0, (uint32_t)s.iter) > 0.5 ? 1 : -1;
-                }
-                const double e1 = next == 1 ? s.dir * s.eps : s.eps;
-                double *rTHM = row(V_THM), *rTHP = row(V_THP), *rPM = row(V_PM), *rPP = row(V_PP), *rGM = row(V_GM),
-                       *rGP = row(V_GP), *rRHO = row(V_RHO);
-#pragma unroll
-                for (int m = 0; m < NJ; ++m) {
-                    const int j = l32 + 32 * m;
-                    if (j < D) {
-                        const double p = pn_[m];
-                        if (next == 1) {
-                            rTHM[j] = ths_[m]; rTHP[j] = ths_[m];
-                            rPM[j] = p; rPP[j] = p;
-                            rGM[j] = gs_[m]; rGP[j] = gs_[m];
-                            rRHO[j] = p;
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            pp_[mm] = Pm[j]; ts_[mm] = ST[j]; gs_[mm] = SG[j]; mm_[mm] = MI[j];
                         }
-                        const double pk = p + 0.5 * e1 * gs_[m];
-                        Pm[j] = pk;
-                        TH[j] = ths_[m] + e1 * mi_[m] * pk;
+#pragma unroll
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            if (j < D) {
+                                const double p = pp_[mm];
+                                if (next == 1) {
+                                    rTHM[j] = ts_[mm]; rTHP[j] = ts_[mm];
+                                    rPM[j] = p; rPP[j] = p;
+                                    rGM[j] = gs_[mm]; rGP[j] = gs_[mm];
+                                    rRHO[j] = p;
+                                }
+                                const double pk = p + 0.5 * e1 * gs_[mm];
+                                Pm[j] = pk;
+                                TH[j] = ts_[mm] + e1 * mm_[mm] * pk;
+                            }
+                        }
                     }
-                }
-            } else if (next == 2) {
-                // continue from the trajectory end in the new direction
-                const int dir = s.dir;
-                const double e1 = dir * s.eps;
-                double et_[NJ], ep_[NJ], eg_[NJ];
-                if (dir == dir_now) {
-                    // same direction again: that end of the trajectory is the point just evaluated (theta, p, grad are here)
+                } else if (next == 2) {
+                    const int dir = s.dir;
+                    const double e1 = dir * s.eps;
+                    const bool same = dir == dir_now;
+                    const double *ET = same ? TH : row(dir > 0 ? V_THP : V_THM), *EP = same ? Pm : row(dir > 0 ? V_PP : V_PM);
+                    const double *EG = same ? G : row(dir > 0 ? V_GP : V_GM);
+#pragma unroll 1
+                    for (int mb = 0; mb < NJ; mb += MB) {
+                        double et_[MB], ep_[MB], eg_[MB], mm_[MB];
 #pragma unroll
-                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; et_[m] = TH[j]; ep_[m] = p_[m]; eg_[m] = g_[m]; }
-                } else {
-                    const double *ET = row(dir > 0 ? V_THP : V_THM), *EP = row(dir > 0 ? V_PP : V_PM), *EG = row(dir > 0 ? V_GP : V_GM);
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            et_[mm] = ET[j]; ep_[mm] = EP[j]; eg_[mm] = EG[j]; mm_[mm] = MI[j];
+                        }
 #pragma unroll
-                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; et_[m] = ET[j]; ep_[m] = EP[j]; eg_[m] = EG[j]; }
-                }
-#pragma unroll
-                for (int m = 0; m < NJ; ++m) {
-                    const int j = l32 + 32 * m;
-                    if (j < D) {
-                        const double pk = ep_[m] + 0.5 * e1 * eg_[m];
-                        Pm[j] = pk;
-                        TH[j] = et_[m] + e1 * mi_[m] * pk;
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            if (j < D) {
+                                const double pk = ep_[mm] + 0.5 * e1 * eg_[mm];
+                                Pm[j] = pk;
+                                TH[j] = et_[mm] + e1 * mm_[mm] * pk;
+                            }
+                        }
                     }
-                }
-            } else if (next == 4) {
-#pragma unroll
-                for (int m = 0; m < NJ; ++m) {
-                    const int j = l32 + 32 * m;
-                    if (j < D) {
+                } else if (next == 4) {
+                    for (int j = l32; j < D; j += 32) {
                         TH[j] = np.init_radius * (2.0 * rng_uniform(rng, (uint32_t)j, RNG_INIT, 0, att, 0) - 1.0);
                         Pm[j] = 0.0;
+                    }
+                }
+            }
+        } else {
+            if (upds || welf || wend || draw >= 0 || next) {
+                const uint32_t iter = (uint32_t)s.iter, trial = (uint32_t)s.eps_trials, att = (uint32_t)s.init_attempt;
+                double *THS = row(V_THS), *GS = row(V_GS);
+                double ths_[NJ], gs_[NJ];
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { ths_[m] = 0.0; gs_[m] = 0.0; }
+                if (upds || welf || wend || draw >= 0 || next == 1 || next == 3) {     // (a plain doubling needs none of it)
+                    // current sample: the proposal of the tree if it was just accepted, else the stored sample
+                    const double *ST = upds ? row(V_THQ) : THS, *SG = upds ? row(V_GQ) : GS;
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; ths_[m] = ST[j]; gs_[m] = SG[j]; }
+                }
+                if (upds) {
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; if (j < D) { THS[j] = ths_[m]; GS[j] = gs_[m]; } }
+                }
+                if (welf || wend) {
+                    double *WM = row(V_WMEAN), *W2 = row(V_WM2);
+                    double wm_[NJ], w2_[NJ];
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; wm_[m] = WM[j]; w2_[m] = W2[j]; }
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) {
+                        const int j = l32 + 32 * m;
+                        if (j < D) {
+                            double mean = wm_[m], m2 = w2_[m];
+                            if (welf) {            // Welford (stan::math::welford_var_estimator)
+                                const double delta = ths_[m] - mean;
+                                mean += delta / wn;
+                                m2 += (ths_[m] - mean) * delta;
+                            }
+                            if (wend) {            // var_adaptation::learn_variance
+                                const double var = wn > 1.0 ? m2 / (wn - 1.0) : 0.0;
+                                mi_[m] = (wn / (wn + 5.0)) * var + 1e-3 * (5.0 / (wn + 5.0));
+                                MI[j] = mi_[m];
+                                mean = 0.0; m2 = 0.0;
+                            }
+                            WM[j] = mean; W2[j] = m2;
+                        }
+                    }
+                }
+                if (draw >= 0 && valid) {
+                    double *dr = a.draws + ((size_t)(c0 + c) * np.n_draws + draw) * D;
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; if (j < D) dr[j] = ths_[m]; }
+                }
+                if (next == 1 || next == 3) {
+                    // fresh momentum p ~ N(0, M), M = diag(1/Minv).  Normals 2i and 2i+1 share one Philox block and one
+                    // Box-Muller transform: a lane produces PAIRS and the chain's scratch row (its share of the idle tile
+                    // LDS) turns them into the lane's own elements j = l32 + 32 m.
+                    double *zrow = MODE == 2 ? s1_grad_row(P, smem, c) : smem + (size_t)c * (tile_doubles / NC);
+                    const bool have_z = next == 1 && s.z_iter == (int)iter;      // stage Z of an earlier round did the work
+                    double z_[NJ];
+                    if (have_z) {
+                        const double *ZN = row(V_ZN);
+#pragma unroll
+                        for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; z_[m] = ZN[j]; }
+                    } else {
+#pragma unroll
+                        for (int mp = 0; mp < (NJ + 1) / 2; ++mp) {
+                            const int i = l32 + 32 * mp;
+                            if (2 * i < D) {
+                                double z0, z1;
+                                rng_normal_pair(rng, (uint32_t)i, next == 1 ? RNG_MOMENTUM : RNG_EPS_MOMENTUM, next == 1 ? 0u : trial, iter, z0, z1);
+                                zrow[2 * i] = z0; zrow[2 * i + 1] = z1;
+                            }
+                        }
+                        lds_wave_sync();
+#pragma unroll
+                        for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; z_[m] = j < D ? zrow[j] : 0.0; }
+                        lds_wave_sync();
+                    }
+                    double kin0 = 0.0;
+                    double pn_[NJ];
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) {
+                        const int j = l32 + 32 * m;
+                        const double p = j < D ? z_[m] / sqrt(mi_[m]) : 0.0;
+                        pn_[m] = p;
+                        kin0 += mi_[m] * p * p;
+                    }
+                    // Hamiltonian at the start point; a new transition also resets the tree and draws its first direction
+                    kin0 = half_sum(kin0);
+                    s.H0 = -s.lps + 0.5 * kin0;
+                    if (next == 1) {
+                        s.lsw = 0.0; s.lsw_sub = -INFINITY; s.depth = 0; s.leaf = 0; s.nleaves = 1;
+                        s.n_leap_iter = 0; s.sum_metro = 0.0;
+                        s.dir = rng_uniform(rng, 0, RNG_DIRECTION, 0, 0, (uint32_t)s.iter) > 0.5 ? 1 : -1;
+                    }
+                    const double e1 = next == 1 ? s.dir * s.eps : s.eps;
+                    double *rTHM = row(V_THM), *rTHP = row(V_THP), *rPM = row(V_PM), *rPP = row(V_PP), *rGM = row(V_GM),
+                           *rGP = row(V_GP), *rRHO = row(V_RHO);
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) {
+                        const int j = l32 + 32 * m;
+                        if (j < D) {
+                            const double p = pn_[m];
+                            if (next == 1) {
+                                rTHM[j] = ths_[m]; rTHP[j] = ths_[m];
+                                rPM[j] = p; rPP[j] = p;
+                                rGM[j] = gs_[m]; rGP[j] = gs_[m];
+                                rRHO[j] = p;
+                            }
+                            const double pk = p + 0.5 * e1 * gs_[m];
+                            Pm[j] = pk;
+                            TH[j] = ths_[m] + e1 * mi_[m] * pk;
+                        }
+                    }
+                } else if (next == 2) {
+                    // continue from the trajectory end in the new direction
+                    const int dir = s.dir;
+                    const double e1 = dir * s.eps;
+                    double et_[NJ], ep_[NJ], eg_[NJ];
+                    if (dir == dir_now) {
+                        // same direction again: that end of the trajectory is the point just evaluated (theta, p, grad are here)
+#pragma unroll
+                        for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; et_[m] = TH[j]; ep_[m] = p_[m]; eg_[m] = g_[m]; }
+                    } else {
+                        const double *ET = row(dir > 0 ? V_THP : V_THM), *EP = row(dir > 0 ? V_PP : V_PM), *EG = row(dir > 0 ? V_GP : V_GM);
+#pragma unroll
+                        for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; et_[m] = ET[j]; ep_[m] = EP[j]; eg_[m] = EG[j]; }
+                    }
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) {
+                        const int j = l32 + 32 * m;
+                        if (j < D) {
+                            const double pk = ep_[m] + 0.5 * e1 * eg_[m];
+                            Pm[j] = pk;
+                            TH[j] = et_[m] + e1 * mi_[m] * pk;
+                        }
+                    }
+                } else if (next == 4) {
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) {
+                        const int j = l32 + 32 * m;
+                        if (j < D) {
+                            TH[j] = np.init_radius * (2.0 * rng_uniform(rng, (uint32_t)j, RNG_INIT, 0, att, 0) - 1.0);
+                            Pm[j] = 0.0;
+                        }
                     }
                 }
             }
