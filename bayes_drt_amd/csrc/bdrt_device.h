@@ -57,6 +57,7 @@ struct DevProblem {
     int n_spectra;
     int XR, ZR, LR, npar;     // LDS row counts
     int toep_all;             // every block takes the structured (banded Toeplitz) L path
+    int w3;                   // structured path: Lr holds all three w_i buffers (else one buffer, i after i: +4 barriers per block)
     int fast_s1;              // single series block, no outlier parameters, structured: bdrt_tile_s1.h evaluates it
     int XCR;                  // rows of the x cache (0: exp(theta_x) is recomputed where needed)
     int xc_off[MAXB];         // first cache row of each block
@@ -455,7 +456,22 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
     for (int b = 0; b < P.nblocks; ++b) {
         const DevBlock &B = P.blk[b];
         const int K = B.K, KP = 8 * B.kpairs;
-        const double *xc = XC + (size_t)P.xc_off[b] * NC;
+        double *xc = XC + (size_t)P.xc_off[b] * NC;
+        if (cache_x && P.nblocks > 1) {
+            // the blocks share ONE x-cache buffer (LDS budget): bring this block's raw x back (phase 1 left the last block's)
+            for (int k0 = g; k0 < KP; k0 += NG * UK) {
+                double t_[UK];
+#pragma unroll
+                for (int u = 0; u < UK; ++u) { const int k = k0 + NG * u; t_[u] = k < K ? TH(B.o_x + k) : 0.0; }
+#pragma unroll
+                for (int u = 0; u < UK; ++u) {
+                    const int k = k0 + NG * u;
+                    if (k < KP) xc[(MAXBW + k) * NC + c] = k < K ? (B.is_pos ? exp(t_[u]) : t_[u]) : 0.0;
+                }
+            }
+            if (g < MAXBW) { xc[g * NC + c] = 0.0; xc[(MAXBW + KP + g) * NC + c] = 0.0; }
+            __syncthreads();
+        }
         if (cache_x) {
             if (!TOEP) for (int k = g; k < KP; k += NG) Xs[k * NC + c] = xc[(MAXBW + k) * NC + c];
         } else {
@@ -470,8 +486,10 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
                 }
             }
         }
-        const int WS = K + 2 * MAXBW;                     // row stride of the w_i buffers in the structured path
         double cv_[3][TOEP ? UK : 1];                      // structured path: v_i[k] of this thread's k's
+        double wreg_[3][TOEP ? UK : 1];                    // structured path: w_i[k] = -d_i v_i / ups^2 (one LDS buffer, i after i)
+#pragma unroll
+        for (int u = 0; u < (TOEP ? UK : 1); ++u) { wreg_[0][u] = 0.0; wreg_[1][u] = 0.0; wreg_[2][u] = 0.0; }
         if (TOEP) {
             // v_i = L_i x as a (2*MAXBW+1)-tap convolution of the cached x.  Tap-outer loop: only the three
             // coefficients of one tap are live (scalar loads), the 18 accumulators stay in registers.
@@ -547,9 +565,15 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
                     GW(B.o_ups + k, uu * gu - (P.ups_alpha + 1.0) + P.ups_beta * ir + jac);
                     PW(B.o_ups + k, uu * (1.0 / 0.15));
                     if (TOEP) {
-                        Lr[(MAXBW + k) * NC + c] = -d0 * v0 * iu2;
-                        Lr[(WS + MAXBW + k) * NC + c] = -d1 * v1 * iu2;
-                        Lr[(2 * WS + MAXBW + k) * NC + c] = -d2 * v2 * iu2;
+                        wreg_[0][TOEP ? u : 0] = -d0 * v0 * iu2;
+                        wreg_[1][TOEP ? u : 0] = -d1 * v1 * iu2;
+                        wreg_[2][TOEP ? u : 0] = -d2 * v2 * iu2;
+                        Lr[(MAXBW + k) * NC + c] = wreg_[0][TOEP ? u : 0];        // w_0 goes out right away
+                        if (P.w3) {
+                            const int WS = K + 2 * MAXBW;
+                            Lr[(WS + MAXBW + k) * NC + c] = wreg_[1][TOEP ? u : 0];
+                            Lr[(2 * WS + MAXBW + k) * NC + c] = wreg_[2][TOEP ? u : 0];
+                        }
                     } else {
                         Lr[k * NC + c] = -d0 * v0 * iu2;
                         Lr[(K + k) * NC + c] = -d1 * v1 * iu2;
@@ -557,9 +581,9 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
                     }
                 }
             }
-            if (TOEP && g < MAXBW) {                    // zero halo of the three w_i buffers
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
+            if (TOEP && g < MAXBW) {                    // zero halo of the w buffer(s)
+                const int WS = K + 2 * MAXBW;
+                for (int i = 0; i < (P.w3 ? 3 : 1); ++i) {
                     Lr[(i * WS + g) * NC + c] = 0.0;
                     Lr[(i * WS + MAXBW + K + g) * NC + c] = 0.0;
                 }
@@ -601,16 +625,39 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
         for (int u = 0; u < (TOEP ? UK : 1); ++u) gl_[u] = 0.0;
         if (TOEP) {
             if (!(P.dbg & 2)) gemm_backward(B.BkA, B.tilesK, B.rpairsA, 0, Ra, Lr, Xs, wave, lane);   // A^T g only
+            if (P.w3) {
+                const int WS = K + 2 * MAXBW;
 #pragma unroll 1
-            for (int d = 0; d <= 2 * MAXBW; ++d) {
-                // (L^T w)[k] = sum_d' L[k - d'][k] w[k - d'] with d' = d - MAXBW
-                const double t0 = B.T[0][d], t1 = B.T[1][d], t2 = B.T[2][d];
+                for (int d = 0; d <= 2 * MAXBW; ++d) {
+                    // (L^T w)[k] = sum_d' L[k - d'][k] w[k - d'] with d' = d - MAXBW
+                    const double t0 = B.T[0][d], t1 = B.T[1][d], t2 = B.T[2][d];
 #pragma unroll
-                for (int u = 0; u < UK; ++u) {
-                    const int k = g + NG * u;
-                    if (k < K) {
-                        const int r = 2 * MAXBW + k - d;                      // = MAXBW + (k - d')
-                        gl_[u] += t0 * Lr[r * NC + c] + t1 * Lr[(WS + r) * NC + c] + t2 * Lr[(2 * WS + r) * NC + c];
+                    for (int u = 0; u < UK; ++u) {
+                        const int k = g + NG * u;
+                        if (k < K) {
+                            const int r = 2 * MAXBW + k - d;                      // = MAXBW + (k - d')
+                            gl_[u] += t0 * Lr[r * NC + c] + t1 * Lr[(WS + r) * NC + c] + t2 * Lr[(2 * WS + r) * NC + c];
+                        }
+                    }
+                }
+            } else
+            // sum_i L_i^T w_i through ONE LDS buffer: w_0 is already there; w_1, w_2 follow (two barriers each)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i > 0) {
+                    __syncthreads();                                          // everybody is done reading w_(i-1)
+#pragma unroll
+                    for (int u = 0; u < UK; ++u) { const int k = g + NG * u; if (k < K) Lr[(MAXBW + k) * NC + c] = wreg_[i][u]; }
+                    __syncthreads();
+                }
+#pragma unroll 1
+                for (int d = 0; d <= 2 * MAXBW; ++d) {
+                    // (L^T w)[k] = sum_d' L[k - d'][k] w[k - d'] with d' = d - MAXBW
+                    const double t = B.T[i][d];
+#pragma unroll
+                    for (int u = 0; u < UK; ++u) {
+                        const int k = g + NG * u;
+                        if (k < K) gl_[u] += t * Lr[(2 * MAXBW + k - d) * NC + c];        // row MAXBW + (k - d')
                     }
                 }
             }

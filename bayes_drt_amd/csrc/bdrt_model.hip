@@ -181,28 +181,40 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
     // cache exp(theta_x) in LDS when the workgroup's LDS budget allows it (it always does for one 81x161 block)
     {
         int rows = 0;
-        for (int b = 0; b < dat->nblocks; ++b) { D.xc_off[b] = rows; rows += 8 * D.blk[b].kpairs + 2 * MAXBW; }
+        // one buffer shared by the blocks (the evaluator regenerates a block's x when it needs it again)
+        for (int b = 0; b < dat->nblocks; ++b) { D.xc_off[b] = 0; rows = std::max(rows, 8 * D.blk[b].kpairs + 2 * MAXBW); }
         D.XCR = rows;
-        // structured path needs the cache and 3 halo-padded w buffers in Lr
-        int LRs = D.LR;
-        for (int b = 0; b < dat->nblocks; ++b) if (toep_ok[b]) LRs = std::max(LRs, (3 * (dat->K[b] + 2 * MAXBW) + 15) / 16 * 16);
+        // structured path: Lr only holds A x (16*tilesA rows) and ONE halo-padded w buffer; dense path: [L0;L1;L2] x
         const int LR0 = D.LR;
-        D.LR = LRs;
-        if (lds_doubles(D) * sizeof(double) + 8192 > 160 * 1024) {
-            D.LR = LR0; D.XCR = 0;
-            for (int b = 0; b < MAXB; ++b) { D.xc_off[b] = 0; toep_ok[b] = 0; }
-            if (lds_doubles(D) * sizeof(double) > 160 * 1024) { /* reported below */ }
+        bool all = !getenv("BDRT_DENSE_L");
+        int LRs = MIN_LR;
+        for (int b = 0; b < dat->nblocks; ++b) {
+            all = all && toep_ok[b];
+            LRs = std::max(LRs, std::max(16 * D.blk[b].tilesA, ((dat->K[b] + 2 * MAXBW) + 15) / 16 * 16));
         }
-        bool all = D.XCR > 0 && !getenv("BDRT_DENSE_L");
-        for (int b = 0; b < dat->nblocks; ++b) all = all && toep_ok[b];
+        if (all) {
+            // all three w buffers when they fit (saves four barriers per block and evaluation), else one
+            int LR3 = LRs;
+            for (int b = 0; b < dat->nblocks; ++b) LR3 = std::max(LR3, (3 * (dat->K[b] + 2 * MAXBW) + 15) / 16 * 16);
+            D.LR = LR3; D.w3 = 1;
+            if (lds_doubles(D) * sizeof(double) + 8192 > 160 * 1024) { D.LR = LRs; D.w3 = 0; }
+            if (lds_doubles(D) * sizeof(double) + 8192 > 160 * 1024) all = false;
+        }
+        if (!all) {
+            D.LR = LR0; D.w3 = 0;
+            if (lds_doubles(D) * sizeof(double) + 8192 > 160 * 1024) { D.XCR = 0; for (int b = 0; b < MAXB; ++b) D.xc_off[b] = 0; }
+        }
         for (int b = 0; b < dat->nblocks; ++b) D.blk[b].toep = all ? 1 : 0;
         D.toep_all = all ? 1 : 0;
-        if (!all) D.LR = LR0;
         // headline family on a log-uniform grid: half-wave-per-chain evaluator (bdrt_tile_s1.h)
         D.fast_s1 = (all && dat->nblocks == 1 && !D.blk[0].is_parallel && D.outlier_mode == 0 && !D.use_x_sum &&
                      D.blk[0].x_scale == 1.0 && nf <= 32 * UN && D.blk[0].K <= 32 * UK &&
                      s1_lds_doubles(D) <= lds_doubles(D) && !getenv("BDRT_GENERIC_TILE")) ? 1 : 0;
     }
+    if (getenv("BDRT_VERBOSE"))
+        fprintf(stderr, "bdrt_problem_create: nf=%d blocks=%d D=%d structured_L=%d (per block %d %d %d) fast_s1=%d LDS rows X=%d Z=%d x%d L=%d XC=%d -> %zu B\n",
+                nf, dat->nblocks, D.D, D.toep_all, toep_ok[0], dat->nblocks > 1 ? toep_ok[1] : -1, dat->nblocks > 2 ? toep_ok[2] : -1,
+                D.fast_s1, D.XR, D.ZR, 1 + D.npar, D.LR, D.XCR, lds_doubles(D) * sizeof(double));
     if (const char *e = getenv("BDRT_DEBUG_SKIP")) D.dbg = atoi(e);
     P.lds_bytes = lds_doubles(D) * sizeof(double);
     if (P.lds_bytes > 160 * 1024) {
