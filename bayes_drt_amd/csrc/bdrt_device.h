@@ -81,6 +81,33 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// Sum over the 32 lanes of a half-wave, result in every lane.  Four of the five butterfly steps are DPP moves on the VALU
+// (quad xor 1, quad xor 2, row_half_mirror, row_mirror: any pairing of equal partial sums will do), only the step across
+// the two 16-lane rows needs the LDS crossbar (ds_swizzle, no address register).  The plain __shfl_xor butterfly is five
+// ds_bpermute round trips (~150 cycles each) on the critical path of every per-chain reduction.
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double swizzle_xor16(double x)
+{
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), 0x401F);      // bit mode: and 0x1F, or 0, xor 0x10
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), 0x401F);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sum32(double x)
+{
+    x += dpp_perm<0xB1>(x);        // quad_perm [1,0,3,2]
+    x += dpp_perm<0x4E>(x);        // quad_perm [2,3,0,1]
+    x += dpp_perm<0x141>(x);       // row_half_mirror
+    x += dpp_perm<0x140>(x);       // row_mirror
+    x += swizzle_xor16(x);
+    return x;
+}
+
 // Y[(16 t + i)][c] = sum_k M[16 t + i][k] X[k][c] for the tiles of this wave.
 // Fragment order (host packing in bdrt_model.hip::pack_forward): element (tile t, pair p, lane l, h) =
 // M[16 t + (l & 15)][8 p + 4 h + (l >> 4)].

@@ -35,15 +35,7 @@ enum { V_TH = 0, V_P, V_G, V_THM, V_PM, V_GM, V_THP, V_PP, V_GP, V_THS, V_GS, V_
        V_WMEAN, V_WM2, V_ZN /* normals of the next transition's momentum, produced ahead of time */, V_CKC /* MAXD */, V_CKP = V_CKC + MAXD /* MAXD */, V_COUNT = V_CKP + MAXD };
 
 // sum over the 32 lanes of a half-wave (one chain), fixed order => deterministic; every lane gets the result
-__device__ __forceinline__ double half_sum(double x)
-{
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 8);
-    x += __shfl_xor(x, 4);
-    x += __shfl_xor(x, 2);
-    x += __shfl_xor(x, 1);
-    return x;
-}
+__device__ __forceinline__ double half_sum(double x) { return sum32(x); }
 
 // compiler-level ordering of one wave's LDS traffic (lanes of a half-wave exchange data through LDS without a barrier;
 // the hardware executes a wave's LDS instructions in order)

@@ -27,12 +27,8 @@ __device__ __forceinline__ int swz(int row, int col) { return row * NC + (col ^ 
 template <int LPC>
 __device__ __forceinline__ double hsum(double x)
 {
+    x = sum32(x);
     if (LPC == 64) x += __shfl_xor(x, 32);
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 8);
-    x += __shfl_xor(x, 4);
-    x += __shfl_xor(x, 2);
-    x += __shfl_xor(x, 1);
     return x;
 }
 
