@@ -230,12 +230,17 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             tx_[u] = k < K ? TH(B.o_x + k) : 0.0;
             tu_[u] = k < K ? TH(B.o_ups + k) : 0.0;
         }
+        // all exponentials of the lane in one straight-line block (tx = 0 beyond K): the polynomial's constants are then
+        // materialised once for the six evaluations instead of once per predicated block
+        double ex_[UKV];
+#pragma unroll
+        for (int u = 0; u < UKV; ++u) ex_[u] = exp(tx_[u]);
 #pragma unroll
         for (int u = 0; u < UKV; ++u) {
             const int k = l32 + LPC * u;
             double xr = 0.0;
             if (k < K) {
-                xr = B.is_pos ? exp(tx_[u]) : tx_[u];
+                xr = B.is_pos ? ex_[u] : tx_[u];
                 if (B.is_pos) lp += jac * tx_[u];
                 PW(B.o_x + k, xr);
             }
