@@ -123,6 +123,38 @@ class StanFit:
         a = self[name]
         return a.reshape((self.chains, self.n_draws) + a.shape[1:])
 
+    def to_saved(self):
+        """Plain-array snapshot for `Inverter.save_fit_data`: no GPU handle, loadable anywhere."""
+        data = {k: np.array(self[k]) for k in self.keys()}
+        data['lp__'] = np.array(self.lp)
+        return SavedFit(data, self.chains, self.n_draws, self.diagnostics, np.array(self.theta))
+
+
+class SavedFit(dict):
+    """HMC result restored from a file: the same `fit[name]` / `chain_draws` / diagnostics surface as StanFit, backed by
+    stored arrays only (what the reference keeps as a pickled pystan fit object, inversion.py:3990)."""
+
+    def __init__(self, data=(), chains=1, n_draws=0, diagnostics=(), theta=None):
+        super().__init__(data)
+        self.chains, self.n_draws = int(chains), int(n_draws)
+        self.diagnostics = list(diagnostics)
+        self.theta = theta
+        self.lp = self.get('lp__')
+        self.stepsize = [d['stepsize'] for d in self.diagnostics]
+        self.n_leapfrog = int(sum(d['n_leapfrog'] for d in self.diagnostics))
+        self.n_divergent = int(sum(d['n_divergent'] for d in self.diagnostics))
+        self.n_max_treedepth = int(sum(d['n_max_treedepth'] for d in self.diagnostics))
+
+    def chain_draws(self, name):
+        a = self[name]
+        return a.reshape((self.chains, self.n_draws) + a.shape[1:])
+
+    def to_saved(self):
+        return self
+
+    def __reduce__(self):
+        return (SavedFit, (dict(self), self.chains, self.n_draws, self.diagnostics, self.theta))
+
 
 class StanModel:
     """GPU-backed stand-in for the compiled pystan model `_get_stan_model` returns."""

@@ -90,6 +90,20 @@ class _QPBatcher(object):
                 self._flush()
 
 
+def _dist_equal(a, b):
+    """Equality of two distribution-info dicts with array values (the reference's utils.check_equality)."""
+    if set(a) != set(b):
+        return False
+    for k in a:
+        va, vb = a[k], b[k]
+        if isinstance(va, np.ndarray) or isinstance(vb, np.ndarray):
+            if not (np.shape(va) == np.shape(vb) and np.allclose(va, vb, equal_nan=True)):
+                return False
+        elif va != vb:
+            return False
+    return True
+
+
 class Inverter:
     def __init__(self, basis_freq=None, basis='gaussian', epsilon=None, fit_inductance=True,
                  distributions={'DRT': {'kernel': 'DRT'}}):
@@ -1094,34 +1108,60 @@ class Inverter:
         return np.argwhere(zs > threshold)
 
     # ================================================================== persistence (reference :3980-4064), arrays only
+    def get_fit_attributes(self, which='all'):
+        """Names of the attributes that make up a stored fit (same sets as the reference, :3980-4002)."""
+        fit_attributes = {
+            'common': {'core': ['distributions', 'distribution_fits', 'f_train', 'Z_train', '_Z_scale', 'fit_type', 'R_inf',
+                                'inductance'],
+                       'detail': ['distribution_matrices']},
+            'ridge': {'core': [], 'detail': ['_iter_history']},
+            'map': {'core': ['stan_model_name', 'error_fit'], 'detail': ['_stan_input', '_init_params', '_opt_result']},
+            'bayes': {'core': ['stan_model_name', '_sample_result', 'error_fit'], 'detail': ['_stan_input', '_init_params']},
+        }
+        if which == 'all':
+            return sum(fit_attributes['common'].values(), []) + sum(fit_attributes[self.fit_type].values(), [])
+        if which not in ('core', 'detail'):
+            raise ValueError("which must be 'core', 'detail' or 'all'")
+        return fit_attributes['common'][which] + fit_attributes[self.fit_type][which]
+
     def get_fit_data(self, which='all'):
-        core = ['distribution_fits', 'R_inf', 'inductance', 'fit_type', '_Z_scale', 'f_train', 'Z_train', 'stan_model_name',
-                'error_fit']
-        detail = ['_opt_result', '_init_params', '_iter_history', 'distribution_matrices', '_stan_input']
-        keys = core if which == 'core' else (detail if which == 'detail' else core + detail)
-        out = {k: deepcopy(getattr(self, k)) for k in keys if hasattr(self, k)}
-        out['distributions'] = deepcopy(self.distributions)
+        out = {}
+        for k in self.get_fit_attributes(which):
+            if not hasattr(self, k):
+                continue                                   # e.g. _init_params of a fit without ridge initialisation
+            v = getattr(self, k)
+            if k == '_sample_result':
+                v = v.to_saved()                           # plain arrays instead of a live GPU-backed fit object
+            elif k == '_iter_history':
+                v = [{kk: vv for kk, vv in h.items() if kk != 'result'} | {'fun': h.get('fun')} for h in v]
+            out[k] = deepcopy(v)
         return out
 
     def save_fit_data(self, filename=None, which='all'):
+        """Store the fit (reference :4004-4036): a pickled dict of plain numpy containers; returned when filename is None."""
         import pickle
         data = self.get_fit_data(which)
         if filename is None:
             return data
         with open(filename, 'wb') as f:
-            pickle.dump(data, f, pickle.HIGHEST_PROTOCOL)
+            pickle.dump(data, f, pickle.DEFAULT_PROTOCOL)
 
     def load_fit_data(self, data):
+        """Restore a stored fit (reference :4038-4064): file name or dict, as produced by `save_fit_data`."""
         import pickle
         if isinstance(data, str):
             with open(data, 'rb') as f:
                 data = pickle.load(f)
-        data = dict(data)
-        if 'distributions' in data:
-            self._distributions = data.pop('distributions')
-        for k, v in data.items():
-            setattr(self, k, v)
-        self._recalc_mat = False
+        f_pred_old = deepcopy(self.f_pred)
         self._cached_distributions = self.distributions.copy()
-        self.f_pred = None
+        for k, v in dict(data).items():
+            if k == '_sample_result' and not hasattr(v, 'chain_draws'):
+                from .engine import SavedFit
+                v = SavedFit(v)
+            setattr(self, k, v)
+        if 'distribution_matrices' not in data:
+            # the stored fit carries no matrices: prediction matrices can be kept only if the distributions are the same
+            same = set(self.distributions) == set(self._cached_distributions) and all(
+                _dist_equal(self.distributions[n], self._cached_distributions[n]) for n in self.distributions)
+            self.f_pred = f_pred_old if same else None
 

@@ -219,3 +219,45 @@ def test_config5_drt_ddt_outliers_K161():
     fit = inv._sample_result
     assert fit['xs'].shape == (40, 161) and fit['xp'].shape == (40, 161) and fit['sigma_out'].shape == (40, 162)
     assert np.all(np.isfinite(fit['Z_hat'])) and fit.n_leapfrog > 0
+
+
+def test_save_and_load_fit_data_round_trip(tmp_path):
+    """Persistence (reference :3980-4064): the stored fit is a pickled dict of plain arrays with the
+    reference's attribute sets; a fresh Inverter that loads it predicts the same numbers (ridge, MAP and HMC fits)."""
+    import pickle
+    from bayes_drt_amd.inversion import Inverter
+    from bayes_drt_amd.engine import SavedFit
+    f, Z, c = _spectrum()
+    inv = Inverter(basis_freq=f)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        inv.fit(f, Z, nonneg=True, mode='sample', warmup=60, samples=40, chains=2)
+    assert set(inv.get_fit_attributes('core')) == {'distributions', 'distribution_fits', 'f_train', 'Z_train', '_Z_scale',
+                                                    'fit_type', 'R_inf', 'inductance', 'stan_model_name', '_sample_result',
+                                                    'error_fit'}
+    path = str(tmp_path / 'fit.pkl')
+    inv.save_fit_data(path, which='core')
+    raw = pickle.load(open(path, 'rb'))
+    assert isinstance(raw['_sample_result'], SavedFit) and raw['_sample_result']['x'].shape == (80, 81)
+    new = Inverter(basis_freq=f)
+    new.load_fit_data(path)
+    assert new.fit_type == 'bayes'
+    for q in (None, 2.5, 97.5):
+        assert np.array_equal(new.predict_distribution('DRT', eval_tau=TAU_PLOT, percentile=q),
+                              inv.predict_distribution('DRT', eval_tau=TAU_PLOT, percentile=q))
+    assert np.array_equal(new.predict_Z(f, percentile=50), inv.predict_Z(f, percentile=50))
+    assert np.array_equal(new._sample_result.chain_draws('x'), inv._sample_result.chain_draws('x'))
+    assert new._sample_result.n_leapfrog == inv._sample_result.n_leapfrog
+    # MAP and ridge fits, dict instead of file, 'all' (with matrices)
+    inv.fit(f, Z, nonneg=True, mode='optimize')
+    d = inv.save_fit_data(which='all')
+    assert 'distribution_matrices' in d and '_opt_result' in d and '_stan_input' in d
+    new = Inverter(basis_freq=f); new.load_fit_data(d)
+    assert np.array_equal(new.predict_distribution('DRT', eval_tau=TAU_PLOT), inv.predict_distribution('DRT', eval_tau=TAU_PLOT))
+    s1, s2 = new.predict_sigma(f), inv.predict_sigma(f)
+    assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[1], s2[1])
+    inv.ridge_fit(f, Z)
+    d = pickle.loads(pickle.dumps(inv.save_fit_data(which='all')))
+    assert '_iter_history' in d and 'result' not in d['_iter_history'][0]
+    new = Inverter(basis_freq=f); new.load_fit_data(d)
+    assert np.array_equal(new.predict_Z(f), inv.predict_Z(f)) and new.fit_type == 'ridge'
