@@ -207,7 +207,7 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
         for (int b = 0; b < dat->nblocks; ++b) D.blk[b].toep = all ? 1 : 0;
         D.toep_all = all ? 1 : 0;
         // headline family on a log-uniform grid: half-wave-per-chain evaluator (bdrt_tile_s1.h)
-        D.fast_s1 = (all && dat->nblocks == 1 && !D.blk[0].is_parallel && D.outlier_mode == 0 && !D.use_x_sum &&
+        D.fast_s1 = (all && dat->nblocks == 1 && !D.blk[0].is_parallel && !D.use_x_sum &&
                      D.blk[0].x_scale == 1.0 && nf <= 32 * UN && D.blk[0].K <= 32 * UK &&
                      s1_lds_doubles(D) <= lds_doubles(D) && !getenv("BDRT_GENERIC_TILE")) ? 1 : 0;
     }

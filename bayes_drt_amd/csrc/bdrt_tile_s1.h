@@ -409,9 +409,18 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             const double wn = wn_[v];
             const double zr = Zh[swz(n, c)] + Rinf;
             const double zi = Zh[swz(nf + n, c)] + induc * wn;
+            // outlier error model (Series_*_outliers_modelcode.txt): 2 Nf extra parameters, read where they are needed
+            double so_re = 0.0, so_im = 0.0, r0 = 0.0, r1 = 0.0, t0 = 0.0, t1 = 0.0;
+            if (P.outlier_mode) {
+                t0 = TH(P.o_so + n); t1 = TH(P.o_so + nf + n);
+                r0 = exp(t0); r1 = exp(t1);
+                PW(P.o_so + n, r0); PW(P.o_so + nf + n, r1);
+                if (P.outlier_mode == 1) so_re = so_im = 0.05 * r0 * r1;
+                else { so_re = 0.05 * r0; so_im = 0.05 * r1; }
+            }
             const double common = ar2 * zr * zr + ai2 * zi * zi;
-            const double s2_re = c0 + ap2 * zr * zr + common;
-            const double s2_im = c0 + ap2 * zi * zi + common;
+            const double s2_re = c0 + ap2 * zr * zr + common + so_re * so_re;
+            const double s2_im = c0 + ap2 * zi * zi + common + so_im * so_im;
             const double e_re = zre_[v] - zr, e_im = zim_[v] - zi;
             const double prod = s2_re * s2_im, ip = 1.0 / prod;       // one reciprocal and one logarithm per (re, im) pair
             const double w_re = s2_im * ip, w_im = s2_re * ip;
@@ -428,6 +437,17 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             sHz2 += h_re * zr * zr + h_im * zi * zi;
             sHzr2 += (h_re + h_im) * zr * zr;
             sHzi2 += (h_re + h_im) * zi * zi;
+            if (P.outlier_mode == 1) {
+                // sigma_out = raw .* scale * 0.05 ; raw ~ exponential(lambda) ; scale ~ inv_gamma(alpha, beta)
+                const double dso = 2.0 * so_re * (h_re + h_im);
+                GW(P.o_so + n, r0 * (0.05 * r1 * dso - P.so_lambda) + jac);
+                GW(P.o_so + nf + n, 0.05 * r0 * r1 * dso - (P.so_alpha + 1.0) + P.so_beta / r1 + jac);
+                lp += -P.so_lambda * r0 - (P.so_alpha + 1.0) * t1 - P.so_beta / r1 + jac * (t0 + t1);
+            } else if (P.outlier_mode == 2) {
+                GW(P.o_so + n, r0 * (0.05 * 2.0 * so_re * h_re - P.so_lambda) + jac);
+                GW(P.o_so + nf + n, r1 * (0.05 * 2.0 * so_im * h_im - P.so_lambda) + jac);
+                lp += -P.so_lambda * (r0 + r1) + jac * (t0 + t1);
+            }
             if (io.Z_hat && valid) { io.Z_hat[(size_t)c * N2 + n] = zr; io.Z_hat[(size_t)c * N2 + nf + n] = zi; }
             if (io.sigma_tot && valid) {
                 io.sigma_tot[(size_t)c * N2 + n] = sqrt(s2_re);

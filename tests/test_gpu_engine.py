@@ -205,7 +205,7 @@ def test_batched_optimize_equals_single_fits():
         assert np.array_equal(one[0], both[i]) and r1[0]['iterations'] == rb[i]['iterations']
 
 
-@pytest.mark.parametrize('family', ['series_outliers_K161', 'series_parallel_2block'])
+@pytest.mark.parametrize('family', ['series_outliers_K161', 'series_parallel_2block', 'series_K192_Nf96'])
 def test_nuts_matches_oracle_on_the_wide_parameter_vectors(family):
     """The sampler kernels for 352 < D <= 512 and D > 512 (outlier error model: D = 493; two blocks of 161: D = 656) against the
     recursive oracle: identical tree shapes, draws equal to summation-order noise (short runs)."""
@@ -218,6 +218,10 @@ def test_nuts_matches_oracle_on_the_wide_parameter_vectors(family):
         so = load('dat_sample_outlier_scalars')
         kw = dict(kw, outlier_mode=1, so_lambda=float(so['sigma_out_lambda']), so_alpha=float(so['sigma_out_alpha']),
                   so_beta=float(so['sigma_out_beta']))
+        args = dict(blocks=[blk], Z=Z, freq=f, **kw)
+    elif family == 'series_K192_Nf96':          # largest problem of the S1 evaluator: sampler state in HBM (D = 393)
+        from tests.test_gpu_edges import _problem
+        blk, Z, f, kw = _problem(96, 192)
         args = dict(blocks=[blk], Z=Z, freq=f, **kw)
     else:
         from bayes_drt_amd.engine import blocks_from_dat

@@ -183,3 +183,32 @@ def test_fast_s1_tile_equals_generic_tile(monkeypatch, jacobian):
     for a, b in zip(tr_f, tr_g):
         assert np.max(np.abs(a - b)) <= 1e-12 * max(1.0, np.max(np.abs(b)))
     assert not np.array_equal(g_f, g_g)          # really two different code paths
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', [1, 2])
+def test_fast_s1_tile_with_outlier_parameters_equals_generic_tile(monkeypatch, mode):
+    """Series / Series_pos with the outlier error model (package form: raw[Nf], scale[Nf]; paper form: raw[2Nf]) also takes
+    the half-wave evaluator; same function as the generic block evaluator and as the oracle."""
+    Problem, orc = _mods()
+    d, blk, kw = _bench_blocks('sample', 'K161')
+    so = load('dat_sample_outlier_scalars')
+    kw = dict(kw, outlier_mode=mode, so_lambda=float(so['sigma_out_lambda']), so_alpha=float(so['sigma_out_alpha']),
+              so_beta=float(so['sigma_out_beta']))
+    rng = np.random.default_rng(40 + mode)
+    fast = Problem([blk], d['Z'], d['freq'], **kw)
+    thetas = rng.uniform(-1.5, 1.5, (21, fast.D))
+    assert fast.D == 331 + 162
+    lp_f, g_f = fast.logp_grad(thetas, jacobian=True)
+    tr_f = fast.transformed(thetas)
+    om = orc.OracleModel([blk], d['Z'], d['freq'], **kw)
+    _compare(fast, om, thetas[:6], True)
+    monkeypatch.setenv('BDRT_GENERIC_TILE', '1')
+    gen = Problem([blk], d['Z'], d['freq'], **kw)
+    lp_g, g_g = gen.logp_grad(thetas, jacobian=True)
+    tr_g = gen.transformed(thetas)
+    assert np.max(np.abs(lp_f - lp_g) / np.maximum(1.0, np.abs(lp_g))) < 1e-12
+    assert np.max(np.abs(g_f - g_g)) < 1e-11 * max(1.0, np.max(np.abs(g_g)))
+    for a, b in zip(tr_f, tr_g):
+        assert np.max(np.abs(a - b)) <= 1e-12 * max(1.0, np.max(np.abs(b)))
+    assert not np.array_equal(g_f, g_g)
