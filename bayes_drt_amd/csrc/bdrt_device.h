@@ -58,7 +58,8 @@ struct DevProblem {
     int XR, ZR, LR, npar;     // LDS row counts
     int toep_all;             // every block takes the structured (banded Toeplitz) L path
     int w3;                   // structured path: Lr holds all three w_i buffers (else one buffer, i after i: +4 barriers per block)
-    int fast_s1;              // single series block, no outlier parameters, structured: bdrt_tile_s1.h evaluates it
+    int fast_s1;              // single series block, structured: bdrt_tile_s1.h evaluates it
+    int fast_hw;              // any other family on log-uniform grids that fits: bdrt_tile_hw.h evaluates it
     int XCR;                  // rows of the x cache (0: exp(theta_x) is recomputed where needed)
     int xc_off[MAXB];         // first cache row of each block
     int dbg;                  // timing ablation only (env BDRT_DEBUG_SKIP): 1 skip forward GEMMs, 2 skip backward GEMM

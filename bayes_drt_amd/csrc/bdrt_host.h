@@ -10,6 +10,7 @@
 #include "../../include/bdrt.h"
 #include "bdrt_device.h"
 #include "bdrt_tile_s1.h"
+#include "bdrt_tile_hw.h"
 
 namespace bdrt {
 

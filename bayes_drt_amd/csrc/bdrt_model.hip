@@ -210,13 +210,18 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
         D.fast_s1 = (all && dat->nblocks == 1 && !D.blk[0].is_parallel && !D.use_x_sum &&
                      D.blk[0].x_scale == 1.0 && nf <= 32 * UN && D.blk[0].K <= 32 * UK &&
                      s1_lds_doubles(D) <= lds_doubles(D) && !getenv("BDRT_GENERIC_TILE")) ? 1 : 0;
+        // every other family (several distributions, parallel blocks, x_sum prior): the general half-wave evaluator
+        bool hw = all && !D.fast_s1 && nf <= 32 * UN && !getenv("BDRT_GENERIC_TILE") &&
+                  (hw_lds_doubles(D) + 64) * sizeof(double) + 4096 <= 160 * 1024;
+        for (int b = 0; b < dat->nblocks; ++b) hw = hw && D.blk[b].K <= 32 * UK;
+        D.fast_hw = hw ? 1 : 0;
     }
     if (getenv("BDRT_VERBOSE"))
-        fprintf(stderr, "bdrt_problem_create: nf=%d blocks=%d D=%d structured_L=%d (per block %d %d %d) fast_s1=%d LDS rows X=%d Z=%d x%d L=%d XC=%d -> %zu B\n",
+        fprintf(stderr, "bdrt_problem_create: nf=%d blocks=%d D=%d structured_L=%d (per block %d %d %d) fast_s1=%d fast_hw=%d LDS rows X=%d Z=%d x%d L=%d XC=%d -> %zu B\n",
                 nf, dat->nblocks, D.D, D.toep_all, toep_ok[0], dat->nblocks > 1 ? toep_ok[1] : -1, dat->nblocks > 2 ? toep_ok[2] : -1,
-                D.fast_s1, D.XR, D.ZR, 1 + D.npar, D.LR, D.XCR, lds_doubles(D) * sizeof(double));
+                D.fast_s1, D.fast_hw, D.XR, D.ZR, 1 + D.npar, D.LR, D.XCR, lds_doubles(D) * sizeof(double));
     if (const char *e = getenv("BDRT_DEBUG_SKIP")) D.dbg = atoi(e);
-    P.lds_bytes = lds_doubles(D) * sizeof(double);
+    P.lds_bytes = std::max(lds_doubles(D), D.fast_hw ? hw_lds_doubles(D) : (size_t)0) * sizeof(double);
     if (P.lds_bytes > 160 * 1024) {
         set_error("bdrt_problem_create: problem needs %zu B of LDS per workgroup (> 160 KiB): nf=%d, K too large",
                   P.lds_bytes, nf);
@@ -267,7 +272,8 @@ __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restr
     io.sigma_tot = sig ? sig + (size_t)c0 * 2 * P.nf : nullptr;
     io.params = params ? params + (size_t)c0 * P.D : nullptr;
     io.prof = nullptr;
-    if (MODE == 2) logp_grad_tile_s1<false>(P, io, smem);
+    if (MODE == 3) logp_grad_tile_hw(P, io, smem);
+    else if (MODE == 2) logp_grad_tile_s1<false>(P, io, smem);
     else if (MODE == 1) logp_grad_tile<true>(P, io, smem);
     else logp_grad_tile<false>(P, io, smem);
 }
@@ -310,12 +316,17 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
                                      (int)p->lds_bytes));
         BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)p->lds_bytes));
+        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)p->lds_bytes));
         attr_bytes = p->lds_bytes;
     }
     const int grid = cdiv(B, NC);
     static const bool wide = getenv("BDRT_S1_WIDE") != nullptr;
     if (p->dev.fast_s1 && wide && p->dev.nf <= 128)
         hipLaunchKernelGGL(logp_grad_kernel_wide, dim3(grid), dim3(1024), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
+                           d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
+    else if (p->dev.fast_hw)
+        hipLaunchKernelGGL(logp_grad_kernel<3>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
                            d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
     else if (p->dev.fast_s1)
         hipLaunchKernelGGL(logp_grad_kernel<2>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,

@@ -66,7 +66,7 @@ struct NutsArgs {
 // NJ = elements of a D-vector per lane (D <= 32*NJ): compile-time so that every pass over a chain's vectors is fully
 // unrolled into a batch of independent loads followed by the arithmetic (one memory round trip per stage instead of one
 // per element -- the state vectors of 2048+ chains live in HBM/MALL, not in L2).
-template <int NJ, int MODE>   // MODE 0: dense L, 1: structured L (generic tile), 2: S1 tile + theta rows in LDS, 3: S1 tile, state in HBM
+template <int NJ, int MODE>   // MODE 0: dense L, 1: structured L (generic tile), 2: S1 tile + theta rows in LDS, 3: S1 tile, state in HBM, 4: general half-wave tile
 __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     const bool valid = c < nvalid;
 
     // LDS carve-up: [tile region | (fast S1 path: theta rows of the 16 chains) | lp of the 16 chains | chain states | spectrum ids]
-    const size_t tile_doubles = MODE >= 2 ? s1_lds_doubles(P) : lds_doubles(P);
+    const size_t tile_doubles = MODE == 4 ? hw_lds_doubles(P) : (MODE >= 2 ? s1_lds_doubles(P) : lds_doubles(P));
     constexpr int DSL = 32 * NJ;                    // LDS row stride of the theta rows
     double *thl = smem + tile_doubles;
     double *lpn = thl + (MODE == 2 ? (size_t)NC * DSL : 0);
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         };
         if (MODE == 2) { logp_grad_tile_s1<true>(P, io, smem); load_state(); }
         else if (MODE == 3) { logp_grad_tile_s1<false>(P, io, smem); load_state(); }
+        else if (MODE == 4) { logp_grad_tile_hw(P, io, smem); load_state(); }
         else { logp_grad_tile<MODE == 1>(P, io, smem); load_state(); }
         if (io.prof && tid == 0) tnp = clock64();
         BDRT_WAVE_PROF(17);
@@ -971,6 +972,7 @@ struct Sampler {
     size_t lds_bytes = 0;
     bool use_s1 = false;     // S1 evaluator with theta rows resident in LDS (MODE 2)
     bool s1_hbm = false;     // S1 evaluator, sampler state in HBM (MODE 3: outlier parameters, K near 192)
+    bool hw = false;         // general half-wave evaluator (MODE 4: several distributions, parallel blocks)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double ms_total = 0.0;
@@ -1047,8 +1049,12 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     S.use_s1 = P.dev.fast_s1 && P.dev.outlier_mode == 0 && P.dev.D <= 2 * RW && P.dev.D <= 32 * 16 &&
                nuts_lds_bytes(P.dev, true) <= 160 * 1024;
     S.s1_hbm = !S.use_s1 && P.dev.fast_s1 && P.dev.D <= 32 * 16;
-    S.lds_bytes = S.s1_hbm ? (s1_lds_doubles(P.dev) + (size_t)NC) * sizeof(double) + NC * sizeof(ChainState) + NC * sizeof(int) + 16
-                           : nuts_lds_bytes(P.dev, S.use_s1);
+    S.hw = P.dev.fast_hw && P.dev.D <= 32 * 27;
+    if (S.s1_hbm || S.hw)
+        S.lds_bytes = ((S.hw ? hw_lds_doubles(P.dev) : s1_lds_doubles(P.dev)) + (size_t)NC) * sizeof(double) + NC * sizeof(ChainState) +
+                      NC * sizeof(int) + 16;
+    else
+        S.lds_bytes = nuts_lds_bytes(P.dev, S.use_s1);
     auto fail = [&](const char *msg) -> bdrt_sampler * { set_error("%s", msg); bdrt_sampler_destroy(s); return nullptr; };
     if (S.lds_bytes > 160 * 1024) return fail("bdrt_sampler_create: problem too large for the 160 KiB LDS budget");
     for (int u = 0; u < n_units; ++u)
@@ -1112,6 +1118,9 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
                                (const void *)nuts_kernel<27, 1>, (const void *)nuts_kernel<27, 0>,
                                (const void *)nuts_kernel<11, 2>, (const void *)nuts_kernel<16, 2>,
                                (const void *)nuts_kernel<11, 3>, (const void *)nuts_kernel<16, 3>};
+        const void *fns4[3] = {(const void *)nuts_kernel<11, 4>, (const void *)nuts_kernel<16, 4>, (const void *)nuts_kernel<27, 4>};
+        for (int i = 0; i < 3 && e == hipSuccess; ++i)
+            e = hipFuncSetAttribute(fns4[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         for (int i = 0; i < 10 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         if (e != hipSuccess) {
@@ -1166,6 +1175,12 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             hipLaunchKernelGGL((nuts_kernel<11, 3>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
         else if (S.s1_hbm)
             hipLaunchKernelGGL((nuts_kernel<16, 3>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
+        else if (S.hw && S.D <= 32 * 11)
+            hipLaunchKernelGGL((nuts_kernel<11, 4>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
+        else if (S.hw && S.D <= 32 * 16)
+            hipLaunchKernelGGL((nuts_kernel<16, 4>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
+        else if (S.hw)
+            hipLaunchKernelGGL((nuts_kernel<27, 4>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
         else if (S.D <= 32 * 11) BDRT_LAUNCH_NUTS(11);
         else if (S.D <= 32 * 16) BDRT_LAUNCH_NUTS(16);
         else BDRT_LAUNCH_NUTS(27);
