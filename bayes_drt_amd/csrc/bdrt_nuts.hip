@@ -358,9 +358,33 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             if constexpr (CHUNKED) {
                 // running sum of the merged sub-subtree in the V_RHOC row (level 0 merges read the momentum row itself)
                 double *RC = row(V_RHOC);
-                for (int l = 0; l < nm; ++l) {
-                    const double *RL = l == 0 ? row(V_CKP) : row(V_CKC + l), *PL = row(V_CKP + l);
-                    const double *RCs = l == 0 ? Pm : RC;
+                if (nm > 0) {
+                    // level 0: the waiting sibling is a single leaf (rho = its momentum) and the running sum is this leaf's
+                    // momentum: three rows instead of five
+                    const double *PL = row(V_CKP);
+                    double a0 = 0.0, a1 = 0.0;
+#pragma unroll 1
+                    for (int mb = 0; mb < NJ; mb += MB) {
+                        double lp_[MB], pp_[MB], mm_[MB];
+#pragma unroll
+                        for (int mm = 0; mm < MB; ++mm) { const int j = l32 + 32 * (mb + mm); lp_[mm] = PL[j]; pp_[mm] = Pm[j]; mm_[mm] = MI[j]; }
+#pragma unroll
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            if (j < D) {
+                                const double rho = lp_[mm] + pp_[mm];
+                                a0 += mm_[mm] * lp_[mm] * rho;
+                                a1 += mm_[mm] * pp_[mm] * rho;
+                                RC[j] = rho;
+                            }
+                        }
+                    }
+                    a0 = half_sum(a0); a1 = half_sum(a1);
+                    ok = ok && (a0 > 0.0) && (a1 > 0.0);
+                }
+                for (int l = 1; l < nm; ++l) {
+                    const double *RL = row(V_CKC + l), *PL = row(V_CKP + l);
+                    const double *RCs = RC;
                     double a0 = 0.0, a1 = 0.0;
 #pragma unroll 1
                     for (int mb = 0; mb < NJ; mb += MB) {

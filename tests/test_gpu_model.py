@@ -212,3 +212,30 @@ def test_fast_s1_tile_with_outlier_parameters_equals_generic_tile(monkeypatch, m
     for a, b in zip(tr_f, tr_g):
         assert np.max(np.abs(a - b)) <= 1e-12 * max(1.0, np.max(np.abs(b)))
     assert not np.array_equal(g_f, g_g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['DRT-2-TpDDT_uniform_0.25', 'DRT-TpDDT-BpDDT_uniform_0.25', 'PDAC_DRT-TpDDT_outliers'])
+def test_general_half_wave_tile_equals_generic_tile(monkeypatch, name):
+    """Several distributions / parallel blocks / x_sum prior / outlier parameters: the general half-wave evaluator
+    (bdrt_tile_hw.h) and the generic block evaluator (BDRT_GENERIC_TILE=1) are the same function."""
+    Problem, orc = _mods()
+    k = kat_to_model(name)
+    rng = np.random.default_rng(77)
+    fast = Problem(**k['kw'])
+    th0 = fast.unconstrain(k['params'])
+    thetas = th0[None] + 0.3 * rng.standard_normal((19, fast.D))
+    lp_f, g_f = fast.logp_grad(thetas, jacobian=True)
+    tr_f = fast.transformed(thetas)
+    monkeypatch.setenv('BDRT_GENERIC_TILE', '1')
+    gen = Problem(**k['kw'])
+    lp_g, g_g = gen.logp_grad(thetas, jacobian=True)
+    tr_g = gen.transformed(thetas)
+    fin = np.isfinite(lp_g)
+    assert np.array_equal(fin, np.isfinite(lp_f)) and fin.sum() >= 10
+    assert np.max(np.abs(lp_f[fin] - lp_g[fin]) / np.maximum(1.0, np.abs(lp_g[fin]))) < 1e-12
+    assert np.max(np.abs(g_f[fin] - g_g[fin])) < 1e-11 * max(1.0, np.max(np.abs(g_g[fin])))
+    for a, b in zip(tr_f, tr_g):
+        assert np.max(np.abs(a[fin] - b[fin])) <= 1e-12 * max(1.0, np.max(np.abs(b[fin])))
+    if 'PDAC' not in name:                       # (the experimental PDAC grid is not log-uniform: generic evaluator either way)
+        assert not np.array_equal(g_f, g_g)      # really two different code paths
