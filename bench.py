@@ -101,8 +101,8 @@ print(n, time.perf_counter() - t0)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000)
-    ap.add_argument('--warmup', type=int, default=500)
+    ap.add_argument('--steps', type=int, default=20000)
+    ap.add_argument('--warmup', type=int, default=2000)
     ap.add_argument('--spectra', type=int, default=N_SPECTRA)
     ap.add_argument('--chains', type=int, default=CHAINS_PER_SPECTRUM)
     ap.add_argument('--no-cpu-baseline', action='store_true')
