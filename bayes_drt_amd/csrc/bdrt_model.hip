@@ -208,10 +208,10 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
         D.toep_all = all ? 1 : 0;
         // headline family on a log-uniform grid: half-wave-per-chain evaluator (bdrt_tile_s1.h)
         D.fast_s1 = (all && dat->nblocks == 1 && !D.blk[0].is_parallel && !D.use_x_sum &&
-                     D.blk[0].x_scale == 1.0 && nf <= 32 * UN && D.blk[0].K <= 32 * UK &&
+                     D.blk[0].x_scale == 1.0 && nf <= 128 && D.blk[0].K <= 32 * UK &&
                      s1_lds_doubles(D) <= lds_doubles(D) && !getenv("BDRT_GENERIC_TILE")) ? 1 : 0;
         // every other family (several distributions, parallel blocks, x_sum prior): the general half-wave evaluator
-        bool hw = all && !D.fast_s1 && nf <= 32 * UN && !getenv("BDRT_GENERIC_TILE") &&
+        bool hw = all && !D.fast_s1 && nf <= 128 && !getenv("BDRT_GENERIC_TILE") &&
                   (hw_lds_doubles(D) + 64) * sizeof(double) + 4096 <= 160 * 1024;
         for (int b = 0; b < dat->nblocks; ++b) hw = hw && D.blk[b].K <= 32 * UK;
         D.fast_hw = hw ? 1 : 0;

@@ -26,7 +26,7 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
 {
     int tid = threadIdx.x;
     __asm__ volatile("" : "+v"(tid));                      // see bdrt_tile_s1.h: keeps index arithmetic out of the caller's loop
-    constexpr int LPC = 32, UKV = 6, UNV = 3, WINV = UKV + NTAP - 1, NWV = 8, GPFV = 7;
+    constexpr int LPC = 32, UKV = 6, UNV = 4, WINV = UKV + NTAP - 1, NWV = 8, GPFV = 7;      // K <= 192, Nf <= 128
     const int lane = tid & 63, wave = tid >> 6;
     const int c = tid / LPC;
     const int l32 = tid % LPC, hb = lane & 32;

@@ -180,7 +180,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     __asm__ volatile("" : "+v"(tid));
     // LPC lanes own one chain: 32 (half-wave, 512 threads, 2 waves per SIMD) or 64 (wave, 1024 threads, 4 waves per SIMD,
     // half the per-lane work and registers)
-    constexpr int UKV = 192 / LPC, UNV = LPC == 32 ? 3 : 2, WINV = UKV + NTAP - 1, NWV = 16 * LPC / 64;
+    constexpr int UKV = 192 / LPC, UNV = 128 / LPC, WINV = UKV + NTAP - 1, NWV = 16 * LPC / 64;     // K <= 192, Nf <= 128
     constexpr int GPFV = LPC == 32 ? 7 : 3;
     const int lane = tid & 63, wave = tid >> 6;
     const int c = tid / LPC;                               // chain owned by this group of LPC lanes

@@ -1,5 +1,5 @@
 """GPU tests (-m gpu): edges of the evaluator's domain -- empty and ragged batches, the largest problem the fast S1 evaluator
-takes (K = 192, Nf = 96), the first size beyond it (generic evaluator), a problem that does not fit the 160 KiB LDS budget
+takes (K = 192, Nf = 128), the first size beyond it (generic evaluator), a problem that does not fit the 160 KiB LDS budget
 (loud error, no fallback), extreme parameter values (overflow -> non-finite lp, never a crash)."""
 import numpy as np
 import pytest
@@ -41,14 +41,15 @@ def _check_vs_oracle(nf, K, n_pts, expect_fast):
     return prob
 
 
-def test_largest_fast_path_problem_K192_Nf96():
-    prob = _check_vs_oracle(96, 192, 21, True)
+def test_largest_fast_path_problem_K192_Nf128():
+    prob = _check_vs_oracle(128, 192, 21, True)
     assert prob.D == 2 * 192 + 9
+    _check_vs_oracle(107, 161, 9, True)            # the length of the reference's experimental spectra (LIB: 107, PDAC: 106)
 
 
 def test_first_size_beyond_the_fast_path_uses_the_generic_evaluator():
     _check_vs_oracle(81, 200, 5, False)
-    _check_vs_oracle(100, 120, 5, False)          # Nf > 96: generic evaluator as well
+    _check_vs_oracle(130, 120, 5, False)          # Nf > 128: generic evaluator as well
 
 
 def test_problem_beyond_the_lds_budget_fails_loudly():

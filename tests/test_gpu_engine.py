@@ -205,7 +205,7 @@ def test_batched_optimize_equals_single_fits():
         assert np.array_equal(one[0], both[i]) and r1[0]['iterations'] == rb[i]['iterations']
 
 
-@pytest.mark.parametrize('family', ['series_outliers_K161', 'series_parallel_2block', 'series_K192_Nf96'])
+@pytest.mark.parametrize('family', ['series_outliers_K161', 'series_parallel_2block', 'series_K192_Nf96', 'series_K161_Nf107'])
 def test_nuts_matches_oracle_on_the_wide_parameter_vectors(family):
     """The sampler kernels for 352 < D <= 512 and D > 512 (outlier error model: D = 493; two blocks of 161: D = 656) against the
     recursive oracle: identical tree shapes, draws equal to summation-order noise (short runs)."""
@@ -219,6 +219,10 @@ def test_nuts_matches_oracle_on_the_wide_parameter_vectors(family):
         kw = dict(kw, outlier_mode=1, so_lambda=float(so['sigma_out_lambda']), so_alpha=float(so['sigma_out_alpha']),
                   so_beta=float(so['sigma_out_beta']))
         args = dict(blocks=[blk], Z=Z, freq=f, **kw)
+    elif family == 'series_K161_Nf107':         # 107 frequencies: the fourth frequency slot per lane, theta rows in LDS
+        from tests.test_gpu_edges import _problem
+        blk, Z, f, kw = _problem(107, 161)
+        args = dict(blocks=[blk], Z=Z, freq=f, **kw)
     elif family == 'series_K192_Nf96':          # largest problem of the S1 evaluator: sampler state in HBM (D = 393)
         from tests.test_gpu_edges import _problem
         blk, Z, f, kw = _problem(96, 192)
@@ -230,7 +234,7 @@ def test_nuts_matches_oracle_on_the_wide_parameter_vectors(family):
         args = dict(blocks=blocks, Z=dd['Z'], freq=dd['freq'], **kw2)
     prob = Problem(**args)
     om = orc.OracleModel(**args)
-    assert prob.D > 352
+    assert prob.D > 352 or family == 'series_K161_Nf107'
     warm, nd, n_units = 6, 4, 3
     ctrl = _ctrl(prob._lib, max_treedepth=5)
     draws, lp, diag = sample_units(prob, n_units, warm, nd, 99, ctrl)
