@@ -67,7 +67,7 @@ SYMBOLS = [
     'bdrt_sampler_phase_profile',
     'bdrt_sample',
     'bdrt_gram', 'bdrt_qp_box', 'bdrt_qp_box_batch',
-    'bdrt_percentiles', 'bdrt_sampler_percentiles',
+    'bdrt_percentiles', 'bdrt_sampler_percentiles', 'bdrt_sampler_summary', 'bdrt_summary', 'bdrt_sampler_draws_dev',
     'bdrt_last_error', 'bdrt_device_count', 'bdrt_set_device', 'bdrt_version',
 ]
 
@@ -127,6 +127,10 @@ def load_library():
     lib.bdrt_qp_box_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     lib.bdrt_percentiles.argtypes = [vp, C.c_int, C.c_int, C.c_long, vp, C.c_int, vp, vp, C.c_int, vp]
     lib.bdrt_sampler_percentiles.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
+    lib.bdrt_sampler_summary.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]
+    lib.bdrt_summary.argtypes = [vp, C.c_int, C.c_int, C.c_long, vp, vp, C.c_int, vp, vp]
+    lib.bdrt_sampler_draws_dev.argtypes = [vp]
+    lib.bdrt_sampler_draws_dev.restype = vp
     lib.bdrt_set_device.argtypes = [C.c_int]
     _LIB = lib
     return lib

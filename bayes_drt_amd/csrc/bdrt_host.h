@@ -2,8 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,6 +26,34 @@ void set_error(const char *fmt, ...);
             return -10;                                                                             \
         }                                                                                           \
     } while (0)
+
+// The HIP current device is per host thread.  bdrt_set_device records the process-wide device; entry points that take no
+// handle (bdrt_build_*, bdrt_gram, bdrt_qp_box_batch, bdrt_percentiles) bind the calling thread to it, entry points that
+// take a problem / sampler bind to the device the problem was created on.
+extern std::atomic<int> g_process_device;
+inline void bind_process_device()
+{
+    const int d = g_process_device.load(std::memory_order_relaxed);
+    if (d >= 0) hipSetDevice(d);
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: high-water mark per device id, guarded by a mutex.
+struct LdsAttrCache {
+    std::mutex mu;
+    size_t hw[64] = {};
+    template <class F>
+    hipError_t ensure(size_t bytes, F set_attrs)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> g(mu);
+        if (dev >= 0 && dev < 64 && bytes <= hw[dev]) return hipSuccess;
+        e = set_attrs();
+        if (e == hipSuccess && dev >= 0 && dev < 64) hw[dev] = bytes;
+        return e;
+    }
+};
 
 struct Problem {
     DevProblem dev;                 // device view (pointers are device pointers), host copy
@@ -50,8 +80,10 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
                      double *d_grad, double *d_params, double *d_Zhat, double *d_sig, hipStream_t stream);
 
 // percentiles of X Phi^T + bias (Phi == nullptr: of X itself) over the rows of a DEVICE matrix X; Phi, bias, q, out: host
+// expcol[K] (host, Phi == nullptr only): columns whose samples are exp(X); mean[ncols] (host): sample means; both optional
 int post_percentiles_device(const double *dX, int rows, int K, long ldx, const double *Phi, int M, const double *bias,
-                            const double *q, int nq, double *out);
+                            const double *q, int nq, double *out, const unsigned char *expcol = nullptr,
+                            double *mean = nullptr);
 
 }  // namespace bdrt
 

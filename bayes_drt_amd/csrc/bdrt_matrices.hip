@@ -167,6 +167,7 @@ int bdrt_build_A(const double *freq, int nf, const double *tau, int k, double ep
         set_error("bdrt_build_A: bad arguments");
         return -1;
     }
+    bind_process_device();
     DevBuf dF, dT, dV, dO;
     int rc;
     if ((rc = dF.alloc(nf * sizeof(double))) || (rc = dT.alloc(k * sizeof(double)))) return rc;
@@ -198,6 +199,7 @@ int bdrt_build_A(const double *freq, int nf, const double *tau, int k, double ep
 int bdrt_build_L(const double *tau, int k, double eps, const double *coef4, double *out)
 {
     if (!tau || !coef4 || !out || k <= 0) { set_error("bdrt_build_L: bad arguments"); return -1; }
+    bind_process_device();
     DevBuf dT, dO;
     int rc;
     if ((rc = dT.alloc(k * sizeof(double))) || (rc = dO.alloc((size_t)k * k * sizeof(double)))) return rc;
@@ -212,6 +214,7 @@ int bdrt_build_L(const double *tau, int k, double eps, const double *coef4, doub
 int bdrt_build_M(const double *tau, int k, double eps, const double *coef3, int toeplitz, double *out)
 {
     if (!tau || !coef3 || !out || k <= 0) { set_error("bdrt_build_M: bad arguments"); return -1; }
+    bind_process_device();
     DevBuf dT, dO;
     int rc;
     if ((rc = dT.alloc(k * sizeof(double))) || (rc = dO.alloc((size_t)k * k * sizeof(double)))) return rc;

@@ -13,6 +13,7 @@
 namespace bdrt {
 
 static thread_local std::string g_last_error;
+std::atomic<int> g_process_device{-1};
 
 void set_error(const char *fmt, ...)
 {
@@ -80,6 +81,7 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
         set_error("bdrt_problem_create: Z/freq missing or n_spectra < 1");
         return -1;
     }
+    bind_process_device();
     BDRT_HIP(hipGetDevice(&P.device));
     DevProblem &D = P.dev;
     memset(&D, 0, sizeof(D));
@@ -306,20 +308,16 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
                      double *d_grad, double *d_params, double *d_Zhat, double *d_sig, hipStream_t stream)
 {
     if (B <= 0) return 0;
-    static size_t attr_bytes = 0;
-    if (p->lds_bytes > attr_bytes) {
-        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)p->lds_bytes));
-        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)p->lds_bytes));
-        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)p->lds_bytes));
-        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)p->lds_bytes));
-        BDRT_HIP(hipFuncSetAttribute((const void *)logp_grad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)p->lds_bytes));
-        attr_bytes = p->lds_bytes;
-    }
+    BDRT_HIP(hipSetDevice(p->device));
+    static LdsAttrCache attr_cache;
+    BDRT_HIP(attr_cache.ensure(p->lds_bytes, [&]() {
+        const void *fns[5] = {(const void *)logp_grad_kernel<0>, (const void *)logp_grad_kernel<1>, (const void *)logp_grad_kernel<2>,
+                              (const void *)logp_grad_kernel_wide, (const void *)logp_grad_kernel<3>};
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < 5 && e == hipSuccess; ++i)
+            e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
+        return e;
+    }));
     const int grid = cdiv(B, NC);
     static const bool wide = getenv("BDRT_S1_WIDE") != nullptr;
     if (p->dev.fast_s1 && wide && p->dev.nf <= 128)
@@ -360,6 +358,7 @@ int bdrt_device_count(void)
 int bdrt_set_device(int dev)
 {
     BDRT_HIP(hipSetDevice(dev));
+    g_process_device.store(dev);
     return 0;
 }
 

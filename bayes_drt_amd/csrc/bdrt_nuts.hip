@@ -1057,6 +1057,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     if (ctrl) c = *ctrl; else bdrt_nuts_defaults(&c);
     if (c.max_treedepth < 1 || c.max_treedepth > MAXD) { set_error("max_treedepth must be in [1,%d]", MAXD); return nullptr; }
     Problem &P = p->impl;
+    if (hipSetDevice(P.device) != hipSuccess) { set_error("bdrt_sampler_create: hipSetDevice(%d) failed", P.device); return nullptr; }
     bdrt_sampler *s = new bdrt_sampler();
     Sampler &S = s->impl;
     memset(&S.args, 0, sizeof(S.args));
@@ -1134,25 +1135,23 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     S.args.done_counter = S.d_done;
     S.args.n_units = n_units;
     if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
-    static size_t attr_bytes = 0;
-    if (S.lds_bytes > attr_bytes) {
-        hipError_t e = hipSuccess;
-        const void *fns[10] = {(const void *)nuts_kernel<11, 1>, (const void *)nuts_kernel<11, 0>,
+    static LdsAttrCache attr_cache;
+    const hipError_t ae = attr_cache.ensure(S.lds_bytes, [&]() {
+        const void *fns[13] = {(const void *)nuts_kernel<11, 1>, (const void *)nuts_kernel<11, 0>,
                                (const void *)nuts_kernel<16, 1>, (const void *)nuts_kernel<16, 0>,
                                (const void *)nuts_kernel<27, 1>, (const void *)nuts_kernel<27, 0>,
                                (const void *)nuts_kernel<11, 2>, (const void *)nuts_kernel<16, 2>,
-                               (const void *)nuts_kernel<11, 3>, (const void *)nuts_kernel<16, 3>};
-        const void *fns4[3] = {(const void *)nuts_kernel<11, 4>, (const void *)nuts_kernel<16, 4>, (const void *)nuts_kernel<27, 4>};
-        for (int i = 0; i < 3 && e == hipSuccess; ++i)
-            e = hipFuncSetAttribute(fns4[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
-        for (int i = 0; i < 10 && e == hipSuccess; ++i)
+                               (const void *)nuts_kernel<11, 3>, (const void *)nuts_kernel<16, 3>,
+                               (const void *)nuts_kernel<11, 4>, (const void *)nuts_kernel<16, 4>, (const void *)nuts_kernel<27, 4>};
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < 13 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(nuts_kernel, %zu B dynamic LDS) failed: %s", S.lds_bytes, hipGetErrorString(e));
-            bdrt_sampler_destroy(s);
-            return nullptr;
-        }
-        attr_bytes = S.lds_bytes;
+        return e;
+    });
+    if (ae != hipSuccess) {
+        set_error("hipFuncSetAttribute(nuts_kernel, %zu B dynamic LDS) failed: %s", S.lds_bytes, hipGetErrorString(ae));
+        bdrt_sampler_destroy(s);
+        return nullptr;
     }
     return s;
 }
@@ -1177,6 +1176,7 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
 {
     if (!s || rounds < 1) { set_error("bdrt_sampler_advance: bad arguments"); return -1; }
     Sampler &S = s->impl;
+    BDRT_HIP(hipSetDevice(S.prob->device));
     S.args.rounds = rounds;
     BDRT_HIP(hipMemsetAsync(S.d_done, 0, sizeof(int), S.stream));
     hipEvent_t e0, e1;
@@ -1333,6 +1333,29 @@ int bdrt_sampler_percentiles(bdrt_sampler *s, int unit_lo, int unit_hi, int col0
     if (rows > (1L << 30)) { set_error("bdrt_sampler_percentiles: too many rows"); return -1; }
     const double *dX = S.args.draws + (size_t)unit_lo * S.np.n_draws * S.D + col0;
     return post_percentiles_device(dX, (int)rows, ncols, (long)S.D, Phi, M, bias, q, nq, out);
+}
+
+int bdrt_sampler_summary(bdrt_sampler *s, int unit_lo, int unit_hi, const double *q, int nq, double *mean, double *pct)
+{
+    if (!s || !q || nq < 1 || !pct) { set_error("bdrt_sampler_summary: null argument"); return -1; }
+    Sampler &S = s->impl;
+    if (unit_lo < 0 || unit_hi > S.n_units || unit_lo >= unit_hi || S.np.n_draws < 1) {
+        set_error("bdrt_sampler_summary: bad unit range");
+        return -1;
+    }
+    BDRT_HIP(hipSetDevice(S.prob->device));
+    BDRT_HIP(hipStreamSynchronize(S.stream));
+    const long rows = (long)(unit_hi - unit_lo) * S.np.n_draws;
+    if (rows > (1L << 30)) { set_error("bdrt_sampler_summary: too many rows"); return -1; }
+    const double *dX = S.args.draws + (size_t)unit_lo * S.np.n_draws * S.D;
+    return post_percentiles_device(dX, (int)rows, S.D, (long)S.D, nullptr, 0, nullptr, q, nq, pct, S.prob->is_pos.data(), mean);
+}
+
+const double *bdrt_sampler_draws_dev(bdrt_sampler *s)
+{
+    if (!s) return nullptr;
+    hipStreamSynchronize(s->impl.stream);
+    return s->impl.args.draws;
 }
 
 int bdrt_sample(bdrt_problem *p, int n_units, const int *spec, const int *chain_id, int warmup, int n_draws,

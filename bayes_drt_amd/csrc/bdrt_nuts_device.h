@@ -124,7 +124,8 @@ struct NutsParams {
 // Stan's windowed_adaptation schedule (stan/mcmc/windowed_adaptation.hpp)
 __host__ __device__ inline void window_init(ChainState &s, int warmup, int init_buffer, int term_buffer, int base_window)
 {
-    if (warmup < 20) {                       // no metric adaptation at all
+    const bool no_metric = warmup < 20;      // Stan: set_window_params returns early, the (unsigned) next window is never reached
+    if (no_metric) {
         init_buffer = warmup; term_buffer = 0; base_window = 0;
     } else if (init_buffer + base_window + term_buffer > warmup) {
         init_buffer = (int)(0.15 * warmup);
@@ -134,7 +135,7 @@ __host__ __device__ inline void window_init(ChainState &s, int warmup, int init_
     s.init_buffer = init_buffer; s.term_buffer = term_buffer; s.base_window = base_window;
     s.win_counter = 0;
     s.win_size = base_window;
-    s.next_window = init_buffer + base_window - 1;
+    s.next_window = no_metric ? -1 : init_buffer + base_window - 1;
     s.win_n = 0;
 }
 __host__ __device__ inline bool window_active(const ChainState &s, int warmup)

@@ -17,7 +17,7 @@
 
 namespace bdrt {
 
-constexpr int PCT_MAX_ROWS = 16384;   // one column (padded to a power of two) must fit in LDS: 16384 doubles = 128 KiB
+constexpr int PCT_MAX_ROWS = 16384;   // a column of up to 16384 samples (128 KiB) is sorted in LDS, a longer one in HBM
 
 __global__ __launch_bounds__(64) void project_kernel(const double *__restrict__ X, int rows, int K, long ldx,
                                                      const double *__restrict__ Phi, int M,
@@ -56,19 +56,43 @@ __device__ inline double numpy_lerp(double a, double b, double t)
     return r;
 }
 
+// One workgroup per column.  IN_LDS: the column (padded to n2, a power of two) is sorted in LDS; otherwise (more than
+// PCT_MAX_ROWS samples) in the column's slice of the global scratch `work` -- same network, same result.
+// expcol[col] != 0: the samples are exp(Y) (constrained scale of a Stan <lower=0> parameter; exp is monotone, so the
+// order statistics are those of Y and only the interpolation differs).  mean_out: sample mean of every column.
+template <bool IN_LDS>
 __global__ __launch_bounds__(512) void percentile_kernel(const double *__restrict__ Y, int rows, long ld_row, long ld_col,
                                                          int ncols, int n2, const double *__restrict__ q, int nq,
-                                                         double *__restrict__ out)
+                                                         double *__restrict__ out, double *__restrict__ work,
+                                                         const unsigned char *__restrict__ expcol,
+                                                         double *__restrict__ mean_out)
 {
-    extern __shared__ __attribute__((aligned(16))) double sh[];
+    extern __shared__ __attribute__((aligned(16))) double sh_[];
     const int col = blockIdx.x, tid = threadIdx.x;
+    double *red = sh_;                                              // 512 doubles: reduction scratch of the mean
+    double *sh = IN_LDS ? sh_ + 512 : work + (size_t)col * n2;
+    const bool ex = expcol && expcol[col];
     int flag = 0;
+    double part = 0.0;
     for (int i = tid; i < n2; i += 512) {
-        double v = i < rows ? Y[(size_t)i * ld_row + (size_t)col * ld_col] : INFINITY;
+        double v = INFINITY;
+        if (i < rows) {
+            v = Y[(size_t)i * ld_row + (size_t)col * ld_col];
+            if (ex) v = exp(v);
+            part += v;
+        }
         if (v != v) { flag = 1; v = INFINITY; }
         sh[i] = v;
     }
+    red[tid] = part;
     const int has_nan = __syncthreads_or(flag);
+    if (mean_out) {
+        for (int w = 256; w > 0; w >>= 1) {
+            if (tid < w) red[tid] += red[tid + w];
+            __syncthreads();
+        }
+        if (tid == 0) mean_out[col] = has_nan ? NAN : red[0] / (double)rows;
+    }
     for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < n2; i += 512) {
@@ -98,47 +122,62 @@ __global__ __launch_bounds__(512) void percentile_kernel(const double *__restric
     }
 }
 
-// device core: percentiles of (X Phi^T + bias) or of X itself (Phi == nullptr); all pointers are device pointers
-static int percentiles_dev(const double *dX, int rows, int K, long ldx, const double *dPhi, int M, const double *dBias,
-                           const double *dq, int nq, double *dOut, hipStream_t stream)
+static int launch_percentiles(const double *dY, int rows, long ld_row, int ncols, const double *dq, int nq, double *dOut,
+                              const unsigned char *dExp, double *dMean, hipStream_t stream)
 {
-    if (rows < 1 || rows > PCT_MAX_ROWS) {
-        set_error("bdrt percentiles: %d sample rows (supported: 1..%d per call)", rows, PCT_MAX_ROWS);
-        return -3;
-    }
     int n2 = 1;
     while (n2 < rows) n2 <<= 1;
-    const size_t lds = (size_t)n2 * sizeof(double);
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-        BDRT_HIP(hipFuncSetAttribute((const void *)percentile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_bytes = lds;
+    if (rows <= PCT_MAX_ROWS) {
+        const size_t lds = (size_t)(n2 + 512) * sizeof(double);
+        static LdsAttrCache attr_cache;
+        BDRT_HIP(attr_cache.ensure(lds, [&]() {
+            return hipFuncSetAttribute((const void *)percentile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }));
+        hipLaunchKernelGGL(percentile_kernel<true>, dim3(ncols), dim3(512), lds, stream, dY, rows, ld_row, 1L, ncols, n2, dq, nq,
+                           dOut, (double *)nullptr, dExp, dMean);
+        BDRT_HIP(hipGetLastError());
+        BDRT_HIP(hipStreamSynchronize(stream));
+        return 0;
     }
+    // long columns (np.percentile has no row limit): sort in a global scratch slice per column
+    double *work = nullptr;
+    BDRT_HIP(hipMalloc((void **)&work, (size_t)ncols * n2 * sizeof(double)));
+    hipLaunchKernelGGL(percentile_kernel<false>, dim3(ncols), dim3(512), 512 * sizeof(double), stream, dY, rows, ld_row, 1L, ncols,
+                       n2, dq, nq, dOut, work, dExp, dMean);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    hipFree(work);
+    if (e != hipSuccess) { set_error("bdrt percentiles: %s", hipGetErrorString(e)); return -10; }
+    return 0;
+}
+
+// device core: percentiles of (X Phi^T + bias) or of X itself (Phi == nullptr); all pointers are device pointers
+static int percentiles_dev(const double *dX, int rows, int K, long ldx, const double *dPhi, int M, const double *dBias,
+                           const double *dq, int nq, double *dOut, const unsigned char *dExp, double *dMean, hipStream_t stream)
+{
+    if (rows < 1) { set_error("bdrt percentiles: no sample rows"); return -3; }
     if (dPhi) {
         double *dY = nullptr;
         BDRT_HIP(hipMalloc((void **)&dY, (size_t)rows * M * sizeof(double)));
         hipLaunchKernelGGL(project_kernel, dim3((rows + 15) / 16, (M + 15) / 16), dim3(64), 0, stream, dX, rows, K, ldx, dPhi,
                            M, dBias, dY);
-        hipLaunchKernelGGL(percentile_kernel, dim3(M), dim3(512), lds, stream, (const double *)dY, rows, (long)M, 1L, M, n2, dq,
-                           nq, dOut);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        int rc = 0;
+        if (e != hipSuccess) { set_error("bdrt percentiles: %s", hipGetErrorString(e)); rc = -10; }
+        if (rc == 0) rc = launch_percentiles(dY, rows, (long)M, M, dq, nq, dOut, nullptr, dMean, stream);
         hipFree(dY);
-        if (e != hipSuccess) { set_error("bdrt percentiles: %s", hipGetErrorString(e)); return -10; }
-    } else {
-        hipLaunchKernelGGL(percentile_kernel, dim3(K), dim3(512), lds, stream, dX, rows, ldx, 1L, K, n2, dq, nq, dOut);
-        BDRT_HIP(hipGetLastError());
-        BDRT_HIP(hipStreamSynchronize(stream));
+        return rc;
     }
-    return 0;
+    return launch_percentiles(dX, rows, ldx, K, dq, nq, dOut, dExp, dMean, stream);
 }
 
 int post_percentiles_device(const double *dX, int rows, int K, long ldx, const double *Phi, int M, const double *bias,
-                            const double *q, int nq, double *out)
+                            const double *q, int nq, double *out, const unsigned char *expcol, double *mean)
 {
     const int ncols = Phi ? M : K;
-    double *dPhi = nullptr, *dBias = nullptr, *dq = nullptr, *dOut = nullptr;
-    auto cleanup = [&]() { hipFree(dPhi); hipFree(dBias); hipFree(dq); hipFree(dOut); };
+    double *dPhi = nullptr, *dBias = nullptr, *dq = nullptr, *dOut = nullptr, *dMean = nullptr;
+    unsigned char *dExp = nullptr;
+    auto cleanup = [&]() { hipFree(dPhi); hipFree(dBias); hipFree(dq); hipFree(dOut); hipFree(dMean); hipFree(dExp); };
 #define PP_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return -10; } } while (0)
     if (Phi) {
         PP_HIP(hipMalloc((void **)&dPhi, (size_t)M * K * sizeof(double)));
@@ -153,9 +192,15 @@ int post_percentiles_device(const double *dX, int rows, int K, long ldx, const d
     PP_HIP(hipMalloc((void **)&dq, (size_t)nq * sizeof(double)));
     PP_HIP(hipMemcpy(dq, quant.data(), (size_t)nq * sizeof(double), hipMemcpyHostToDevice));
     PP_HIP(hipMalloc((void **)&dOut, (size_t)nq * ncols * sizeof(double)));
-    const int rc = percentiles_dev(dX, rows, K, ldx, dPhi, M, dBias, dq, nq, dOut, nullptr);
+    if (expcol && !Phi) {
+        PP_HIP(hipMalloc((void **)&dExp, (size_t)K));
+        PP_HIP(hipMemcpy(dExp, expcol, (size_t)K, hipMemcpyHostToDevice));
+    }
+    if (mean) PP_HIP(hipMalloc((void **)&dMean, (size_t)ncols * sizeof(double)));
+    const int rc = percentiles_dev(dX, rows, K, ldx, dPhi, M, dBias, dq, nq, dOut, dExp, dMean, nullptr);
     if (rc) { cleanup(); return rc; }
     PP_HIP(hipMemcpy(out, dOut, (size_t)nq * ncols * sizeof(double), hipMemcpyDeviceToHost));
+    if (mean) PP_HIP(hipMemcpy(mean, dMean, (size_t)ncols * sizeof(double), hipMemcpyDeviceToHost));
 #undef PP_HIP
     cleanup();
     return 0;
@@ -174,11 +219,26 @@ int bdrt_percentiles(const double *X, int rows, int K, long ldx, const double *P
         set_error("bdrt_percentiles: bad arguments");
         return -1;
     }
+    bind_process_device();
     double *dX = nullptr;
     const size_t nb = ((size_t)(rows - 1) * ldx + K) * sizeof(double);
     if (hipMalloc((void **)&dX, nb) != hipSuccess) { set_error("bdrt_percentiles: hipMalloc(%zu) failed", nb); return -10; }
     if (hipMemcpy(dX, X, nb, hipMemcpyHostToDevice) != hipSuccess) { hipFree(dX); set_error("bdrt_percentiles: copy failed"); return -10; }
     const int rc = post_percentiles_device(dX, rows, K, ldx, Phi, M, bias, q, nq, out);
+    hipFree(dX);
+    return rc;
+}
+
+int bdrt_summary(const double *X, int rows, int K, long ldx, const unsigned char *is_pos, const double *q, int nq,
+                 double *mean, double *pct)
+{
+    if (!X || rows < 1 || K < 1 || ldx < K || !q || nq < 1 || !pct) { set_error("bdrt_summary: bad arguments"); return -1; }
+    bind_process_device();
+    double *dX = nullptr;
+    const size_t nb = ((size_t)(rows - 1) * ldx + K) * sizeof(double);
+    if (hipMalloc((void **)&dX, nb) != hipSuccess) { set_error("bdrt_summary: hipMalloc(%zu) failed", nb); return -10; }
+    if (hipMemcpy(dX, X, nb, hipMemcpyHostToDevice) != hipSuccess) { hipFree(dX); set_error("bdrt_summary: copy failed"); return -10; }
+    const int rc = post_percentiles_device(dX, rows, K, ldx, nullptr, 0, nullptr, q, nq, pct, is_pos, mean);
     hipFree(dX);
     return rc;
 }

@@ -278,6 +278,7 @@ int bdrt_qp_box_batch(const double *P, const double *q, const double *lo, int n,
                       double *primal_objective, int *iterations)
 {
     if (!P || !q || !x || n < 1 || nb < 1) { set_error("bdrt_qp_box_batch: bad arguments"); return -1; }
+    bind_process_device();
     const int np = (n + 1) & ~1;
     const size_t vec_bytes = ((size_t)(QP_NVEC + 1) * np + 32) * sizeof(double);      // + diag, reduction scratch
     const size_t msize = (size_t)n * (n + 1) / 2;
@@ -300,12 +301,13 @@ int bdrt_qp_box_batch(const double *P, const double *q, const double *lo, int n,
     QP_HIP(hipMalloc((void **)&dobj, (size_t)nb * sizeof(double)));
     QP_HIP(hipMalloc((void **)&dit, (size_t)nb * sizeof(int)));
     if (!in_lds) QP_HIP(hipMalloc((void **)&dwork, (size_t)nb * msize * sizeof(double)));
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-        QP_HIP(hipFuncSetAttribute((const void *)qp_box_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        QP_HIP(hipFuncSetAttribute((const void *)qp_box_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_bytes = lds;
-    }
+    static LdsAttrCache attr_cache;
+    QP_HIP(attr_cache.ensure(lds, [&]() {
+        hipError_t e = hipFuncSetAttribute((const void *)qp_box_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)qp_box_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return e;
+    }));
     if (in_lds)
         hipLaunchKernelGGL(qp_box_kernel<true>, dim3(nb), dim3(QP_NT), lds, 0, dP, dq, dlo, n, dx, dobj, dit, dwork);
     else

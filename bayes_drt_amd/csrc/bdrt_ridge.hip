@@ -58,6 +58,7 @@ int bdrt_gram(const double *WA, const double *WZ, int nrows, int n, const double
               double *q)
 {
     if (!WA || nrows < 1 || n < 1 || (!P && !q) || (q && !WZ)) { set_error("bdrt_gram: bad arguments"); return -1; }
+    bind_process_device();
     double *dWA = nullptr, *dWZ = nullptr, *dL2 = nullptr, *dL1 = nullptr, *dP = nullptr, *dq = nullptr;
     auto cleanup = [&]() { hipFree(dWA); hipFree(dWZ); hipFree(dL2); hipFree(dL1); hipFree(dP); hipFree(dq); };
 #define GR_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return -10; } } while (0)

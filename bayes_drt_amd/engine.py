@@ -330,44 +330,117 @@ class StanModel:
         return StanFit(self, theta, lp.reshape(-1), diag, chains, n_draws)
 
 
+class DeviceArray:
+    """Zero-copy view of a device buffer for consumers that understand `__cuda_array_interface__` (torch on ROCm does):
+    lets torch.distributed (RCCL) gather the sampler's draws straight from HBM."""
+
+    def __init__(self, ptr_value, shape, owner):
+        self._owner = owner                      # keeps the sampler (and its device memory) alive
+        self.__cuda_array_interface__ = {'shape': tuple(int(x) for x in shape), 'typestr': '<f8',
+                                         'data': (int(ptr_value), True), 'version': 2, 'strides': None}
+
+
+class Sampler:
+    """A set of device-resident NUTS chains (bdrt_sampler of include/bdrt.h): unit u samples spectrum spec[u] with the
+    RNG stream (seed, chain_ids[u]).  The draws stay in HBM until `results()`; `summary()` reduces them there."""
+
+    def __init__(self, problem, n_units, warmup, n_draws, seed, ctrl=None, spec=None, chain_ids=None, init_theta=None):
+        lib = problem._lib
+        if ctrl is None:
+            ctrl = NutsControl()
+            lib.bdrt_nuts_defaults(C.byref(ctrl))
+        sp = None if spec is None else np.ascontiguousarray(np.asarray(spec, dtype=np.int32))
+        ci = None if chain_ids is None else np.ascontiguousarray(np.asarray(chain_ids, dtype=np.int32))
+        it = None if init_theta is None else f64(init_theta)
+        self.problem, self._lib, self.ctrl = problem, lib, ctrl
+        self.n_units, self.warmup, self.n_draws = int(n_units), int(warmup), int(n_draws)
+        self.handle = lib.bdrt_sampler_create(problem.handle, self.n_units, ptr(sp), ptr(ci), self.warmup, self.n_draws,
+                                              C.c_uint64(int(seed)), ptr(it), C.byref(ctrl))
+        if not self.handle:
+            raise _lib.BdrtError('bdrt_sampler_create: ' + lib.bdrt_last_error().decode())
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self._lib.bdrt_sampler_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def advance(self, rounds, want_done=False):
+        done = C.c_int(0)
+        check(self._lib.bdrt_sampler_advance(self.handle, int(rounds), C.byref(done) if want_done else None),
+              'bdrt_sampler_advance')
+        return bool(done.value)
+
+    def sync(self):
+        check(self._lib.bdrt_sampler_sync(self.handle), 'bdrt_sampler_sync')
+
+    def run(self, rounds_per_launch=None):
+        if not rounds_per_launch:
+            check(self._lib.bdrt_sampler_run(self.handle), 'bdrt_sampler_run')
+            return
+        bound = ((1 << self.ctrl.max_treedepth) + 64) * (self.warmup + self.n_draws + 2) + 200
+        spent = 0
+        while spent <= bound:
+            if self.advance(rounds_per_launch, want_done=True):
+                return
+            spent += int(rounds_per_launch)
+        raise _lib.BdrtError('sampler did not finish within the leapfrog bound')
+
+    def total_leapfrogs(self):
+        return int(self._lib.bdrt_sampler_total_leapfrogs(self.handle))
+
+    def kernel_time(self, reset=False):
+        ms = C.c_double(); nl = C.c_int64()
+        check(self._lib.bdrt_sampler_kernel_time(self.handle, C.byref(ms), C.byref(nl), int(reset)), 'bdrt_sampler_kernel_time')
+        return ms.value, int(nl.value)
+
+    def results(self, want_draws=True):
+        """(draws [n_units, n_draws, D] unconstrained or None, lp [n_units, n_draws], per-chain diagnostics)."""
+        draws = np.empty((self.n_units, self.n_draws, self.problem.D)) if want_draws else None
+        lp = np.empty((self.n_units, self.n_draws))
+        diag = (ChainDiag * self.n_units)()
+        check(self._lib.bdrt_sampler_results(self.handle, ptr(draws), ptr(lp), diag), 'bdrt_sampler_results')
+        dl = [dict(n_leapfrog=d.n_leapfrog, n_divergent=d.n_divergent, n_max_treedepth=d.n_max_treedepth,
+                   stepsize=d.stepsize, mean_accept=d.mean_accept) for d in diag]
+        if any(d['n_leapfrog'] < 0 for d in dl):
+            raise _lib.BdrtError('a chain found no finite initial point in 100 attempts')
+        return draws, lp, dl
+
+    def draws_device(self):
+        """The draws where the sampler left them (HBM), as a `__cuda_array_interface__` object."""
+        p = self._lib.bdrt_sampler_draws_dev(self.handle)
+        if not p:
+            raise _lib.BdrtError('bdrt_sampler_draws_dev failed')
+        return DeviceArray(p, (self.n_units, self.n_draws, self.problem.D), self)
+
+    def summary(self, unit_lo, unit_hi, q=(2.5, 50.0, 97.5)):
+        """Posterior mean [D] and percentiles [len(q), D] of the CONSTRAINED parameters over all draws of units
+        [unit_lo, unit_hi), reduced on the device (np.mean / np.percentile of the reference, inversion.py:2517-2519, :2560)."""
+        qa = np.ascontiguousarray(np.atleast_1d(np.asarray(q, dtype=np.float64)))
+        mean = np.empty(self.problem.D); pct = np.empty((qa.size, self.problem.D))
+        check(self._lib.bdrt_sampler_summary(self.handle, int(unit_lo), int(unit_hi), ptr(qa), qa.size, ptr(mean), ptr(pct)),
+              'bdrt_sampler_summary')
+        return mean, pct
+
+
 def sample_units(problem, n_units, warmup, n_draws, seed, ctrl=None, spec=None, chain_ids=None, init_theta=None,
                  rounds_per_launch=None):
     """Run n_units chains (unit u: spectrum spec[u], RNG stream (seed, chain_ids[u])) to completion on the GPU.
     Returns draws [n_units, n_draws, D] (unconstrained), lp [n_units, n_draws], list of per-chain diagnostics."""
-    lib = problem._lib
-    if ctrl is None:
-        ctrl = NutsControl()
-        lib.bdrt_nuts_defaults(C.byref(ctrl))
-    sp = None if spec is None else np.ascontiguousarray(np.asarray(spec, dtype=np.int32))
-    ci = None if chain_ids is None else np.ascontiguousarray(np.asarray(chain_ids, dtype=np.int32))
-    it = None if init_theta is None else f64(init_theta)
-    h = lib.bdrt_sampler_create(problem.handle, int(n_units), ptr(sp), ptr(ci), int(warmup), int(n_draws),
-                                C.c_uint64(int(seed)), ptr(it), C.byref(ctrl))
-    if not h:
-        raise _lib.BdrtError('bdrt_sampler_create: ' + lib.bdrt_last_error().decode())
-    try:
-        if rounds_per_launch:
-            done = C.c_int(0)
-            bound = ((1 << ctrl.max_treedepth) + 64) * (warmup + n_draws + 2) + 200
-            spent = 0
-            while not done.value and spent <= bound:
-                check(lib.bdrt_sampler_advance(h, int(rounds_per_launch), C.byref(done)), 'bdrt_sampler_advance')
-                spent += int(rounds_per_launch)
-            if not done.value:
-                raise _lib.BdrtError('sampler did not finish within the leapfrog bound')
-        else:
-            check(lib.bdrt_sampler_run(h), 'bdrt_sampler_run')
-        draws = np.empty((n_units, n_draws, problem.D))
-        lp = np.empty((n_units, n_draws))
-        diag = (ChainDiag * n_units)()
-        check(lib.bdrt_sampler_results(h, ptr(draws), ptr(lp), diag), 'bdrt_sampler_results')
-    finally:
-        lib.bdrt_sampler_destroy(h)
-    dl = [dict(n_leapfrog=d.n_leapfrog, n_divergent=d.n_divergent, n_max_treedepth=d.n_max_treedepth,
-               stepsize=d.stepsize, mean_accept=d.mean_accept) for d in diag]
-    if any(d['n_leapfrog'] < 0 for d in dl):
-        raise _lib.BdrtError('a chain found no finite initial point in 100 attempts')
-    return draws, lp, dl
+    with Sampler(problem, n_units, warmup, n_draws, seed, ctrl, spec=spec, chain_ids=chain_ids, init_theta=init_theta) as smp:
+        smp.run(rounds_per_launch)
+        return smp.results()
 
 
 def optimize_batch(problem, theta0, spec=None, max_iter=50000, **opts):

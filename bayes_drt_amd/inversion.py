@@ -43,33 +43,43 @@ class _QPResult(dict):
 
 
 def _qp_batch(P, q, lo):
-    """min 1/2 x'Px + q'x s.t. x >= lo for a stack of problems: one GPU launch (bdrt_qp.hip)."""
+    """min 1/2 x'Px + q'x s.t. x >= lo for a stack of problems: one GPU launch (bdrt_qp.hip).
+
+    A problem that reaches the iteration limit keeps its last iterate (cvxopt returns status 'unknown' with the best
+    iterate in that case and the reference uses it, inversion.py:1066-1067); only a KKT matrix that is not positive
+    definite is an error."""
     lib = _lib.require_gpu()
     P = np.ascontiguousarray(P, dtype=np.float64); q = np.ascontiguousarray(q, dtype=np.float64)
     nb, n = q.shape
     x = np.empty((nb, n)); obj = np.empty(nb)
-    _lib.check(lib.bdrt_qp_box_batch(ptr(P), ptr(q), ptr(np.ascontiguousarray(lo, dtype=np.float64)), n, nb, ptr(x),
-                                     ptr(obj), None), 'bdrt_qp_box_batch')
+    rc = lib.bdrt_qp_box_batch(ptr(P), ptr(q), ptr(np.ascontiguousarray(lo, dtype=np.float64)), n, nb, ptr(x), ptr(obj), None)
+    if rc == -4:
+        warnings.warn('bdrt_qp_box_batch: iteration limit reached; the last iterate is used')
+    else:
+        _lib.check(rc, 'bdrt_qp_box_batch')
     return x, obj
 
 
 class _QPBatcher(object):
     """Rendezvous of the independent ridge fits of a Re-Im cross-validation: each fit (one thread) hands in its QP and
-    waits; when every fit still running has handed one in, the last arrival solves them all in one batched launch."""
+    waits; when every fit still running has handed one in, the last arrival solves them all in one batched launch.
+    A failed launch is delivered to every waiting fit (each re-raises it), never left pending."""
 
     def __init__(self, n_workers):
         import threading
         self.cv = threading.Condition()
         self.alive = n_workers
         self.pending = []            # [P, q, lo, slot]
-        self.generation = 0
 
     def _flush(self):
         items, self.pending = self.pending, []
-        x, obj = _qp_batch(np.stack([it[0] for it in items]), np.stack([it[1] for it in items]), items[0][2])
-        for k, it in enumerate(items):
-            it[3]['x'], it[3]['obj'] = x[k], obj[k]
-        self.generation += 1
+        try:
+            x, obj = _qp_batch(np.stack([it[0] for it in items]), np.stack([it[1] for it in items]), items[0][2])
+            for k, it in enumerate(items):
+                it[3]['x'], it[3]['obj'] = x[k], obj[k]
+        except BaseException as e:                       # noqa: BLE001 -- handed to every waiter
+            for it in items:
+                it[3]['err'] = e
         self.cv.notify_all()
 
     def solve(self, P, q, lo):
@@ -79,8 +89,10 @@ class _QPBatcher(object):
             if len(self.pending) == self.alive:
                 self._flush()
             else:
-                while 'x' not in slot:
+                while 'x' not in slot and 'err' not in slot:
                     self.cv.wait()
+        if 'err' in slot:
+            raise slot['err']
         return slot['x'], slot['obj']
 
     def leave(self):
@@ -104,62 +116,85 @@ def _dist_equal(a, b):
     return True
 
 
+# DDT options: allowed values and the defaults AS CODED in the reference (inversion.py:119), which differ from its
+# docstring (:77 says transmissive).  The validation default of `bc` / `ct` below is what the reference's
+# checks assume when the key is absent (:100-111).
+_DDT_OPTIONS = (
+    # key, allowed values, default used by the validity check, message
+    ('dist_type', ('series', 'parallel'), 'parallel', "Invalid dist_type '{}' for distribution '{}'"),
+    ('symmetry', ('planar', 'spherical'), 'planar', "Invalid symmetry '{}' for distribution '{}'"),
+    ('bc', ('transmissive', 'blocking'), 'transmissive', "Invalid bc '{}' for distribution '{}'"),
+    ('ct', (True, False), True, "Invalid ct {} for distribution '{}'"),
+)
+_DDT_DEFAULTS = {'dist_type': 'parallel', 'symmetry': 'planar', 'bc': 'blocking', 'ct': False}
+_DRT_ONLY_INVALID = ('symmetry', 'bc', 'ct', 'k_ct')
+
+
+def _invalidating_property(attr, check=None):
+    """Inverter property whose assignment invalidates the cached matrices (reference :4069-4110)."""
+    def getter(self):
+        return getattr(self, attr)
+
+    def setter(self, value):
+        if check is not None:
+            check(value)
+        setattr(self, attr, value)
+        self._invalidate()
+    return getter, setter
+
+
+def _check_basis(basis):
+    if basis != 'gaussian':
+        raise ValueError(f'Invalid basis {basis}. Options are gaussian')
+
+
 class Inverter:
     def __init__(self, basis_freq=None, basis='gaussian', epsilon=None, fit_inductance=True,
                  distributions={'DRT': {'kernel': 'DRT'}}):
         """See the reference docstring (bayes_drt/inversion.py:29-49): basis_freq (10 points per decade recommended),
         basis ('gaussian' only), epsilon (None: 1/mean spacing of ln tau), fit_inductance (ridge_fit only),
         distributions {name: {kernel, dist_type, symmetry, bc, ct, k_ct, basis_freq, epsilon, x_scale}}."""
-        self._recalc_mat = True
         self.distribution_matrices = {}
-        self.set_basis_freq(basis_freq)
-        self.set_basis(basis)
-        self.set_epsilon(epsilon)
-        self.set_fit_inductance(fit_inductance)
-        self.set_distributions(deepcopy(distributions))
+        self._invalidate()
+        self.basis_freq, self.basis, self.epsilon = basis_freq, basis, epsilon
+        self.fit_inductance = fit_inductance
+        self.distributions = deepcopy(distributions)
         self._cached_distributions = self.distributions.copy()
-        self.f_train = [0]
-        self.Z_train = None
+        # state of "no fit yet" (reference :59-64)
+        self.__dict__.update(f_train=[0], Z_train=None, _Z_scale=1.0, _init_params={}, distribution_fits={},
+                             _iter_history=None)
+
+    def _invalidate(self):
+        """Matrices and prediction matrices must be rebuilt."""
+        self._recalc_mat = True
         self.f_pred = None
-        self._Z_scale = 1.0
-        self._init_params = {}
-        self.distribution_fits = {}
-        self._iter_history = None
 
     # ------------------------------------------------------------------ distributions (reference :66-137)
     def set_distributions(self, distributions):
         for name, info in distributions.items():
-            if info['kernel'] == 'DRT':
-                if info.get('dist_type', 'series') != 'series':
+            kernel = info['kernel']
+            if kernel == 'DRT':
+                given = info.get('dist_type', 'series')
+                if given != 'series':
                     warnings.warn("dist_type for DRT kernel must be series. Overwriting supplied dist_type '{}' for "
-                                  "distribution '{}' with 'series'".format(name, info['dist_type']))
+                                  "distribution '{}' with 'series'".format(name, given))
                 info['dist_type'] = 'series'
-                bad = np.intersect1d(list(info.keys()), ['symmetry', 'bc', 'ct', 'k_ct'])
-                if len(bad) > 0:
+                ignored = np.intersect1d(list(info.keys()), list(_DRT_ONLY_INVALID))
+                if len(ignored) > 0:
                     warnings.warn("The following keys are invalid for distribution '{}': {}.\n These keys will be "
-                                  "ignored".format(name, bad))
-            elif info['kernel'] == 'DDT':
-                if info.get('dist_type', 'parallel') not in ['series', 'parallel']:
-                    raise ValueError("Invalid dist_type '{}' for distribution '{}'".format(info.get('dist_type', 'NA'), name))
-                elif info.get('symmetry', 'planar') not in ['planar', 'spherical']:
-                    raise ValueError("Invalid symmetry '{}' for distribution '{}'".format(info.get('symmetry', 'NA'), name))
-                elif info.get('bc', 'transmissive') not in ['transmissive', 'blocking']:
-                    raise ValueError("Invalid bc '{}' for distribution '{}'".format(info.get('bc', 'NA'), name))
-                elif info.get('ct', True) not in [True, False]:
-                    raise ValueError("Invalid ct {} for distribution '{}'".format(info['ct'], name))
-                if info.get('ct', False) == True and 'k_ct' not in info.keys():
+                                  "ignored".format(name, ignored))
+            elif kernel == 'DDT':
+                for key, allowed, assumed, msg in _DDT_OPTIONS:
+                    if info.get(key, assumed) not in allowed:
+                        raise ValueError(msg.format(info.get(key, 'NA'), name))
+                if info.get('ct', False) == True and 'k_ct' not in info:
                     raise ValueError("k_ct must be supplied for distribution '{}' if ct==True".format(name))
-                # defaults as coded in the reference (:119), which differ from its docstring (SURVEY H10)
-                full = {'dist_type': 'parallel', 'symmetry': 'planar', 'bc': 'blocking', 'ct': False}
-                full.update(info)
-                distributions[name] = full
+                distributions[name] = dict(_DDT_DEFAULTS, **info)
             else:
-                raise ValueError("Invalid kernel '{}' for distribution '{}'".format(info['kernel'], name))
-            if name not in self.distribution_matrices.keys():
-                self.distribution_matrices[name] = {}
+                raise ValueError("Invalid kernel '{}' for distribution '{}'".format(kernel, name))
+            self.distribution_matrices.setdefault(name, {})
         self._distributions = distributions
-        self._recalc_mat = True
-        self.f_pred = None
+        self._invalidate()
 
     def get_distributions(self):
         return self._distributions
@@ -167,26 +202,9 @@ class Inverter:
     distributions = property(get_distributions, set_distributions)
 
     # ------------------------------------------------------------------ properties (reference :4069-4110)
-    def get_basis_freq(self):
-        return self._basis_freq
-
-    def set_basis_freq(self, basis_freq):
-        self._basis_freq = basis_freq
-        self._recalc_mat = True
-        self.f_pred = None
-
+    get_basis_freq, set_basis_freq = _invalidating_property('_basis_freq')
     basis_freq = property(get_basis_freq, set_basis_freq)
-
-    def get_basis(self):
-        return self._basis
-
-    def set_basis(self, basis):
-        if basis != 'gaussian':
-            raise ValueError(f'Invalid basis {basis}. Options are gaussian')
-        self._basis = basis
-        self._recalc_mat = True
-        self.f_pred = None
-
+    get_basis, set_basis = _invalidating_property('_basis', _check_basis)
     basis = property(get_basis, set_basis)
 
     def get_epsilon(self):
@@ -194,11 +212,10 @@ class Inverter:
 
     def set_epsilon(self, epsilon, override_distributions=False):
         self._epsilon = epsilon
-        self._recalc_mat = True
+        self._invalidate()
         if override_distributions:
-            for name in self.distributions.keys():
-                self.distributions[name]['epsilon'] = epsilon
-        self.f_pred = None
+            for info in self.distributions.values():
+                info['epsilon'] = epsilon
 
     epsilon = property(get_epsilon, set_epsilon)
 
@@ -623,27 +640,26 @@ class Inverter:
         return load_pickle(os.path.join(script_dir, 'stan_model_files', s)), s
 
     def _get_init_from_ridge(self, frequencies, Z, mode, nonneg, outliers, inductance_scale, ridge_kw):
-        """Initial values from an under-fitted hyper-ridge solution (reference :1616-1682)."""
-        name = list(self.distributions.keys())[0]
-        dist_type = self.distributions[name]['dist_type']
-        kw = dict(penalty='integral', hyper_lambda=True, lambda_0=1, hl_beta=5, weights='modulus')
-        kw.update(ridge_kw)
-        self.ridge_fit(frequencies, Z, **kw)
+        """Initial values from a deliberately under-fitted hyper-ridge solution (reference :1616-1682).  Returns the
+        callable Stan's `init=` takes; it yields constrained values on the scaled-Z problem."""
+        name = next(iter(self.distributions))
+        settings = dict(penalty='integral', hyper_lambda=True, lambda_0=1, hl_beta=5, weights='modulus')
+        settings.update(ridge_kw)                       # user settings win
+        self.ridge_fit(frequencies, Z, **settings)
+        zs = self._Z_scale
         coef = self.distribution_fits[name]['coef']
-        iv = {'x': coef / self._Z_scale if dist_type == 'series' else coef * self._Z_scale}
-        iv['Rinf'] = self.R_inf / self._Z_scale
-        iv['Rinf_raw'] = iv['Rinf'] / 100
-        iv['induc'] = self.inductance / self._Z_scale
-        if iv['induc'] <= 0:
-            iv['induc'] = 1e-10
-        iv['induc_raw'] = iv['induc'] / inductance_scale
+        series = self.distributions[name]['dist_type'] == 'series'
+        Rinf = self.R_inf / zs
+        induc = max(self.inductance / zs, 0.0) or 1e-10  # lower=0 parameter: strictly positive start
+        values = {'x': coef / zs if series else coef * zs, 'Rinf': Rinf, 'Rinf_raw': Rinf / 100, 'induc': induc,
+                  'induc_raw': induc / inductance_scale}
         if outliers:
-            idx = self.check_outliers(frequencies, Z, threshold=3, use_existing_fit=True)
-            if outliers is True or len(idx) > 0:
-                so = np.zeros(len(Z)) + 0.1
-                so[idx] = 1
-                iv['sigma_out_raw'] = so
-        return lambda: iv
+            suspects = self.check_outliers(frequencies, Z, threshold=3, use_existing_fit=True)   # lenient threshold
+            if outliers is True or len(suspects) > 0:
+                start = np.full(len(Z), 0.1)
+                start[suspects] = 1
+                values['sigma_out_raw'] = start
+        return lambda: values
 
     def _prep_stan_data(self, frequencies, Z, part, model_type, dist_mat, outliers, sigma_min, mode, inductance_scale,
                         outlier_lambda, fitY, SA, SASY):
@@ -802,40 +818,45 @@ class Inverter:
         self._cached_distributions = self.distributions.copy()
         return frequencies, Z, W_re @ Z.real, W_im @ Z.imag, W_re, W_im, dist_mat
 
+    # named weighting schemes -> complex weight vector (real part weights Z', imaginary part Z''); reference :2351-2366
+    _WEIGHT_SCHEMES = {
+        'unity': lambda Z: np.ones(len(Z)) * (1 + 1j),
+        'modulus': lambda Z: (1 + 1j) / np.sqrt(np.real(Z * Z.conjugate())),
+        'Orazem': lambda Z: (1 + 1j) / (np.abs(Z.real) + np.abs(Z.imag)),
+        'proportional': lambda Z: 1 / np.abs(Z.real) + 1j / np.abs(Z.imag),
+        'prop_adj': lambda Z: (lambda floor: 1 / (np.abs(Z.real) + floor) + 1j / (np.abs(Z.imag) + floor))(
+            np.percentile(np.real(Z * Z.conjugate()), 25)),
+    }
+
     def _format_weights(self, frequencies, Z, weights, part):
-        """Complex weight vector: real part weights Z', imaginary part Z'' (reference :2338-2395)."""
-        if weights is None or (isinstance(weights, str) and weights == 'unity'):
-            weights = np.ones_like(frequencies) * (1 + 1j)
-        elif isinstance(weights, str):
-            if weights == 'modulus':
-                weights = (1 + 1j) / np.sqrt(np.real(Z * Z.conjugate()))
-            elif weights == 'Orazem':
-                weights = (1 + 1j) / (np.abs(Z.real) + np.abs(Z.imag))
-            elif weights == 'proportional':
-                weights = 1 / np.abs(Z.real) + 1j / np.abs(Z.imag)
-            elif weights == 'prop_adj':
-                zm = np.real(Z * Z.conjugate())
-                weights = 1 / (np.abs(Z.real) + np.percentile(zm, 25)) + 1j / (np.abs(Z.imag) + np.percentile(zm, 25))
-            else:
+        """Complex weight vector: real part weights Z', imaginary part Z'' (reference :2338-2395).
+        weights: None | scheme name | real or complex scalar | array (real: both parts; complex: one part each)."""
+        if part not in ('both', 'real', 'imag'):
+            raise ValueError(f"Invalid part {part}. Options are 'both', 'real', or 'imag'")
+        n = len(frequencies)
+        if weights is None:
+            weights = 'unity'
+        if isinstance(weights, str):
+            scheme = self._WEIGHT_SCHEMES.get(weights)
+            if scheme is None:
                 raise ValueError(f"Invalid weights argument {weights}. String options are 'unity', 'modulus', "
                                  f"'proportional', and 'prop_adj'")
+            w = scheme(Z)
         elif type(weights) in (float, int):
-            weights = np.ones_like(frequencies) * (1 + 1j) * weights
+            w = np.full(n, weights * (1 + 1j))
         elif type(weights) == complex:
-            weights = np.ones_like(frequencies) * weights
-        elif len(weights) != len(frequencies):
-            raise ValueError("Weights array must match length of data")
-        if part == 'both':
-            if np.min(np.isreal(weights)) == True:
-                weights = weights + 1j * weights
-        elif part == 'real':
-            weights = np.real(weights) + 1j * np.ones_like(frequencies)
-        elif part == 'imag':
-            if np.min(np.isreal(weights)) == True:
-                weights = np.ones_like(frequencies) + 1j * weights
+            w = np.full(n, weights)
         else:
-            raise ValueError(f"Invalid part {part}. Options are 'both', 'real', or 'imag'")
-        return weights
+            if len(weights) != n:
+                raise ValueError("Weights array must match length of data")
+            w = weights
+        all_real = bool(np.min(np.isreal(w)))
+        one = np.ones(n)
+        if part == 'real':                       # the imaginary part is not fitted: unit weight
+            return np.real(w) + 1j * one
+        if not all_real:                         # complex weights already carry one weight per part
+            return w
+        return w + 1j * w if part == 'both' else one + 1j * w
 
     def _scale_Z(self, Z, fit_type):
         """_Z_scale = std|Z| / sqrt(N/81); pure parallel planar DDT scales the admittance instead (reference :2411-2443)."""
@@ -967,8 +988,7 @@ class Inverter:
             if full and len(ft) == len(frequencies) and bool(np.min(rel_round(ft, 10) == rel_round(frequencies, 10))):
                 Zp = post.percentile(self._sample_result['Z_hat'], percentile, axis=0) * self._Z_scale
                 return Zp[:len(frequencies)] + 1j * Zp[len(frequencies):]
-            if (full and len(distributions) == 1 and self.distributions[distributions[0]]['dist_type'] == 'series'
-                    and len(self._sample_result['Rinf']) <= post.MAX_ROWS):
+            if full and len(distributions) == 1 and self.distributions[distributions[0]]['dist_type'] == 'series':
                 # one series distribution: Z of a draw is affine in (Rinf, induc, coef): project and reduce on the GPU
                 name = distributions[0]
                 mat = self._get_prediction_matrices(frequencies, distributions)[name]

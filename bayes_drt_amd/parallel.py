@@ -1,12 +1,18 @@
 """Multi-GPU execution: one process per GPU, units (spectrum, chain) sharded with NO data-path collective.
 
-The path shards naturally: chains are independent given the data and spectra are independent fits.
-Communication is limited to (1) one broadcast of the problem description from rank 0 (matrices + spectra, a few
-MB) and (2) one gather of the results at the end -- RCCL over xGMI when the process group backend is "nccl"
-(GPU tensors), gloo on CPU tensors in the tests.  Draws are a function of (seed, chain id) only, so the result is
-independent of how units are distributed over ranks.
+The path shards naturally: chains are independent given the data (the reference runs one process per
+chain, bayes_drt/inversion.py:1218-1221) and spectra are independent fits.  Communication is limited to
+  (1) one broadcast of the problem description from rank 0 (matrices + spectra, a few MB), and
+  (2) one gather at the end -- per-spectrum posterior SUMMARIES (mean + percentiles, reduced on each GPU by
+      bdrt_sampler_summary) or, on request, the raw draws, taken straight from HBM (no host round trip) --
+over RCCL / xGMI when the process group backend is "nccl", gloo on CPU tensors in the tests.
+Partition (`partition_units`): whole spectra per rank when there are at least as many spectra as ranks (BASELINE
+config 4), otherwise the chains of the few spectra are spread over the ranks (configs 3 and 5: one spectrum, 4 chains
+=> 4 GPUs busy).  Draws are a function of (seed, chain id) only, so results do not depend on the partition.
 """
 import numpy as np
+
+_INT_LIMIT = 2 ** 53        # integers travel inside a float64 buffer: exact below this
 
 
 def shard_bounds(n_items, world, rank):
@@ -23,6 +29,15 @@ def make_units(n_spectra, chains):
     return spec, chain
 
 
+def partition_units(n_spectra, chains, world):
+    """[(unit_lo, unit_hi)] per rank over the spectrum-major unit list.
+    n_spectra >= world: block partition by SPECTRUM (a rank keeps whole spectra, so its summaries are complete);
+    fewer spectra than ranks: block partition of the UNITS themselves (chains of one spectrum on several GPUs)."""
+    if n_spectra >= world:
+        return [tuple(chains * b for b in shard_bounds(n_spectra, world, r)) for r in range(world)]
+    return [shard_bounds(n_spectra * chains, world, r) for r in range(world)]
+
+
 def _dist():
     import torch.distributed as dist
     return dist
@@ -36,14 +51,21 @@ def _device_for_group(group=None):
 
 
 def broadcast_arrays(arrays, src=0, group=None):
-    """Broadcast a dict of numpy arrays / scalars from `src` to every rank (one metadata object + one flat fp64
+    """Broadcast a dict of real numpy arrays / scalars from `src` to every rank (one metadata object + one flat fp64
     buffer, i.e. a single large collective instead of one per array)."""
     import torch
     dist = _dist()
     rank = dist.get_rank(group)
     meta = [None]
     if rank == src:
-        meta[0] = [(k, np.asarray(v).shape, str(np.asarray(v).dtype)) for k, v in arrays.items()]
+        meta[0] = []
+        for k, v in arrays.items():
+            a = np.asarray(v)
+            if a.dtype.kind not in 'fiub':
+                raise TypeError('broadcast_arrays: %s has dtype %s; only real floating / integer / bool arrays travel' % (k, a.dtype))
+            if a.dtype.kind in 'iu' and a.size and np.max(np.abs(a.astype(np.float64))) >= _INT_LIMIT:
+                raise ValueError('broadcast_arrays: integer values of %s exceed 2^53' % k)
+            meta[0].append((k, a.shape, str(a.dtype)))
     dist.broadcast_object_list(meta, src=src, group=group)
     dev = _device_for_group(group)
     total = int(sum(int(np.prod(shape)) if len(shape) else 1 for _, shape, _ in meta[0]))
@@ -65,40 +87,89 @@ def broadcast_arrays(arrays, src=0, group=None):
 
 
 def gather_rows(local, counts, group=None):
-    """All-gather row blocks of unequal length (counts[r] rows on rank r): returns the concatenation on every rank."""
+    """All-gather row blocks of unequal length (counts[r] rows on rank r): returns the concatenation (numpy) on every
+    rank.  `local`: numpy array, torch tensor, or an object with `__cuda_array_interface__` (device memory of the sampler):
+    for an "nccl" group a device-resident block is gathered where it is."""
     import torch
     dist = _dist()
     world = dist.get_world_size(group)
     dev = _device_for_group(group)
-    local = np.ascontiguousarray(local, dtype=np.float64)
-    tail = local.shape[1:]
+    if hasattr(local, '__cuda_array_interface__') and dev.type == 'cuda':
+        t_local = torch.as_tensor(local, device=dev)
+    elif hasattr(local, '__cuda_array_interface__'):
+        raise TypeError('gather_rows: a device buffer needs an nccl process group')
+    elif isinstance(local, torch.Tensor):
+        t_local = local.to(dev, dtype=torch.float64)
+    else:
+        t_local = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64)).to(dev)
+    tail = tuple(t_local.shape[1:])
     width = int(np.prod(tail)) if len(tail) else 1
-    maxc = int(max(counts))
-    pad = np.zeros((maxc, width))
-    pad[:local.shape[0]] = local.reshape(local.shape[0], width)
-    t = torch.from_numpy(pad).to(dev)
-    outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t, group=group)
-    parts = [outs[r].cpu().numpy()[:counts[r]] for r in range(world)]
-    return np.concatenate(parts, axis=0).reshape((int(sum(counts)),) + tuple(tail))
+    maxc = int(max(counts)) if len(counts) else 0
+    if maxc == 0:
+        return np.zeros((0,) + tail)
+    pad = torch.zeros((maxc, width), dtype=torch.float64, device=dev)
+    if t_local.shape[0]:
+        pad[:t_local.shape[0]] = t_local.reshape(t_local.shape[0], width)
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad, group=group)
+    full = torch.cat([outs[r][:counts[r]] for r in range(world)], dim=0)
+    return full.cpu().numpy().reshape((int(sum(counts)),) + tail)
 
 
-def _gpu_sample_fn(problem_kwargs, spec, chain_ids, warmup, n_draws, seed, control):
-    """Default per-rank worker: build the problem in this rank's HBM and run the device-resident NUTS."""
-    import ctypes as C
-    from . import _lib
-    from .engine import sample_units
-    from .model import Problem
-    kw = dict(problem_kwargs)
-    blocks = kw.pop('blocks'); Z = kw.pop('Z'); freq = kw.pop('freq')
-    prob = Problem(blocks, Z, freq, **kw)
-    ctrl = _lib.NutsControl()
-    prob._lib.bdrt_nuts_defaults(C.byref(ctrl))
-    for k, v in (control or {}).items():
-        setattr(ctrl, k, v)
-    draws, lp, diag = sample_units(prob, len(spec), warmup, n_draws, seed, ctrl, spec=spec, chain_ids=chain_ids)
-    stats = np.array([[d['n_leapfrog'], d['n_divergent'], d['n_max_treedepth'], d['stepsize'], d['mean_accept']] for d in diag])
-    return draws, lp, stats
+class GpuWorker:
+    """Per-rank worker: the problem in this rank's HBM + the device-resident NUTS chains of this rank's units."""
+
+    def __init__(self, problem_kwargs):
+        from .model import Problem
+        kw = dict(problem_kwargs)
+        blocks = kw.pop('blocks'); Z = kw.pop('Z'); freq = kw.pop('freq')
+        self.problem = Problem(blocks, Z, freq, **kw)
+        self.D = self.problem.D
+        self.sampler = None
+
+    def run(self, spec, chain_ids, warmup, n_draws, seed, control):
+        import ctypes as C
+        from . import _lib
+        from .engine import Sampler
+        ctrl = _lib.NutsControl()
+        self.problem._lib.bdrt_nuts_defaults(C.byref(ctrl))
+        for k, v in (control or {}).items():
+            setattr(ctrl, k, v)
+        self.sampler = Sampler(self.problem, len(spec), warmup, n_draws, seed, ctrl, spec=spec, chain_ids=chain_ids)
+        self.sampler.run()
+        _, self._lp, diag = self.sampler.results(want_draws=False)
+        self._stats = np.array([[d['n_leapfrog'], d['n_divergent'], d['n_max_treedepth'], d['stepsize'], d['mean_accept']]
+                                for d in diag]).reshape(len(spec), 5)
+
+    def lp(self):
+        return self._lp
+
+    def stats(self):
+        return self._stats
+
+    def draws(self, device):
+        """[n_units, n_draws, D]: the device buffer itself for a cuda group, a host copy otherwise."""
+        if device.type == 'cuda':
+            return self.sampler.draws_device()
+        return self.sampler.results()[0]
+
+    def summary(self, unit_lo, unit_hi, q):
+        return self.sampler.summary(unit_lo, unit_hi, q)
+
+    def is_pos(self):
+        return self.problem.is_pos
+
+    @staticmethod
+    def reduce(block, is_pos, q):
+        """(mean [D], pct [len(q), D]) of the constrained parameters over the rows of `block` (unconstrained draws): the
+        arithmetic of `summary`, on host-resident draws (bdrt_summary)."""
+        from . import post
+        return post.summary(block, q, is_pos)
+
+    def close(self):
+        if self.sampler is not None:
+            self.sampler.close()
+        self.problem.close()
 
 
 def _pack_problem(problem_kwargs):
@@ -108,12 +179,18 @@ def _pack_problem(problem_kwargs):
     flat['n_blocks'] = np.array(len(blocks))
     for b, blk in enumerate(blocks):
         for k in ('A', 'L0', 'L1', 'L2'):
-            flat['b%d_%s' % (b, k)] = np.asarray(blk[k], dtype=np.float64)
+            a = np.asarray(blk[k])
+            if a.dtype.kind not in 'fiu':
+                raise TypeError('problem matrix %s of block %d must be real (got %s)' % (k, b, a.dtype))
+            flat['b%d_%s' % (b, k)] = a.astype(np.float64)
         flat['b%d_flags' % b] = np.array([float(bool(blk.get('parallel', False))), float(bool(blk.get('nonneg', False))),
                                          float(blk.get('x_scale', 1.0))])
     for k, v in kw.items():
         if v is not None:
-            flat['kw_' + k] = np.asarray(v, dtype=np.float64)
+            a = np.asarray(v)
+            if a.dtype.kind not in 'fiub':
+                raise TypeError('problem entry %s must be real (got %s)' % (k, a.dtype))
+            flat['kw_' + k] = a.astype(np.float64)
     return flat
 
 
@@ -133,35 +210,74 @@ def _unpack_problem(flat):
 
 
 def sample_sharded(problem_kwargs, n_spectra, chains, warmup, n_draws, seed=1234, control=None, group=None,
-                   sample_fn=None):
+                   worker_cls=None, gather='draws', q=(2.5, 50.0, 97.5)):
     """Sample `chains` chains for each of `n_spectra` spectra on all ranks of the process group.
 
     problem_kwargs (needed on rank 0 only; other ranks may pass None): dict(blocks=[...], Z=[n_spectra x 2nf], freq=...,
-    **scalars) as for model.Problem.  Returns on every rank (draws [n_units, n_draws, D], lp [n_units, n_draws],
-    stats [n_units, 5]) in unit order (spectrum-major), identical for any world size."""
+    **scalars) as for model.Problem.  Returns, identically on every rank and for any world size, a dict with
+      stats [n_units, 5]   per chain: leapfrogs, divergent, max-treedepth hits, step size, mean accept (unit order)
+      lp    [n_units, n_draws]
+      mean  [n_spectra, D], pct [n_spectra, len(q), D]   posterior summary of the CONSTRAINED parameters per spectrum
+      draws [n_units, n_draws, D] (unconstrained)        only with gather='draws'
+    gather='summary' moves n_spectra*(1+len(q))*D numbers instead of the draws; when the chains of a
+    spectrum are spread over ranks (fewer spectra than ranks) the summary needs all of them, so the draws are gathered
+    in that case regardless."""
+    if gather not in ('draws', 'summary'):
+        raise ValueError("gather must be 'draws' or 'summary'")
     dist = _dist()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     flat = broadcast_arrays(_pack_problem(problem_kwargs) if rank == 0 else None, src=0, group=group)
     kw = _unpack_problem(flat)
+    dev = _device_for_group(group)
+    q = [float(v) for v in np.atleast_1d(q)]
     spec, chain = make_units(n_spectra, chains)
-    bounds = [shard_bounds(n_spectra, world, r) for r in range(world)]        # whole spectra per rank
-    s0, s1 = bounds[rank]
-    sel = (spec >= s0) & (spec < s1)
-    fn = sample_fn or _gpu_sample_fn
-    if s1 > s0:
+    parts = partition_units(n_spectra, chains, world)
+    u0, u1 = parts[rank]
+    whole = n_spectra >= world                                     # every spectrum lives on exactly one rank
+    counts = [hi - lo for lo, hi in parts]
+    cls = worker_cls or GpuWorker
+    worker = None
+    D = None
+    if u1 > u0:
+        s0, s1 = int(spec[u0]), int(spec[u1 - 1]) + 1
         local_kw = dict(kw)
-        local_kw['Z'] = np.atleast_2d(kw['Z'])[s0:s1]                          # only this rank's spectra go to HBM
-        draws, lp, stats = fn(local_kw, spec[sel] - s0, chain[sel], warmup, n_draws, seed, control)
+        local_kw['Z'] = np.atleast_2d(kw['Z'])[s0:s1]                # only this rank's spectra go to HBM
+        worker = cls(local_kw)
+        worker.run(spec[u0:u1] - s0, chain[u0:u1], warmup, n_draws, seed, control)
+        D = int(worker.D)
+    # ranks without work learn D (and which parameters are <lower=0>) from the first rank that has some
+    owners = [r for r in range(world) if counts[r] > 0]
+    if not owners:
+        return dict(stats=np.zeros((0, 5)), lp=np.zeros((0, n_draws)), mean=np.zeros((0, 0)), pct=np.zeros((0, len(q), 0)),
+                    draws=np.zeros((0, n_draws, 0)))
+    dd = [(D, np.asarray(worker.is_pos(), dtype=bool).tolist()) if worker is not None else None]
+    dist.broadcast_object_list(dd, src=owners[0], group=group)
+    D, is_pos = int(dd[0][0]), np.asarray(dd[0][1], dtype=bool)
+    out = {}
+    out['stats'] = gather_rows(worker.stats() if worker else np.zeros((0, 5)), counts, group)
+    out['lp'] = gather_rows(worker.lp() if worker else np.zeros((0, n_draws)), counts, group)
+    need_draws = gather == 'draws' or not whole
+    if need_draws:
+        local = worker.draws(dev) if worker else np.zeros((0, n_draws, D))
+        out['draws'] = gather_rows(local, counts, group)
+    if whole:
+        # per-spectrum summaries reduced where the draws are; gather [1 + nq, D] per spectrum
+        ns_local = (u1 - u0) // chains
+        loc = np.zeros((ns_local, 1 + len(q), D))
+        for i in range(ns_local):
+            m, p = worker.summary(i * chains, (i + 1) * chains, q)
+            loc[i, 0], loc[i, 1:] = m, p
+        summ = gather_rows(loc, [c // chains for c in counts], group)
+        out['mean'], out['pct'] = summ[:, 0], summ[:, 1:]
     else:
-        D = None
-        draws = lp = stats = None
-    # agree on D for ranks without work
-    dd = [None]
-    if rank == 0:
-        dd[0] = int(draws.shape[2])
-    dist.broadcast_object_list(dd, src=0, group=group)
-    D = dd[0]
-    if draws is None:
-        draws, lp, stats = np.zeros((0, n_draws, D)), np.zeros((0, n_draws)), np.zeros((0, 5))
-    counts = [(b[1] - b[0]) * chains for b in bounds]
-    return (gather_rows(draws, counts, group), gather_rows(lp, counts, group), gather_rows(stats, counts, group))
+        # the chains of a spectrum are on several ranks: reduce the gathered draws (every rank, same arithmetic)
+        mean = np.empty((n_spectra, D)); pct = np.empty((n_spectra, len(q), D))
+        for sidx in range(n_spectra):
+            block = out['draws'][sidx * chains:(sidx + 1) * chains].reshape(chains * n_draws, D)
+            mean[sidx], pct[sidx] = cls.reduce(block, is_pos, q)
+        out['mean'], out['pct'] = mean, pct
+        if gather == 'summary':
+            out.pop('draws')
+    if worker is not None:
+        worker.close()
+    return out

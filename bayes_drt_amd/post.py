@@ -8,7 +8,7 @@ import numpy as np
 
 from . import _lib
 
-MAX_ROWS = 16384
+LDS_ROWS = 16384      # columns up to this many draws are sorted in LDS; longer ones in an HBM scratch (no limit)
 
 
 def _ptr(a):
@@ -36,9 +36,6 @@ def project_percentile(samples, Phi, bias, q):
         lead = None
     X = np.ascontiguousarray(X)
     rows, K = X.shape
-    if rows > MAX_ROWS:
-        raise _lib.BdrtError('percentile: %d sample rows; the device kernel sorts one column in LDS (max %d rows)'
-                             % (rows, MAX_ROWS))
     qa = np.atleast_1d(np.asarray(q, dtype=np.float64))
     if np.any(qa < 0) or np.any(qa > 100):
         raise ValueError('Percentiles must be in the range [0, 100]')
@@ -62,3 +59,25 @@ def project_percentile(samples, Phi, bias, q):
     if one_d and Phi is None:
         out = out[:, 0]
     return out[0] if np.ndim(q) == 0 else out
+
+
+def summary(draws, q, is_pos=None):
+    """(mean [K], pct [len(q), K]) over the rows of `draws` [rows x K] after exp() of the columns flagged in `is_pos`
+    (constrained scale of Stan <lower=0> parameters): np.mean / np.percentile of the reference (inversion.py:2517-2519,
+    :2560) in one device pass -- the host-buffer form of bdrt_sampler_summary."""
+    lib = _lib.require_gpu()
+    X = np.ascontiguousarray(np.asarray(draws, dtype=np.float64))
+    if X.ndim != 2:
+        raise ValueError('summary: draws must be [rows x K]')
+    rows, K = X.shape
+    qa = np.ascontiguousarray(np.atleast_1d(np.asarray(q, dtype=np.float64)))
+    if np.any(qa < 0) or np.any(qa > 100):
+        raise ValueError('Percentiles must be in the range [0, 100]')
+    mask = None
+    if is_pos is not None:
+        mask = np.ascontiguousarray(np.asarray(is_pos, dtype=np.uint8))
+        if mask.shape != (K,):
+            raise ValueError('summary: is_pos must have one entry per column')
+    mean = np.empty(K); pct = np.empty((qa.size, K))
+    _lib.check(lib.bdrt_summary(_ptr(X), rows, K, K, _ptr(mask), _ptr(qa), qa.size, _ptr(mean), _ptr(pct)), 'bdrt_summary')
+    return mean, pct

@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- HMC log-posterior+gradient evaluations per second, 81 frequencies x 161 tau-basis (BASELINE.json).
 
-Workload (config.workload): BASELINE config 4 sharded the weak-scaling way -- every GPU samples the SAME batch of
-512 synthetic 2-ZARC spectra (shared frequency / tau grids => one A/L set in HBM) with 8 NUTS chains per spectrum
-(4096 units per GPU = 16 chains on each of the 256 CUs; rank r owns chain ids 8r..8r+7, so 4 GPUs = "32 chains
-total" per spectrum, 8 GPUs = 64).  `--chains 4` gives the 2048-unit variant (half of the CUs idle).  Model
-Series_pos, D = 331, sampling-mode hyper-parameters.  Each unit is a real NUTS chain (device-resident
-transitions, bdrt_nuts.hip); a "step" is one leapfrog round: every unit performs one log-posterior+gradient
-evaluation inside its current tree.  No data-path collective: units are independent.
+Workload (config.workload): BASELINE config 4, weak scaling -- every GPU holds its own shard of 512 synthetic 2-ZARC
+spectra (shared frequency / tau grids => one A/L set in HBM) with 8 NUTS chains per spectrum = 4096 units per GPU = 16
+chains on each of the 256 CUs.  With N GPUs the job is 512*N spectra, partitioned by `parallel.partition_units`
+(whole spectra per rank -- the function `parallel.sample_sharded` uses), so rank r samples spectra [512 r, 512 (r+1)).
+Model Series_pos, D = 331, sampling-mode hyper-parameters.  Each unit is a real NUTS chain (device-resident
+transitions, bdrt_nuts.hip).  No data-path collective: units are independent.
+
+A STEP is one launch of the sampler kernel that advances every chain by `--rounds` (default 1000) leapfrogs: one
+log-posterior+gradient evaluation per unit and round inside the chain's current tree.  With the driver's
+`--steps 20 --warmup 5` the timed region is 20 000 rounds (~0.7 s) after 5 000 warm-up rounds (initial points, step-size
+search and the first transitions are behind every chain).
 
 Prints ONE JSON line (rank 0).  `value` = gradient evaluations actually executed by all ranks during the timed
-region / wall time (max over ranks).  `roofline` is for the dominant kernel (nuts_kernel): achieved = algorithmic
-FLOPs per launch (4.27e5 per evaluation) / HIP-event launch duration.  `cpu_baseline` = the CPU
-oracle (plain C port of the same log-posterior+gradient) timed on this box's host cores, one process per core.
+region (device counter) / wall time (max over ranks).  `roofline` is for the dominant kernel (nuts_kernel):
+achieved = algorithmic FLOPs per launch (4.27e5 per evaluation) / HIP-event launch duration on the
+sampler's stream.  `cpu_baseline` = the CPU oracle (plain C port of the same log-posterior+gradient, -O3 -march=native)
+inside the oracle's NUTS driver, timed on this box's host cores: one core, and one chain per core on all cores.
+N > 1 additionally times, outside the steady-state region, one complete `parallel.sample_sharded` call (broadcast of
+the problem + short run + gather of per-spectrum summaries over RCCL) and reports it in `config.dist_roundtrip`.
 """
 import argparse
 import ctypes as C
@@ -28,18 +35,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_EVAL = 4.27e5      # 4*(2Nf*K + 3K^2) + ~12k element-wise, Nf=81, K=161
-BYTES_PER_EVAL = 8.39e5     # unique operand bytes when B = 1
 # what the structured path really executes per evaluation on a log-uniform grid: A GEMMs on padded 176 x 168 tiles
-# (2 * 462 MFMA * 2048 flop / 16 chains = 1.18e5) + six 17-tap convolutions (3.3e4) + ~1.5e4 element-wise
+# (2 * 462 MFMA * 2048 flop / 16 chains = 1.18e5) + six banded convolutions + ~1.5e4 element-wise
 FLOP_PER_EVAL_EXECUTED = 1.66e5
 PEAK_F64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix peak; measured 78.05 by tools/mfma_probe (profiles/)
 NF, K = 81, 161
 N_SPECTRA, CHAINS_PER_SPECTRUM = 512, 8
-ROUNDS_PER_LAUNCH = 50
+ROUNDS_PER_STEP = 1000
+# BASELINE.md section 1 / SURVEY section 6: derived from the reference's notebook (4 chains x 1000 iterations in 515 s at
+# K = 81 => 6-8 k evals/s over 4 processes), scaled by the dense work ratio to K = 161.  NOT measured here: pystan
+# cannot be installed on this box.
+PYSTAN_DERIVED = {'value': 2250.0, 'unit': 'evals/s', 'processes': 4,
+                  'source': 'derived from reference notebook timings (Run fits.ipynb cell 6: 4x1000 iterations, 515 s, '
+                            'K=81), scaled to K=161; not measured on this box'}
 
 
 def synth_spectra(n, seed=20260101):
-    """512 two-ZARC spectra, parameters per SURVEY 8(d) config 4; noise models cycled uniform/Orazem/Macdonald 0.25 %."""
+    """n two-ZARC spectra, parameters per SURVEY 8(d) config 4; noise models cycled uniform/Orazem/Macdonald 0.25 %."""
     rs = np.random.RandomState(seed)
     f = np.logspace(6, -2, NF)
     w = 2 * np.pi * f
@@ -64,10 +76,7 @@ def synth_spectra(n, seed=20260101):
     return f, Z
 
 
-def cpu_baseline(seconds=12.0):
-    """Oracle log_prob+grad evaluations/s on the host cores: one worker process per core (pystan's own layout)."""
-    ncores = min(os.cpu_count() or 1, 16)
-    code = r'''
+_CPU_WORKER = r'''
 import sys, time, numpy as np
 sys.path.insert(0, %r)
 from oracle import oracle as orc
@@ -77,15 +86,22 @@ tau = 1 / (2 * np.pi * np.logspace(10, -6, K)); eps = 1 / np.mean(np.diff(np.log
 A = np.vstack([orc.construct_A(f, 'real', tau=tau, epsilon=eps), orc.construct_A(f, 'imag', tau=tau, epsilon=eps)])
 blk = dict(A=A, L0=orc.construct_L(tau, eps, 0), L1=orc.construct_L(tau, eps, 1), L2=0.75 * orc.construct_L(tau, eps, 2), nonneg=True)
 m = orc.OracleModel([blk], Z[0], f, ups_alpha=1.0, ups_beta=0.1)
-th = np.random.RandomState(int(sys.argv[1])).uniform(-1, 1, m.D)
-orc.eval_loop(m, th, 50)
-n = 0; t0 = time.perf_counter()
-while time.perf_counter() - t0 < float(sys.argv[2]):
-    orc.eval_loop(m, th, 500); n += 500
+ctrl = orc.nuts_control(adapt_delta=0.9, adapt_t0=10.0)
+chain, budget = int(sys.argv[1]), float(sys.argv[2])
+n = 0; t0 = time.perf_counter(); it = 6
+# the oracle's own NUTS driver (oracle/nuts_oracle.c), warm-up transitions of a real chain; repeated with a fresh chain id
+# and a doubled iteration count until the time budget is used
+while time.perf_counter() - t0 < budget:
+    _, _, d = orc.nuts_sample(m, chain, 1234, it, 0, control=ctrl)
+    n += d['n_leapfrog']; chain += 1000; it = min(2 * it, 48)
 print(n, time.perf_counter() - t0)
 ''' % ROOT
-    procs = [subprocess.Popen([sys.executable, '-c', code, str(i), str(seconds)], stdout=subprocess.PIPE,
-                              stderr=subprocess.PIPE, cwd=ROOT) for i in range(ncores)]
+
+
+def _cpu_leg(nproc, seconds):
+    env = dict(os.environ, BDRT_ORACLE_NATIVE='1')
+    procs = [subprocess.Popen([sys.executable, '-c', _CPU_WORKER, str(i), str(seconds)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, cwd=ROOT, env=env) for i in range(nproc)]
     total = 0.0
     for p in procs:
         out, err = p.communicate()
@@ -93,20 +109,53 @@ print(n, time.perf_counter() - t0)
             raise RuntimeError('cpu_baseline worker failed: ' + err.decode()[-400:])
         n, t = out.decode().split()
         total += float(n) / float(t)
-    return dict(value=total, unit='evals/s', cores=ncores, kind='port',
-                sample='%d processes x %.0f s of oracle/bdrt_oracle.c log_prob+grad (Series_pos, 81x161, jacobian on), '
-                       'plain C -O2, one process per core' % (ncores, seconds))
+    return total
+
+
+def cpu_baseline(seconds=8.0):
+    """Oracle log_prob+grad evaluations/s inside the oracle's NUTS driver on the host cores: one core, then one chain
+    per core (pystan's own layout: one process per chain)."""
+    from oracle import oracle as orc
+    orc.build(force=True, native=True)           # -O3 -march=native for THIS host (the checker build is untouched)
+    ncores = min(os.cpu_count() or 1, 16)
+    single = _cpu_leg(1, seconds)
+    allc = _cpu_leg(ncores, seconds)
+    model = ''
+    try:
+        with open('/proc/cpuinfo') as fh:
+            model = next((ln.split(':', 1)[1].strip() for ln in fh if ln.startswith('model name')), '')
+    except OSError:
+        pass
+    return dict(value=allc, unit='evals/s', cores=ncores, kind='port', single_core=single, cpu_model=model,
+                pystan_derived=PYSTAN_DERIVED,
+                sample='leapfrogs of real NUTS warm-up transitions (oracle/nuts_oracle.c driving oracle/bdrt_oracle.c, '
+                       'Series_pos 81x161, jacobian on), gcc -O3 -march=native: 1 process x %.0f s (single_core), then %d '
+                       'processes x %.0f s, one chain per core (value)' % (seconds, ncores, seconds))
+
+
+def build_problem_kwargs(n_spectra, lib=None):
+    """Global problem of the benchmark: shared 81 x 161 grids, matrices built on the GPU, n_spectra synthetic spectra."""
+    from bayes_drt_amd import matrices as gm
+    f, Z = synth_spectra(n_spectra)
+    basis_freq = np.logspace(10, -6, K)
+    tau = 1 / (2 * np.pi * basis_freq)
+    eps = 1 / np.mean(np.diff(np.log(tau)))
+    A = np.vstack([gm.construct_A(f, 'real', tau=tau, epsilon=eps), gm.construct_A(f, 'imag', tau=tau, epsilon=eps)])
+    L = [gm.construct_L(basis_freq, tau=tau, epsilon=eps, order=o) for o in (0, 1, 2)]
+    blk = dict(A=A, L0=L[0], L1=L[1], L2=0.75 * L[2], nonneg=True)       # sample-mode scaling (inversion.py:1725-1730)
+    return dict(blocks=[blk], Z=Z, freq=f, sigma_min=0.002, ups_alpha=1.0, ups_beta=0.1, induc_scale=1.0)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20000)
-    ap.add_argument('--warmup', type=int, default=2000)
-    ap.add_argument('--spectra', type=int, default=N_SPECTRA)
+    ap.add_argument('--steps', type=int, default=20, help='timed launches of --rounds leapfrog rounds each')
+    ap.add_argument('--warmup', type=int, default=5, help='untimed launches before the timed region')
+    ap.add_argument('--rounds', type=int, default=ROUNDS_PER_STEP, help='leapfrog rounds per launch (= per step)')
+    ap.add_argument('--spectra', type=int, default=N_SPECTRA, help='spectra per GPU')
     ap.add_argument('--chains', type=int, default=CHAINS_PER_SPECTRUM)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--cpu-seconds', type=float, default=8.0)
     ap.add_argument('--phase-profile', action='store_true', help='print the in-kernel cycle breakdown (perturbs timing)')
     args = ap.parse_args()
 
@@ -119,8 +168,6 @@ def main():
     # CPU baseline first (rank 0, N=1 only), before this process touches the GPU: workers are plain subprocesses
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as orc
-        orc.build()
         cpu = cpu_baseline(args.cpu_seconds)
 
     import torch
@@ -133,83 +180,88 @@ def main():
     if use_dist:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
-    from bayes_drt_amd import _lib, matrices as gm
-    from bayes_drt_amd._lib import NutsControl, check, ptr
+    from bayes_drt_amd import _lib, parallel as par
+    from bayes_drt_amd._lib import NutsControl, check
+    from bayes_drt_amd.engine import Sampler
     from bayes_drt_amd.model import Problem
     lib = _lib.require_gpu()
     check(lib.bdrt_set_device(local_rank), 'bdrt_set_device')
 
-    # ---- problem: matrices built on the GPU, 512 spectra resident in HBM ----
-    f, Z = synth_spectra(args.spectra)
-    basis_freq = np.logspace(10, -6, K)
-    tau = 1 / (2 * np.pi * basis_freq)
-    eps = 1 / np.mean(np.diff(np.log(tau)))
-    A = np.vstack([gm.construct_A(f, 'real', tau=tau, epsilon=eps), gm.construct_A(f, 'imag', tau=tau, epsilon=eps)])
-    L = [gm.construct_L(basis_freq, tau=tau, epsilon=eps, order=o) for o in (0, 1, 2)]
-    blk = dict(A=A, L0=L[0], L1=L[1], L2=0.75 * L[2], nonneg=True)       # sample-mode scaling (inversion.py:1725-1730)
-    prob = Problem([blk], Z, f, sigma_min=0.002, ups_alpha=1.0, ups_beta=0.1, induc_scale=1.0)
+    # ---- the job: args.spectra * world spectra, partitioned like parallel.sample_sharded does (whole spectra per rank) ----
+    n_global = args.spectra * world
+    t_setup0 = time.perf_counter()
+    if use_dist:
+        kw = par._unpack_problem(par.broadcast_arrays(par._pack_problem(build_problem_kwargs(n_global)) if rank == 0 else None, src=0))
+    else:
+        kw = build_problem_kwargs(n_global)
+    spec, chain = par.make_units(n_global, args.chains)
+    u0, u1 = par.partition_units(n_global, args.chains, world)[rank]
+    s0, s1 = int(spec[u0]), int(spec[u1 - 1]) + 1
+    local_kw = dict(kw); blocks = local_kw.pop('blocks'); Zall = local_kw.pop('Z'); freq = local_kw.pop('freq')
+    prob = Problem(blocks, np.atleast_2d(Zall)[s0:s1], freq, **local_kw)
     assert prob.D == 2 * K + 9
-
-    n_units = args.spectra * args.chains
-    spec = np.repeat(np.arange(args.spectra, dtype=np.int32), args.chains)
-    chain_id = np.tile(np.arange(args.chains, dtype=np.int32), args.spectra) + rank * args.chains
+    n_units = u1 - u0
     ctrl = NutsControl()
     lib.bdrt_nuts_defaults(C.byref(ctrl))
     ctrl.adapt_delta, ctrl.adapt_t0 = 0.9, 10.0                          # inversion.py:1221
     # warm-up long enough that no chain finishes inside the benchmark (adaptation windows at 100, 150, 250, ...)
-    h = lib.bdrt_sampler_create(prob.handle, n_units, ptr(spec), ptr(chain_id), 1000000, 1, C.c_uint64(1234), None,
-                                C.byref(ctrl))
-    if not h:
-        raise SystemExit('bdrt_sampler_create: ' + lib.bdrt_last_error().decode())
-
-    def advance(rounds):
-        left = rounds
-        while left > 0:
-            r = min(ROUNDS_PER_LAUNCH, left)
-            check(lib.bdrt_sampler_advance(h, r, None), 'bdrt_sampler_advance')
-            left -= r
+    smp = Sampler(prob, n_units, 1000000, 1, 1234, ctrl, spec=spec[u0:u1] - s0, chain_ids=chain[u0:u1])
+    setup_ms = (time.perf_counter() - t_setup0) * 1e3
 
     def sync_all():
-        check(lib.bdrt_sampler_sync(h), 'bdrt_sampler_sync')
+        smp.sync()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
 
-    advance(args.warmup)
+    for _ in range(args.warmup):
+        smp.advance(args.rounds)
     sync_all()
     if args.phase_profile:
-        check(lib.bdrt_sampler_phase_profile(h, 1, None), 'phase_profile')
-    ms0 = C.c_double(); nl0 = C.c_int64()
-    check(lib.bdrt_sampler_kernel_time(h, C.byref(ms0), C.byref(nl0), 1), 'kernel_time')
-    n0 = lib.bdrt_sampler_total_leapfrogs(h)
+        check(lib.bdrt_sampler_phase_profile(smp.handle, 1, None), 'phase_profile')
+    smp.kernel_time(reset=True)
+    n0 = smp.total_leapfrogs()
     sync_all()
     t0 = time.perf_counter()
-    advance(args.steps)
-    check(lib.bdrt_sampler_sync(h), 'bdrt_sampler_sync')
+    for _ in range(args.steps):
+        smp.advance(args.rounds)
+    smp.sync()
     torch.cuda.synchronize()
-    t1 = time.perf_counter()
     if use_dist:
         dist.barrier()
-    elapsed = t1 - t0
-    n1 = lib.bdrt_sampler_total_leapfrogs(h)
-    ms = C.c_double(); nl = C.c_int64()
-    check(lib.bdrt_sampler_kernel_time(h, C.byref(ms), C.byref(nl), 0), 'kernel_time')
+    elapsed = time.perf_counter() - t0
+    n1 = smp.total_leapfrogs()
+    ms_total, launches = smp.kernel_time()
     evals = float(n1 - n0)
     if args.phase_profile and rank == 0:
         cyc = (C.c_longlong * 32)()
-        check(lib.bdrt_sampler_phase_profile(h, 0, cyc), 'phase_profile')
+        check(lib.bdrt_sampler_phase_profile(smp.handle, 0, cyc), 'phase_profile')
         names = ['tile:scalars', 'tile:x', 'tile:gemmA', 'tile:Zacc', 'tile:likelihood', 'tile:x2', 'tile:gemmL',
                  'tile:prior', 'tile:gemmBwd', 'tile:epilogue', 'nuts:A kick-drift', 'nuts:C kick+kin', 'nuts:S1',
                  'nuts:D tree', 'nuts:S2', 'nuts:E next', 'nuts:S3']
         tot = float(sum(cyc[:17])) or 1.0
         n_wg = (n_units + 15) // 16
+        rounds_total = args.steps * args.rounds
         for k, nm in enumerate(names):
-            print('PHASE %-20s %6.2f %%  %9.0f cycles/round' % (nm, 100 * cyc[k] / tot, cyc[k] / n_wg / args.steps), file=sys.stderr)
+            print('PHASE %-20s %6.2f %%  %9.0f cycles/round' % (nm, 100 * cyc[k] / tot, cyc[k] / n_wg / rounds_total), file=sys.stderr)
         wnames = ['tile', 'C', 'S1', 'D', "A'", "E+S3+A''", 'end-of-round barrier wait']
         for k, nm in enumerate(wnames):
-            print('WAVE-AVG %-26s %9.0f cycles/round' % (nm, cyc[17 + k] / n_wg / args.steps / 8), file=sys.stderr)
-        print('half-waves per round in stage E (new start point): %.2f of 16' % (cyc[24] / n_wg / args.steps * 2), file=sys.stderr)
-    lib.bdrt_sampler_destroy(h)
+            print('WAVE-AVG %-26s %9.0f cycles/round' % (nm, cyc[17 + k] / n_wg / rounds_total / 8), file=sys.stderr)
+        print('half-waves per round in stage E (new start point): %.2f of 16' % (cyc[24] / n_wg / rounds_total * 2), file=sys.stderr)
+    smp.close()
+
+    # ---- N > 1: one complete sample_sharded call (broadcast + short run + summary gather), timed apart from the rate ----
+    roundtrip = None
+    if use_dist:
+        small = dict(kw, Z=np.atleast_2d(Zall)[:8 * world]) if rank == 0 else None
+        dist.barrier()
+        t_rt = time.perf_counter()
+        res = par.sample_sharded(small, 8 * world, args.chains, 6, 4, seed=1234, control={'max_treedepth': 5},
+                                 gather='summary')
+        torch.cuda.synchronize()
+        dist.barrier()
+        roundtrip = {'ms': (time.perf_counter() - t_rt) * 1e3, 'spectra': 8 * world, 'chains': args.chains,
+                     'warmup': 6, 'draws': 4, 'gather': 'summary', 'finite': bool(np.all(np.isfinite(res['mean'])))}
 
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
@@ -220,8 +272,8 @@ def main():
 
     if rank == 0:
         value = evals / elapsed
-        launches = max(int(nl.value), 1)
-        avg_ms = ms.value / launches
+        launches = max(launches, 1)
+        avg_ms = ms_total / launches
         evals_per_launch = (n1 - n0) / launches                       # this rank's launches
         achieved = evals_per_launch * FLOP_PER_EVAL / (avg_ms * 1e-3) / 1e12
         traffic = None
@@ -236,17 +288,20 @@ def main():
             'value': value, 'unit': 'evals/s', 'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'config4-shard: %d synthetic 2-ZARC spectra x %d NUTS chains per GPU (%d units/GPU), '
-                                   'Series_pos 81x161 (D=331), real NUTS transitions, step = one leapfrog round'
-                                   % (args.spectra, args.chains, n_units),
-                       'units_per_gpu': n_units, 'rounds_per_launch': ROUNDS_PER_LAUNCH,
-                       'evals_in_timed_region': evals},
+            'config': {'workload': 'config4-shard: %d synthetic 2-ZARC spectra x %d NUTS chains per GPU (%d units/GPU; %d '
+                                   'spectra over %d GPU(s), whole spectra per rank), Series_pos 81x161 (D=331), real NUTS '
+                                   'transitions; step = one launch of %d leapfrog rounds'
+                                   % (args.spectra, args.chains, n_units, n_global, world, args.rounds),
+                       'units_per_gpu': n_units, 'rounds_per_launch': args.rounds,
+                       'evals_in_timed_region': evals, 'timed_region_s': elapsed, 'setup_ms': setup_ms},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F64_MFMA_TFLOPS, 'traffic': traffic,
                          'kernel': 'nuts_kernel', 'avg_launch_ms': avg_ms, 'launches': launches,
-                         'hbm_frac_B1_accounting': value / args.gpus * BYTES_PER_EVAL / 8e12,
+                         'flop_per_eval_algorithmic': FLOP_PER_EVAL,
                          'executed_tflops_structured_path': achieved * FLOP_PER_EVAL_EXECUTED / FLOP_PER_EVAL},
         }
+        if roundtrip is not None:
+            line['config']['dist_roundtrip'] = roundtrip
         if cpu is not None:
             line['cpu_baseline'] = cpu
         print(json.dumps(line))

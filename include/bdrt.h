@@ -209,13 +209,26 @@ int bdrt_qp_box_batch(const double *P, const double *q, const double *lo, int n,
  * out[nq x ncols] (row-major) = percentile q[t] (0..100, numpy's default 'linear' rule, same lerp formula) over the
  * `rows` samples of every column of Y, where Y = X (Phi == NULL, ncols = K) or Y = X Phi^T + bias (Phi is [M x K]
  * row-major, bias [M] or NULL, ncols = M).  X is [rows x K] with row stride ldx >= K (doubles).  A column that
- * contains a NaN yields NaN (numpy behaviour).  rows <= 16384 per call (one column is sorted in LDS). */
+ * contains a NaN yields NaN (numpy behaviour).  Columns of up to 16384 samples are sorted in LDS, longer ones in an HBM
+ * scratch buffer (np.percentile has no row limit either). */
 int bdrt_percentiles(const double *X, int rows, int K, long ldx, const double *Phi, int M, const double *bias,
                      const double *q, int nq, double *out);
 /* The same on the draws a sampler holds on the device (unconstrained parameters theta): samples = all draws of units
  * [unit_lo, unit_hi), columns [col0, col0 + ncols) of theta.  The draws are not copied to the host. */
 int bdrt_sampler_percentiles(bdrt_sampler *s, int unit_lo, int unit_hi, int col0, int ncols, const double *Phi, int M,
                              const double *bias, const double *q, int nq, double *out);
+
+/* Per-spectrum posterior summary on the CONSTRAINED scale (what the reference reduces fit['x'], fit['Rinf'], ... to:
+ * np.mean(..., axis=0) inversion.py:2517-2519 and np.percentile(..., q, axis=0) :2560): samples = all draws of units
+ * [unit_lo, unit_hi); <lower=0> parameters are exp(theta).  mean [D] (may be NULL), pct [nq x D].  This is what a
+ * multi-GPU run gathers instead of raw draws. */
+int bdrt_sampler_summary(bdrt_sampler *s, int unit_lo, int unit_hi, const double *q, int nq, double *mean, double *pct);
+/* the same reduction on host-resident draws X [rows x K] (row stride ldx): is_pos[K] flags the exp() columns (NULL: none) */
+int bdrt_summary(const double *X, int rows, int K, long ldx, const unsigned char *is_pos, const double *q, int nq,
+                 double *mean, double *pct);
+/* device pointer of the draws [n_units x n_draws x D] (unconstrained), valid until bdrt_sampler_destroy: lets a
+ * collective library (RCCL) gather draws without a host round trip.  Synchronises the sampler's stream. */
+const double *bdrt_sampler_draws_dev(bdrt_sampler *s);
 
 /* ---- misc ----------------------------------------------------------------------------------------- */
 const char *bdrt_last_error(void);

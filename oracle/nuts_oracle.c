@@ -155,10 +155,13 @@ static int build_tree(nctx *x, int depth, double *rho, double *psl, double *psr)
 typedef struct { int counter, size, next, init_buffer, term_buffer, base_window; } win_t;
 static void win_init(win_t *w, int warmup, int ib, int tb, int bw)
 {
-    if (warmup < 20) { ib = warmup; tb = 0; bw = 0; }
+    /* num_warmup < 20: stan::mcmc::windowed_adaptation::set_window_params returns early, its unsigned next-window index
+       stays at UINT_MAX and neither the metric nor the step-size restart is ever triggered */
+    const int no_metric = warmup < 20;
+    if (no_metric) { ib = warmup; tb = 0; bw = 0; }
     else if (ib + bw + tb > warmup) { ib = (int)(0.15 * warmup); tb = (int)(0.1 * warmup); bw = warmup - (ib + tb); }
     w->init_buffer = ib; w->term_buffer = tb; w->base_window = bw;
-    w->counter = 0; w->size = bw; w->next = ib + bw - 1;
+    w->counter = 0; w->size = bw; w->next = no_metric ? -1 : ib + bw - 1;
 }
 static int win_active(const win_t *w, int warmup) { return w->counter >= w->init_buffer && w->counter < warmup - w->term_buffer && w->counter != warmup; }
 static int win_end(const win_t *w, int warmup) { return w->counter == w->next && w->counter != warmup; }

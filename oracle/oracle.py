@@ -35,18 +35,24 @@ class _Model(C.Structure):
                 ('use_x_sum', C.c_int), ('x_sum_invscale', C.c_double)]
 
 
-def build(force=False):
-    so = os.path.join(_HERE, 'liboracle.so')
+def build(force=False, native=False):
+    """liboracle.so (the checker, -O2, host independent) or, native=True, liboracle_native.so (-O3 -march=native: the CPU
+    baseline of bench.py; always rebuilt with force=True there because -march=native code does not travel)."""
+    name = 'liboracle_native.so' if native else 'liboracle.so'
+    so = os.path.join(_HERE, name)
     srcs = [os.path.join(_HERE, f) for f in ('bdrt_oracle.c', 'bdrt_oracle.h', 'nuts_oracle.c')]
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(['make', '-s', '-C', _HERE, 'liboracle.so'])
+    if force and os.path.exists(so):
+        os.remove(so)
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(['make', '-s', '-C', _HERE, name])
     return so
 
 
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        # BDRT_ORACLE_NATIVE=1 (set by bench.py's cpu_baseline workers only): the -O3 -march=native build
+        _LIB = C.CDLL(build(native=bool(os.environ.get('BDRT_ORACLE_NATIVE'))))
         _LIB.orc_num_params.restype = C.c_int
         _LIB.orc_logp_grad.restype = C.c_int
         _LIB.orc_forward.restype = C.c_int

@@ -309,7 +309,51 @@ def gen_predict():
          **{'err_' + k: np.array(v) for k, v in inv.error_fit.items()})
 
 
+def gen_host():
+    """Host-logic leaves of the Inverter: _format_weights (inversion.py:2338-2395) for every scheme x part, the
+    distribution dicts set_distributions produces (:66-127), and _scale_Z's admittance branch (:2417-2434)."""
+    from bayes_drt.inversion import Inverter
+    f, Z = read_Z(os.path.join(REF, 'data/simulated/Z_2ZARC_uniform_0.25.csv'))
+    inv = Inverter()
+    out = {'freq': f, 'Z': Z}
+    rs = np.random.RandomState(0)
+    arr_real = rs.uniform(0.5, 2.0, len(f))
+    arr_cplx = rs.uniform(0.5, 2.0, len(f)) + 1j * rs.uniform(0.5, 2.0, len(f))
+    cases = {'none': None, 'unity': 'unity', 'modulus': 'modulus', 'Orazem': 'Orazem', 'proportional': 'proportional',
+             'prop_adj': 'prop_adj', 'float': 0.7, 'int': 3, 'complex': 0.3 + 1.2j, 'array_real': arr_real,
+             'array_complex': arr_cplx}
+    out['arr_real'], out['arr_cplx'] = arr_real, arr_cplx
+    for name, w in cases.items():
+        for part in ('both', 'real', 'imag'):
+            try:
+                out['w_%s_%s' % (name, part)] = np.asarray(inv._format_weights(f, Z, w, part), dtype=complex)
+            except ValueError:
+                # numpy >= 1.25: `array == 'unity'` is element-wise and the reference's first test raises for array
+                # weights; those cases are checked by property in tests/test_inverter_host.py instead
+                pass
+    save('host_weights', **out)
+    # distribution dicts after the constructor's validation / default filling (values as strings: key=value;...)
+    dists = {'DRT': {'kernel': 'DRT'}, 'tp': {'kernel': 'DDT', 'bc': 'transmissive', 'dist_type': 'parallel'},
+             'bs': {'kernel': 'DDT', 'symmetry': 'spherical'}, 'ct': {'kernel': 'DDT', 'ct': True, 'k_ct': 2.0, 'dist_type': 'series'}}
+    res = {}
+    for name, info in dists.items():
+        got = Inverter(distributions={name: dict(info)}).distributions[name]
+        res[name] = ';'.join('%s=%s' % (k, got[k]) for k in sorted(got))
+    save('host_distributions', **{k: np.array(v) for k, v in res.items()})
+    # _scale_Z for a single parallel planar DDT (admittance scaling) -- transmissive and blocking targets
+    fz, Zz = read_Z(os.path.join(REF, 'data/simulated/Z_BimodalTP-DDT_uniform_0.25.csv'))
+    sc = {}
+    for bc in ('transmissive', 'blocking'):
+        iv = Inverter(distributions={'d': {'kernel': 'DDT', 'dist_type': 'parallel', 'symmetry': 'planar', 'bc': bc}})
+        Zs = iv._scale_Z(Zz, 'map')
+        sc['scale_' + bc] = np.array(iv._Z_scale)
+        sc['Zs_' + bc] = Zs
+        Zr = iv._scale_Z(Zz, 'ridge')
+        sc['scale_ridge_' + bc] = np.array(iv._Z_scale)
+    save('host_scale_parallel', freq=fz, Z=Zz, **sc)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['matrices', 'ddt', 'dat', 'kats', 'csv', 'predict']
+    which = sys.argv[1:] or ['matrices', 'ddt', 'dat', 'kats', 'csv', 'predict', 'host']
     for w in which:
         globals()['gen_' + w]()

@@ -1,6 +1,10 @@
-"""GPU test (-m gpu): bench.py end to end under the launcher the driver uses for N > 1 (`python -m torch.distributed.run`),
-with one rank and BDRT_BENCH_FORCE_DIST=1 so that the RCCL code path (init_process_group, barrier, all_reduce of the
-timing / evaluation counts, destroy) runs on a 1-GPU box; checks the one-line JSON contract."""
+"""GPU tests (-m gpu) of bench.py.
+(1) The driver's exact single-GPU command line (`bench.py --gpus 1 --steps 20 --warmup 5`): the timed region must be the
+    steady state -- at least 0.3 s of sampling, every unit evaluated once per round -- and the line must carry `roofline`
+    and `cpu_baseline` (with the single-core figure and the labelled pystan estimate).
+(2) bench.py under the launcher the driver uses for N > 1 (`python -m torch.distributed.run`), with one rank and
+    BDRT_BENCH_FORCE_DIST=1 so that the RCCL code path (init_process_group, problem broadcast, barrier, all_reduce of the
+    timing / evaluation counts, the sample_sharded round trip, destroy) runs on a 1-GPU box."""
 import json
 import os
 import subprocess
@@ -10,24 +14,51 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+        'vs_baseline', 'dtype', 'data', 'config', 'roofline')
+
+
+def _line(out):
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in KEYS:
+        assert k in d, k
+    return d
+
+
+def test_driver_command_line_times_the_steady_state():
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5', '--cpu-seconds', '2']
+    d = _line(subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900))
+    c, r = d['config'], d['roofline']
+    assert d['n_gpus'] == 1 and d['steps'] == 20 and d['warmup'] == 5 and d['scaling'] == 'weak' and d['dtype'] == 'f64'
+    assert c['rounds_per_launch'] >= 1000 and c['units_per_gpu'] == 4096
+    assert c['timed_region_s'] >= 0.3, c['timed_region_s']
+    assert abs(d['ms_per_step'] * d['steps'] - c['timed_region_s'] * 1e3) < 1e-6 * c['timed_region_s'] * 1e3
+    # every chain is active in every round of the timed region: evaluations = units x rounds
+    assert c['evals_in_timed_region'] == c['units_per_gpu'] * c['rounds_per_launch'] * d['steps']
+    assert abs(d['value'] - c['evals_in_timed_region'] / c['timed_region_s']) <= 1e-9 * d['value']
+    assert d['value'] > 5e7
+    assert r['bound'] == 'mfma' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['launches'] == 20
+    assert 'hbm_frac_B1_accounting' not in r
+    # the kernel's HIP-event time cannot exceed the wall time of the region that contains it
+    assert r['avg_launch_ms'] * r['launches'] <= c['timed_region_s'] * 1e3 * 1.001
+    b = d['cpu_baseline']
+    assert b['kind'] == 'port' and b['cores'] >= 1 and 0 < b['single_core'] <= b['value']
+    assert b['pystan_derived']['value'] > 0 and 'derived' in b['pystan_derived']['source']
 
 
 def test_bench_contract_under_torchrun_single_rank():
     env = dict(os.environ, BDRT_BENCH_FORCE_DIST='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
-           '127.0.0.1', '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '100',
-           '--warmup', '50', '--no-cpu-baseline', '--spectra', '64']
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
-              'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
-        assert k in d, k
-    assert d['n_gpus'] == 1 and d['steps'] == 100 and d['warmup'] == 50 and d['scaling'] == 'weak' and d['dtype'] == 'f64'
+           '127.0.0.1', '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4',
+           '--warmup', '2', '--rounds', '50', '--no-cpu-baseline', '--spectra', '64']
+    d = _line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600))
+    assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 2 and d['scaling'] == 'weak' and d['dtype'] == 'f64'
     assert d['value'] > 1e6 and d['unit'] == 'evals/s' and 'workload' in d['config']
     r = d['roofline']
     assert r['bound'] == 'mfma' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['unit'] == 'TFLOP/s'
-    # evaluations counted = units x steps (every chain is active in every round of the timed region)
-    assert d['config']['evals_in_timed_region'] == d['config']['units_per_gpu'] * 100
+    assert d['config']['evals_in_timed_region'] == d['config']['units_per_gpu'] * 50 * 4
+    rt = d['config']['dist_roundtrip']            # broadcast + short sample_sharded run + summary gather over RCCL
+    assert rt['finite'] and rt['ms'] > 0 and rt['gather'] == 'summary'

@@ -1,0 +1,80 @@
+"""GPU tests (-m gpu) at BASELINE config 4's FULL size: 512 synthetic spectra x 8 chains = 4096 units on one GPU (one
+16-chain workgroup per CU) -- the workload bench.py times, here with its results checked:
+  * every draw of every unit finite, every chain past warm-up;
+  * >= 8 (spectrum, chain) units, including spectrum 511 and a unit in the last workgroup, compared draw by draw with the
+    recursive CPU oracle NUTS (same Philox streams => identical tree shapes, draws equal to 1e-6);
+  * per-spectrum posterior summaries reduced on the device (bdrt_sampler_summary) equal numpy on the constrained draws."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config4_full_size_draws_match_oracle_and_summaries_match_numpy():
+    import bench
+    from bayes_drt_amd import _lib
+    from bayes_drt_amd.engine import Sampler
+    from bayes_drt_amd.model import Problem
+    from bayes_drt_amd.parallel import make_units
+    from oracle import oracle as orc
+    lib = _lib.require_gpu()
+    kw = bench.build_problem_kwargs(bench.N_SPECTRA)
+    blocks, Z, freq = kw.pop('blocks'), kw.pop('Z'), kw.pop('freq')
+    prob = Problem(blocks, Z, freq, **kw)
+    assert prob.D == 331 and Z.shape == (512, 162)
+    spec, chain = make_units(bench.N_SPECTRA, bench.CHAINS_PER_SPECTRUM)
+    ctrl = _lib.NutsControl(); lib.bdrt_nuts_defaults(C.byref(ctrl))
+    ctrl.adapt_delta, ctrl.adapt_t0, ctrl.max_treedepth = 0.9, 10.0, 5
+    warm, nd = 6, 4
+    with Sampler(prob, len(spec), warm, nd, 1234, ctrl, spec=spec, chain_ids=chain) as smp:
+        smp.run()
+        draws, lp, diag = smp.results()
+        assert draws.shape == (4096, nd, 331) and np.all(np.isfinite(draws)) and np.all(np.isfinite(lp))
+        assert all(d['n_leapfrog'] > 0 for d in diag)
+        # (spectrum, chain) units spread over the grid: first / middle / last workgroups, spectrum 511 twice
+        picks = [(0, 0), (0, 7), (37, 3), (255, 5), (256, 0), (400, 6), (511, 0), (511, 7), (129, 2)]
+        octrl = orc.nuts_control(adapt_delta=0.9, adapt_t0=10.0, max_treedepth=5)
+        for s, c in picks:
+            u = s * bench.CHAINS_PER_SPECTRUM + c
+            assert spec[u] == s and chain[u] == c
+            om = orc.OracleModel(blocks, Z[s], freq, **kw)
+            ref, lpr, dr = orc.nuts_sample(om, c, 1234, warm, nd, control=octrl)
+            assert dr['n_leapfrog'] == diag[u]['n_leapfrog'], (s, c, dr, diag[u])
+            assert dr['n_divergent'] == diag[u]['n_divergent']
+            assert np.max(np.abs(draws[u] - ref)) < 1e-6 * np.max(np.abs(ref)), (s, c)
+            assert np.allclose(lp[u], lpr, rtol=1e-8, atol=1e-6)
+        # device summaries of whole spectra (what a multi-GPU run gathers) vs numpy on the constrained draws
+        q = [2.5, 50.0, 97.5]
+        for s in (0, 300, 511):
+            mean, pct = smp.summary(8 * s, 8 * s + 8, q)
+            cons = prob.constrain(draws[8 * s:8 * s + 8].reshape(-1, prob.D))
+            assert np.allclose(mean, cons.mean(axis=0), rtol=1e-13, atol=0)
+            assert np.allclose(pct, np.percentile(cons, q, axis=0), rtol=1e-14, atol=0)
+    prob.close()
+
+
+def test_summary_on_host_draws_equals_summary_on_the_sampler():
+    """post.summary (host buffer; used when the chains of a spectrum were sampled on several GPUs) performs the arithmetic
+    of Sampler.summary: bit-identical."""
+    from bayes_drt_amd import post
+    from bayes_drt_amd.engine import Sampler
+    from bayes_drt_amd.model import Problem
+    from tests.helpers import load
+    d = load('dat_sample_2ZARC_uniform_0.25_K81')
+    blk = dict(A=d['A'], L0=d['L0'], L1=d['L1'], L2=d['L2'], nonneg=True)
+    prob = Problem([blk], d['Z'], d['freq'], sigma_min=float(d['sigma_min']), ups_alpha=1.0, ups_beta=0.1)
+    ctrl = None
+    with Sampler(prob, 4, 8, 16, 7, ctrl) as smp:
+        smp.run()
+        draws, _, _ = smp.results()
+        m1, p1 = smp.summary(0, 4, [5.0, 50.0, 95.0])
+        m2, p2 = post.summary(draws.reshape(-1, prob.D), [5.0, 50.0, 95.0], prob.is_pos)
+        assert np.array_equal(m1, m2) and np.array_equal(p1, p2)
+        m3, p3 = smp.summary(1, 3, [50.0])
+        m4, p4 = post.summary(draws[1:3].reshape(-1, prob.D), [50.0], prob.is_pos)
+        assert np.array_equal(m3, m4) and np.array_equal(p3, p4)
+        cons = prob.constrain(draws.reshape(-1, prob.D))
+        assert np.allclose(p1, np.percentile(cons, [5.0, 50.0, 95.0], axis=0), rtol=1e-14, atol=0)
+    prob.close()

@@ -36,8 +36,15 @@ def test_percentile_nan_column_and_range_checks():
     assert np.array_equal(got[:, [0, 1, 3]], want[:, [0, 1, 3]])
     with pytest.raises(ValueError):
         post.percentile(X, 101.0)
-    with pytest.raises(_lib.BdrtError):
-        post.percentile(np.zeros((post.MAX_ROWS + 1, 1)), 50.0)
+
+
+def test_percentile_long_columns_match_numpy():
+    """More draws than fit in LDS (np.percentile has no row limit; e.g. chains=4 x samples=5000): the HBM-scratch path."""
+    from bayes_drt_amd import post
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((post.LDS_ROWS + 3617, 5)) * 3.0
+    q = [0.0, 2.5, 50.0, 97.5, 100.0]
+    assert np.array_equal(post.percentile(X, q), np.percentile(X, q, axis=0))
 
 
 def test_projected_percentiles_match_numpy():

@@ -138,3 +138,114 @@ def test_weights(inv_mod):
         inv._format_weights(f, Z, 'nope', 'both')
     with pytest.raises(ValueError):
         inv._format_weights(f, Z, np.ones(3), 'both')
+
+
+def test_qp_batcher_delivers_a_failed_launch_to_every_waiter(monkeypatch):
+    """A batched QP launch that fails (non-PD KKT matrix at tiny lambda_0, ...) must reach every fit of the lock-step
+    cross-validation: no thread may stay blocked in the rendezvous."""
+    import threading
+    from bayes_drt_amd import inversion
+
+    def boom(P, q, lo):
+        raise inversion._lib.BdrtError('KKT matrix not positive definite')
+    monkeypatch.setattr(inversion, '_qp_batch', boom)
+    n = 5
+    b = inversion._QPBatcher(n)
+    seen = []
+
+    def run(k):
+        try:
+            b.solve(np.eye(3), np.ones(3), np.zeros(3))
+        except inversion._lib.BdrtError as e:
+            seen.append((k, str(e)))
+        finally:
+            b.leave()
+    ts = [threading.Thread(target=run, args=(k,), daemon=True) for k in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=10)
+    assert not any(t.is_alive() for t in ts)
+    assert len(seen) == n
+
+
+def test_qp_batcher_flush_on_leave(monkeypatch):
+    """A fit that converges (leaves) while the others wait triggers the launch for the rest."""
+    import threading, time
+    from bayes_drt_amd import inversion
+    monkeypatch.setattr(inversion, '_qp_batch', lambda P, q, lo: (np.zeros(q.shape) + 7.0, np.arange(len(q), dtype=float)))
+    b = inversion._QPBatcher(3)
+    out = {}
+
+    def waiter(k):
+        out[k] = b.solve(np.eye(2), np.ones(2), np.zeros(2))
+        b.leave()
+    ts = [threading.Thread(target=waiter, args=(k,), daemon=True) for k in range(2)]
+    for t in ts:
+        t.start()
+    time.sleep(0.2)
+    b.leave()                                   # the third fit finished without another QP
+    for t in ts:
+        t.join(timeout=10)
+    assert not any(t.is_alive() for t in ts) and len(out) == 2 and all(np.all(v[0] == 7.0) for v in out.values())
+
+
+def test_format_weights_matches_reference(inv_mod):
+    """Every named scheme / scalar form x part against the reference's own _format_weights (golden host_weights.npz);
+    array weights (which the reference itself cannot take under numpy >= 1.25) by their documented meaning."""
+    g = load('host_weights')
+    f, Z = g['freq'], g['Z']
+    inv = inv_mod.Inverter()
+    cases = {'none': None, 'unity': 'unity', 'modulus': 'modulus', 'Orazem': 'Orazem', 'proportional': 'proportional',
+             'prop_adj': 'prop_adj', 'float': 0.7, 'int': 3, 'complex': 0.3 + 1.2j}
+    n = 0
+    for name, w in cases.items():
+        for part in ('both', 'real', 'imag'):
+            key = 'w_%s_%s' % (name, part)
+            if key in g.files:
+                got = np.asarray(inv._format_weights(f, Z, w, part), dtype=complex)
+                assert np.array_equal(got, g[key]), key
+                n += 1
+    assert n == 27
+    ar, ac = g['arr_real'], g['arr_cplx']
+    assert np.array_equal(inv._format_weights(f, Z, ar, 'both'), ar + 1j * ar)
+    assert np.array_equal(inv._format_weights(f, Z, ar, 'imag'), 1 + 1j * ar)
+    assert np.array_equal(inv._format_weights(f, Z, ar, 'real'), ar + 1j)
+    assert np.array_equal(inv._format_weights(f, Z, ac, 'both'), ac)
+    assert np.array_equal(inv._format_weights(f, Z, ac, 'imag'), ac)
+    assert np.array_equal(inv._format_weights(f, Z, ac, 'real'), ac.real + 1j)
+    with pytest.raises(ValueError):
+        inv._format_weights(f, Z, 'nonsense', 'both')
+    with pytest.raises(ValueError):
+        inv._format_weights(f, Z, ar[:-1], 'both')
+    with pytest.raises(ValueError):
+        inv._format_weights(f, Z, None, 'neither')
+
+
+def test_distribution_defaults_match_reference(inv_mod):
+    g = load('host_distributions')
+    dists = {'DRT': {'kernel': 'DRT'}, 'tp': {'kernel': 'DDT', 'bc': 'transmissive', 'dist_type': 'parallel'},
+             'bs': {'kernel': 'DDT', 'symmetry': 'spherical'}, 'ct': {'kernel': 'DDT', 'ct': True, 'k_ct': 2.0, 'dist_type': 'series'}}
+    for name, info in dists.items():
+        got = inv_mod.Inverter(distributions={name: dict(info)}).distributions[name]
+        assert ';'.join('%s=%s' % (k, got[k]) for k in sorted(got)) == str(g[name]), name
+    for bad in ({'kernel': 'DDT', 'dist_type': 'diagonal'}, {'kernel': 'DDT', 'symmetry': 'cubic'}, {'kernel': 'DDT', 'bc': 'open'},
+                {'kernel': 'DDT', 'ct': 'yes'}, {'kernel': 'DDT', 'ct': True}, {'kernel': 'XYZ'}):
+        with pytest.raises(ValueError):
+            inv_mod.Inverter(distributions={'d': bad})
+    with pytest.warns(UserWarning):
+        inv_mod.Inverter(distributions={'d': {'kernel': 'DRT', 'dist_type': 'parallel'}})
+    with pytest.warns(UserWarning):
+        inv_mod.Inverter(distributions={'d': {'kernel': 'DRT', 'bc': 'blocking'}})
+
+
+def test_scale_Z_admittance_branch_matches_reference(inv_mod):
+    """A single parallel planar DDT scales the ADMITTANCE to a fixed spread (reference inversion.py:2417-2434)."""
+    g = load('host_scale_parallel')
+    for bc in ('transmissive', 'blocking'):
+        iv = inv_mod.Inverter(distributions={'d': {'kernel': 'DDT', 'dist_type': 'parallel', 'symmetry': 'planar', 'bc': bc}})
+        Zs = iv._scale_Z(g['Z'], 'map')
+        assert abs(iv._Z_scale - float(g['scale_' + bc])) <= 1e-14 * abs(float(g['scale_' + bc]))
+        assert np.allclose(Zs, g['Zs_' + bc], rtol=1e-14, atol=0)
+        iv._scale_Z(g['Z'], 'ridge')
+        assert abs(iv._Z_scale - float(g['scale_ridge_' + bc])) <= 1e-14 * abs(float(g['scale_ridge_' + bc]))

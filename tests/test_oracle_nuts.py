@@ -53,3 +53,17 @@ def test_drt_posterior_small_runs():
     assert diag['n_leapfrog'] > 0
     # lp stored with the draw is the log density at the draw
     assert abs(m.logp(draws[-1], True) - lp[-1]) < 1e-9 * max(1, abs(lp[-1]))
+
+
+def test_short_warmup_leaves_the_metric_alone():
+    """num_warmup < 20: Stan 2.19 performs no variance estimation at all (windowed_adaptation::set_window_params returns
+    early), so the metric stays at its initial value instead of being overwritten by the empty-window regulariser 1e-3
+    (which made trees ~30x longer).  Known answer: a 20-d unit Gaussian, warmup=10."""
+    mu = np.zeros(20); sd = np.ones(20)
+    for chain in (0, 1):
+        _, dw = orc.nuts_sample_gauss(mu, sd, chain, 5, 10, 0)
+        _, d = orc.nuts_sample_gauss(mu, sd, chain, 5, 10, 200)
+        per_draw = (d['n_leapfrog'] - dw['n_leapfrog']) / 200       # post-warm-up leapfrogs per draw
+        # unit metric, adapted eps >= 0.15: half a period is at most pi / 0.15 = 21 steps => trees of <= 31 leapfrogs;
+        # with the metric overwritten by 1e-3 the same eps needed ~30x as many (312 per draw measured)
+        assert d['stepsize'] > 0.1 and per_draw < 40, (chain, d['stepsize'], per_draw)

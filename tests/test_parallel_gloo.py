@@ -20,10 +20,46 @@ def _fake_sampler(kw, spec, chain_ids, warmup, n_draws, seed, control):
     out = np.empty((len(spec), n_draws, D)); lp = np.empty((len(spec), n_draws)); st = np.zeros((len(spec), 5))
     for u, (s, c) in enumerate(zip(spec, chain_ids)):
         rs = np.random.RandomState((seed * 1000003 + int(c)) % (2 ** 31))
-        out[u] = rs.standard_normal((n_draws, D)) + Z[s].sum() + float(kw['sigma_min'])
+        out[u] = 0.3 * rs.standard_normal((n_draws, D)) + 0.01 * Z[s].sum() + float(kw['sigma_min'])
         lp[u] = out[u].sum(axis=1)
         st[u, 0] = 10 * c
     return out, lp, st
+
+
+class FakeWorker:
+    """Stand-in for parallel.GpuWorker (test-only injection): same protocol, numpy arithmetic, records which rank ran."""
+
+    def __init__(self, kw):
+        self.kw = kw
+        self.D = 2 * kw['blocks'][0]['A'].shape[1] + 9
+
+    def run(self, spec, chain_ids, warmup, n_draws, seed, control):
+        self._draws, self._lp, self._stats = _fake_sampler(self.kw, spec, chain_ids, warmup, n_draws, seed, control)
+        self._stats[:, 1] = dist.get_rank()            # "n_divergent" column abused as the rank that sampled the unit
+
+    def lp(self):
+        return self._lp
+
+    def stats(self):
+        return self._stats
+
+    def draws(self, device):
+        return self._draws
+
+    def is_pos(self):
+        m = np.zeros(self.D, dtype=bool); m[2:self.D - 3:2] = True
+        return m
+
+    def summary(self, lo, hi, q):
+        return FakeWorker.reduce(self._draws[lo:hi].reshape(-1, self.D), self.is_pos(), q)
+
+    @staticmethod
+    def reduce(block, is_pos, q):
+        c = np.where(is_pos, np.exp(block), block)
+        return c.mean(axis=0), np.percentile(c, q, axis=0)
+
+    def close(self):
+        pass
 
 
 def _problem(n_spectra):
@@ -35,15 +71,15 @@ def _problem(n_spectra):
                 ups_alpha=1.0, ups_beta=0.1, outlier_mode=0, use_x_sum=False)
 
 
-def _worker(rank, world, port, n_spectra, q):
+def _worker(rank, world, port, n_spectra, chains, gather, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         pk = _problem(n_spectra) if rank == 0 else None
-        draws, lp, st = par.sample_sharded(pk, n_spectra, 3, 5, 4, seed=11, sample_fn=_fake_sampler)
+        res = par.sample_sharded(pk, n_spectra, chains, 5, 4, seed=11, worker_cls=FakeWorker, gather=gather)
         if rank == world - 1:
-            q.put((draws, lp, st))
+            q.put(res)
     finally:
         dist.destroy_process_group()
 
@@ -53,11 +89,11 @@ def _free_port():
     return p
 
 
-def _run(world, n_spectra):
+def _run(world, n_spectra, chains=3, gather='draws'):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_spectra, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_spectra, chains, gather, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=120)
@@ -65,6 +101,14 @@ def _run(world, n_spectra):
         p.join(timeout=60)
         assert p.exitcode == 0
     return res
+
+
+def _same(a, b, skip=('stats',)):
+    assert set(a) == set(b)
+    for k in a:
+        assert a[k].shape == b[k].shape, k
+        if k not in skip:
+            assert np.array_equal(a[k], b[k]), k
 
 
 def test_shard_bounds_cover_everything():
@@ -75,20 +119,68 @@ def test_shard_bounds_cover_everything():
             assert max(e - s for s, e in b) - min(e - s for s, e in b) <= 1
 
 
-@pytest.mark.parametrize('n_spectra', [5, 1])
+def test_partition_units_whole_spectra_or_chains():
+    # config 4: whole spectra per rank
+    p = par.partition_units(512, 8, 8)
+    assert p[0] == (0, 512) and p[-1] == (3584, 4096) and all((hi - lo) % 8 == 0 for lo, hi in p)
+    # config 3 / 5: one spectrum, 4 chains => chains are spread, 4 of 8 ranks busy
+    p = par.partition_units(1, 4, 8)
+    assert [hi - lo for lo, hi in p] == [1, 1, 1, 1, 0, 0, 0, 0]
+    assert par.partition_units(1, 4, 2) == [(0, 2), (2, 4)]
+    assert par.partition_units(0, 4, 2) == [(0, 0), (0, 0)]
+    for ns, ch, w in ((5, 3, 2), (2, 4, 3), (3, 2, 8)):
+        p = par.partition_units(ns, ch, w)
+        assert p[0][0] == 0 and p[-1][1] == ns * ch and all(p[i][1] == p[i + 1][0] for i in range(w - 1))
+
+
+@pytest.mark.parametrize('n_spectra', [5, 2])
 def test_world2_equals_world1(n_spectra):
     ref = _run(1, n_spectra)
     two = _run(2, n_spectra)
-    for a, b in zip(ref, two):
-        assert a.shape == b.shape and np.array_equal(a, b)
+    _same(ref, two)
+    assert np.array_equal(ref['stats'][:, 0], two['stats'][:, 0])
+    assert set(two['stats'][:, 1]) == {0.0, 1.0}                 # both ranks sampled
     pk = _problem(n_spectra)
     spec, chain = par.make_units(n_spectra, 3)
     direct = _fake_sampler(pk, spec, chain, 5, 4, 11, None)
-    assert np.array_equal(direct[0], ref[0])
+    assert np.array_equal(direct[0], ref['draws'])
+    m, p = FakeWorker.reduce(direct[0][:3].reshape(-1, direct[0].shape[2]), FakeWorker(pk).is_pos(), [2.5, 50.0, 97.5])
+    assert np.array_equal(ref['mean'][0], m) and np.array_equal(ref['pct'][0], p)
+
+
+def test_single_spectrum_chains_are_spread_over_ranks():
+    """BASELINE configs 3 and 5: one spectrum, 4 chains, 2 ranks => each rank samples 2 chains; same result as 1 rank."""
+    ref = _run(1, 1, chains=4)
+    two = _run(2, 1, chains=4)
+    _same(ref, two)
+    assert list(two['stats'][:, 1]) == [0.0, 0.0, 1.0, 1.0]     # chains 0,1 on rank 0, chains 2,3 on rank 1
+    three = _run(3, 1, chains=4, gather='summary')             # 4 units on 3 ranks; summaries only
+    assert 'draws' not in three
+    assert np.array_equal(three['mean'], ref['mean']) and np.array_equal(three['pct'], ref['pct'])
+
+
+def test_summary_gather_moves_no_draws():
+    ref = _run(1, 4, gather='draws')
+    summ = _run(2, 4, gather='summary')
+    assert 'draws' not in summ
+    for k in ('mean', 'pct', 'lp'):
+        assert np.array_equal(ref[k], summ[k]), k
 
 
 def test_world3_with_idle_rank():
     ref = _run(1, 2)
-    three = _run(3, 2)          # 2 spectra on 3 ranks: one rank has no work
-    for a, b in zip(ref, three):
-        assert np.array_equal(a, b)
+    three = _run(3, 2)          # 2 spectra x 3 chains on 3 ranks: chains are spread (2 units per rank)
+    _same(ref, three)
+    eight = _run(8, 1, chains=4)        # more ranks than units: four ranks idle
+    _same(_run(1, 1, chains=4), eight)
+
+
+def test_no_spectra_is_an_empty_result():
+    res = _run(2, 0)
+    assert res['draws'].shape[0] == 0 and res['stats'].shape == (0, 5)
+
+
+def test_broadcast_rejects_what_float64_cannot_carry():
+    with pytest.raises(TypeError):
+        par._pack_problem(dict(blocks=[dict(A=np.ones((2, 2)) * 1j, L0=np.eye(2), L1=np.eye(2), L2=np.eye(2))], Z=np.ones(2),
+                               freq=np.ones(1)))
