@@ -34,6 +34,11 @@ static_assert(NW * NQ_CHK * NC <= MIN_LR * NC, "Lr buffer too small for the NUTS
 enum { V_TH = 0, V_P, V_G, V_THM, V_PM, V_GM, V_THP, V_PP, V_GP, V_THS, V_GS, V_THQ, V_GQ, V_RHO, V_RHOC, V_MINV,
        V_WMEAN, V_WM2, V_ZN /* normals of the next transition's momentum, produced ahead of time */, V_CKC /* MAXD */, V_CKP = V_CKC + MAXD /* MAXD */, V_COUNT = V_CKP + MAXD };
 
+// chain k of a workgroup <-> column (half-wave) of the 16-column tile: k = 0..7 -> columns 0, 2, .., 14 (one wave each),
+// k = 8..15 -> columns 1, 3, .., 15
+__host__ __device__ __forceinline__ int slot_col(int k) { return 2 * (k & 7) + (k >> 3); }
+__host__ __device__ __forceinline__ int col_slot(int c) { return (c & 1) * 8 + (c >> 1); }
+
 // sum over the 32 lanes of a half-wave (one chain), fixed order => deterministic; every lane gets the result
 __device__ __forceinline__ double half_sum(double x) { return sum32(x); }
 
@@ -54,6 +59,7 @@ struct NutsArgs {
     unsigned long long *leap_counter;   // total leapfrogs (all chains)
     int *done_counter;     // workgroups whose chains are all finished
     int n_units;
+    int cpw;               // chains per workgroup (1..16): few chains are spread over many workgroups / waves
     int rounds;
     int ds;                // row stride of the state vectors (D rounded up to 32)
     long long *prof;       // optional [n_wg][32] cycle counters (phase profile)
@@ -76,9 +82,14 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     int l32 = lane & 31;
     const int D = P.D, DS = a.ds;
     const int wg = blockIdx.x;
-    const int c0 = wg * NC;
-    const int nvalid = min(NC, a.n_units - c0);
-    const bool valid = c < nvalid;
+    // Unit u = wg * cpw + k sits in column slot_col(k): the first eight chains of a workgroup get one wave each (even
+    // columns = lanes 0..31 of waves 0..7), the next eight the other half-waves.  With few chains per workgroup the per-chain
+    // VALU work of a round is then spread over the four SIMDs instead of piling up on one.
+    const int c0 = wg * a.cpw;
+    const int nvalid = min(a.cpw, a.n_units - c0);
+    const int kslot = col_slot(c);                       // this column's chain index within the workgroup
+    const bool valid = kslot < nvalid;
+    const int unit = c0 + kslot;
 
     // LDS carve-up: [tile region | (fast S1 path: theta rows of the 16 chains) | lp of the 16 chains | chain states | spectrum ids]
     const size_t tile_doubles = MODE == 4 ? hw_lds_doubles(P) : (MODE >= 2 ? s1_lds_doubles(P) : lds_doubles(P));
@@ -93,9 +104,10 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     auto row = [&](int v) -> double * { return V + ((size_t)v * NC + c) * DS; };   // this chain's row of vector v
 
     if (tid < NC) {
-        if (tid < nvalid) sts[tid] = a.states[c0 + tid];
+        const int k = col_slot(tid);
+        if (k < nvalid) sts[tid] = a.states[c0 + k];
         else { memset(&sts[tid], 0, sizeof(ChainState)); sts[tid].phase = PH_DONE; }
-        spec[tid] = tid < nvalid ? sts[tid].spec : 0;
+        spec[tid] = k < nvalid ? sts[tid].spec : 0;
     }
     __syncthreads();
     ChainState &s = sts[c];
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 if (endt == 2) s.n_div = s.n_div + 1;
                 if (s.depth >= np.max_depth) s.n_maxdepth = s.n_maxdepth + 1;
                 draw = iter - np.warmup;
-                if (a.lp_draws && valid && l32 == 0) a.lp_draws[(size_t)(c0 + c) * np.n_draws + draw] = s.lps;
+                if (a.lp_draws && valid && l32 == 0) a.lp_draws[(size_t)unit * np.n_draws + draw] = s.lps;
             }
             bool redo_eps = false;
             if (warm) {
@@ -672,7 +684,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 if (upds || welf || wend || draw >= 0) {
                     const double *ST = upds ? row(V_THQ) : THS, *SG = upds ? row(V_GQ) : GS;
                     double *WM = row(V_WMEAN), *W2 = row(V_WM2);
-                    double *dr = (draw >= 0 && valid) ? a.draws + ((size_t)(c0 + c) * np.n_draws + draw) * D : nullptr;
+                    double *dr = (draw >= 0 && valid) ? a.draws + ((size_t)unit * np.n_draws + draw) * D : nullptr;
 #pragma unroll 1
                     for (int mb = 0; mb < NJ; mb += MB) {
                         double ts_[MB], gs_[MB], wm_[MB], w2_[MB];
@@ -855,7 +867,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     }
                 }
                 if (draw >= 0 && valid) {
-                    double *dr = a.draws + ((size_t)(c0 + c) * np.n_draws + draw) * D;
+                    double *dr = a.draws + ((size_t)unit * np.n_draws + draw) * D;
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; if (j < D) dr[j] = ths_[m]; }
                 }
@@ -975,7 +987,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         double *THg = row(V_TH);
         for (int j = l32; j < D; j += 32) THg[j] = TH[j];
     }
-    if (l32 == 0 && valid) a.states[c0 + c] = s;
+    if (l32 == 0 && valid) a.states[unit] = s;
     {
         unsigned long long x = my_leaps;      // non-zero only in lane 0 of each half-wave
         x += __shfl_xor(x, 32);
@@ -1063,7 +1075,16 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     memset(&S.args, 0, sizeof(S.args));
     S.prob = &P;
     S.n_units = n_units;
-    S.n_wg = (n_units + NC - 1) / NC;
+    // chains per workgroup: fill every CU with one workgroup before putting a second chain on any wave
+    {
+        hipDeviceProp_t prop;
+        int n_cu = 256;
+        if (hipGetDeviceProperties(&prop, P.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        int cpw = (n_units + n_cu - 1) / n_cu;
+        if (const char *e = getenv("BDRT_CHAINS_PER_WG")) cpw = atoi(e);     // diagnostics: force a packing
+        S.args.cpw = std::min(NC, std::max(1, cpw));
+    }
+    S.n_wg = (n_units + S.args.cpw - 1) / S.args.cpw;
     S.D = P.dev.D;
     S.np.warmup = warmup; S.np.n_draws = n_draws; S.np.max_depth = c.max_treedepth;
     S.np.delta = c.adapt_delta; S.np.gamma = c.adapt_gamma; S.np.t0 = c.adapt_t0; S.np.kappa = c.adapt_kappa;
@@ -1102,7 +1123,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         st.dir = 1;
         st.lsw_sub = -INFINITY;
         window_init(st, warmup, c.init_buffer, c.term_buffer, c.base_window);
-        const int wg = u / NC, cc = u % NC;
+        const int wg = u / S.args.cpw, cc = slot_col(u % S.args.cpw);
         double *V = hv.data() + (size_t)wg * V_COUNT * NC * DS;
         const Philox rng = {S.np.seed_lo, S.np.seed_hi, (uint32_t)st.chain_id};
         for (int j = 0; j < S.D; ++j) {
@@ -1113,12 +1134,13 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         }
         if (!init_theta) st.init_attempt = 0;
     }
-    // padded columns of the last workgroup: finite placeholders
-    for (int u = n_units; u < S.n_wg * NC; ++u) {
-        const int wg = u / NC, cc = u % NC;
-        double *V = hv.data() + (size_t)wg * V_COUNT * NC * DS;
-        for (int j = 0; j < S.D; ++j) V[((size_t)V_MINV * NC + cc) * DS + j] = 1.0;
-    }
+    // unused columns (cpw < 16, last workgroup): finite placeholders
+    for (int wg = 0; wg < S.n_wg; ++wg)
+        for (int k = 0; k < NC; ++k) {
+            if (k < S.args.cpw && wg * S.args.cpw + k < n_units) continue;
+            double *V = hv.data() + (size_t)wg * V_COUNT * NC * DS;
+            for (int j = 0; j < S.D; ++j) V[((size_t)V_MINV * NC + slot_col(k)) * DS + j] = 1.0;
+        }
     if (hipMalloc((void **)&S.args.vecs, nvec * sizeof(double)) != hipSuccess) return fail("hipMalloc(vecs) failed");
     if (hipMalloc((void **)&S.args.states, hs.size() * sizeof(ChainState)) != hipSuccess) return fail("hipMalloc(states) failed");
     const size_t nd = (size_t)n_units * std::max(n_draws, 1) * S.D;

@@ -337,7 +337,7 @@ class DeviceArray:
     def __init__(self, ptr_value, shape, owner):
         self._owner = owner                      # keeps the sampler (and its device memory) alive
         self.__cuda_array_interface__ = {'shape': tuple(int(x) for x in shape), 'typestr': '<f8',
-                                         'data': (int(ptr_value), True), 'version': 2, 'strides': None}
+                                         'data': (int(ptr_value), False), 'version': 2, 'strides': None}
 
 
 class Sampler:

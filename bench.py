@@ -240,7 +240,8 @@ def main():
                  'tile:prior', 'tile:gemmBwd', 'tile:epilogue', 'nuts:A kick-drift', 'nuts:C kick+kin', 'nuts:S1',
                  'nuts:D tree', 'nuts:S2', 'nuts:E next', 'nuts:S3']
         tot = float(sum(cyc[:17])) or 1.0
-        n_wg = (n_units + 15) // 16
+        cpw = min(16, max(1, -(-n_units // 256)))          # chains per workgroup (bdrt_sampler_create)
+        n_wg = -(-n_units // cpw)
         rounds_total = args.steps * args.rounds
         for k, nm in enumerate(names):
             print('PHASE %-20s %6.2f %%  %9.0f cycles/round' % (nm, 100 * cyc[k] / tot, cyc[k] / n_wg / rounds_total), file=sys.stderr)

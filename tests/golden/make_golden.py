@@ -258,7 +258,7 @@ def gen_csv():
         a = a[[c for c in a.columns if not c.startswith('Unnamed')]]
         return a.values.astype(float), np.array(list(a.columns))
 
-    for stem in ('2ZARC_uniform_0.25', '2ZARC_noiseless', '2RC_uniform_0.25', 'RC-ZARC_uniform_0.25'):
+    for stem in ('2ZARC_uniform_0.25', '2ZARC_noiseless', '2RC_uniform_0.25', 'RC-ZARC_uniform_0.25', 'BimodalTP-DDT_uniform_0.25'):
         out = {}
         for key, rel in (('Z', 'data/simulated/Z_%s.csv'), ('Gout_map', 'code_EchemActa/map_results/Gout_%s.csv'),
                          ('Zout_map', 'code_EchemActa/map_results/Zout_%s.csv'),

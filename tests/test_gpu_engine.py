@@ -96,6 +96,32 @@ def test_nuts_is_independent_of_packing_and_launch_slicing():
     assert np.array_equal(sliced, part)
     other, _, _ = sample_units(prob, 3, 20, 10, 8, ctrl, chain_ids=ids[[17, 2, 9]])
     assert not np.array_equal(other, part)
+    # few chains are spread one per workgroup / wave (the reference's own call shape is 2-4 chains); forcing other
+    # packings -- all 20 chains on two workgroups, three per workgroup -- gives the same bits
+    try:
+        for cpw in ('16', '3', '1'):
+            os.environ['BDRT_CHAINS_PER_WG'] = cpw
+            packed, _, _ = sample_units(prob, 20, 20, 10, 7, ctrl, chain_ids=ids)
+            assert np.array_equal(packed, full), cpw
+    finally:
+        os.environ.pop('BDRT_CHAINS_PER_WG', None)
+
+
+def test_few_chain_packing_benchmark_shape_bitwise():
+    """81 x 161 (the LDS-resident fast path): 4 chains on 4 workgroups (default) == the same 4 chains packed in one."""
+    from bayes_drt_amd.model import Problem
+    from bayes_drt_amd.engine import sample_units
+    blk, Z, f, kw, d = _bench_problem()
+    prob = Problem([blk], Z, f, **kw)
+    ctrl = _ctrl(prob._lib, max_treedepth=6)
+    spread, lp0, dg0 = sample_units(prob, 4, 12, 6, 1234, ctrl)
+    try:
+        os.environ['BDRT_CHAINS_PER_WG'] = '16'
+        packed, lp1, dg1 = sample_units(prob, 4, 12, 6, 1234, ctrl)
+    finally:
+        os.environ.pop('BDRT_CHAINS_PER_WG', None)
+    assert np.array_equal(spread, packed) and np.array_equal(lp0, lp1)
+    assert [x['n_leapfrog'] for x in dg0] == [x['n_leapfrog'] for x in dg1]
 
 
 def test_nuts_posterior_matches_oracle_statistically():
