@@ -48,6 +48,9 @@ struct DevBlock {
     int toep;         // 1: use T[][] instead of Lf / the L part of Bk
     const double *BkA;// [tilesK][rpairsA][64][2]  transposed A only
     double T[3][2 * MAXBW + 1];   // T[i][d + MAXBW] = L_i[k][k + d]
+    // A_re and A_im exactly Toeplitz (log-uniform frequency and tau grids, reference matrices.py:197-205): their generators
+    // [2][nf + K - 1], tg[b][n - m + K - 1] = A_b[n][m]; nullptr otherwise.  Used by the one-chain-per-workgroup path.
+    const double *tg;
 };
 
 struct DevProblem {

@@ -149,6 +149,23 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
         if ((rc = upload(P, pack_fragments(B.tilesK, B.rpairsA + B.rpairsL, Telem), &B.Bk))) return rc;
         auto TAelem = [&](int k, int r) -> double { return Aelem(r, k); };
         if ((rc = upload(P, pack_fragments(B.tilesK, B.rpairsA, TAelem), &B.BkA))) return rc;
+        // exact Toeplitz structure of the two halves of A (what construct_A builds from one column and one row on
+        // log-uniform grids, reference matrices.py:236-242): generators for the one-chain-per-workgroup path (bdrt_solo.h)
+        {
+            const int glen = nf + K - 1;
+            std::vector<double> tgv((size_t)2 * glen, 0.0);
+            bool tz = true;
+            for (int h = 0; h < 2 && tz; ++h) {
+                const double *Ah = A + (size_t)h * nf * K;
+                for (int n = 0; n < nf; ++n) tgv[(size_t)h * glen + n + K - 1] = Ah[(size_t)n * K];
+                for (int m = 0; m < K; ++m) tgv[(size_t)h * glen + K - 1 - m] = Ah[m];
+                for (int n = 0; n < nf && tz; ++n)
+                    for (int m = 0; m < K; ++m)
+                        if (Ah[(size_t)n * K + m] != tgv[(size_t)h * glen + n - m + K - 1]) { tz = false; break; }
+            }
+            B.tg = nullptr;
+            if (tz && (rc = upload(P, tgv, &B.tg))) return rc;
+        }
         // banded-Toeplitz detection of L0, L1, L2 (log-uniform tau grids): every entry outside the band
         // is below 1e-19 of the largest entry and every diagonal is constant to 1e-12 relative.  The dense MFMA path
         // remains for any other grid.

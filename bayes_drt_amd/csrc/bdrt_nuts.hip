@@ -23,6 +23,7 @@
 
 #include "bdrt_host.h"
 #include "bdrt_nuts_device.h"
+#include "bdrt_solo.h"
 
 namespace bdrt {
 
@@ -1000,6 +1001,388 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// One chain per workgroup (bdrt_solo.h): the same transition logic as nuts_kernel, element j of every vector in thread j,
+// all vectors in LDS.  Global state layout: vecs [n_units][SG_COUNT][ds]; states [n_units].
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SOLO_NT) void nuts_solo_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, SoloGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const DevProblem &P = *Pp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int unit = blockIdx.x;
+    const int D = g.D, DS = a.ds, j = tid;
+    const bool own = j < D;                                // this thread owns element j of the D-vectors
+    double *Vg = a.vecs + (size_t)unit * SG_COUNT * DS;    // global rows
+    double *V = smem + g.o_vec;                            // LDS rows
+    auto row = [&](int v) -> double * { return V + (size_t)v * g.DSS; };
+    double *red = smem + g.o_red;
+    double *zrow = smem + g.o_z;
+    double *lps_l = smem + g.o_scv + 12;                   // lp of the last evaluation
+    int slot = 0;
+
+    ChainState s = a.states[unit];                         // every thread keeps the whole scalar state (identical updates)
+    const Philox rng = {np.seed_lo, np.seed_hi, (uint32_t)s.chain_id};
+#pragma unroll 7
+    for (int v = 0; v < SV_COUNT; ++v) {
+        const double x = own ? Vg[(size_t)v * DS + j] : 0.0;
+        if (j < g.DSS) row(v)[j] = x;
+    }
+    solo_eval_init(P, g, smem, tid);
+    const SoloEvalRegs er = solo_eval_setup(P, g, s.spec, tid);
+    double *TH = row(SV_TH), *Pm = row(SV_P), *G = row(SV_G), *MI = row(SV_MINV);
+    __syncthreads();
+
+    if (!s.kicked) {
+        const int ph = s.phase;
+        const double e = ph == PH_EPS ? s.eps : (ph == PH_TREE ? s.dir * s.eps : 0.0);
+        if ((ph == PH_INIT || ph == PH_EPS || ph == PH_TREE) && own) {
+            const double p = Pm[j] + 0.5 * e * G[j];
+            Pm[j] = p;
+            TH[j] += e * MI[j] * p;
+        }
+        s.kicked = 1;
+        __syncthreads();
+    }
+    unsigned long long my_leaps = 0;
+
+    for (int round = 0; round < a.rounds; ++round) {
+        const int ph0 = s.phase;
+        const bool act = ph0 == PH_INIT || ph0 == PH_EPS || ph0 == PH_TREE;
+        if (!act) break;
+        const double e = ph0 == PH_EPS ? s.eps : (ph0 == PH_TREE ? s.dir * s.eps : 0.0);
+
+        // ---- B: log-posterior + gradient at the new point ------------------------------------------------------------------
+        solo_eval(P, g, smem, TH, G, lps_l, er, 1, tid);
+
+        // ---- C: second half kick, kinetic energy, finiteness of the gradient ----------------------------------------------------
+        double p = 0.0, gj = 0.0, mi = 1.0;
+        double kin = 0.0, nonfin = 0.0;
+        if (own) {
+            gj = G[j]; mi = MI[j];
+            p = Pm[j] + 0.5 * e * gj;
+            kin = mi * p * p;
+            nonfin = isfinite(gj) ? 0.0 : 1.0;
+        }
+        solo_block_sum2(kin, nonfin, red, slot, wave, lane);
+        kin *= 0.5;
+
+        // ---- S1: scalar logic after the evaluation (identical in every thread) ---------------------------------------------------
+        bool copyq = false, cur2s = false, tree = false, last = false;
+        bool upds = false, welf = false, wend = false;
+        int nm = 0, endt = 0, next = 0, draw = -1;
+        double wn = 0.0;
+        const int dir_now = s.dir;
+        const int leaf_now = s.leaf;
+        {
+            const double lp = *lps_l;
+            const bool finite_pt = isfinite(lp) && nonfin == 0.0;
+            if (ph0 == PH_INIT) {
+                if (finite_pt) {
+                    s.lps = lp;
+                    cur2s = true;
+                    s.phase = PH_EPS; s.eps_dir = 0; s.eps_trials = 0;
+                    next = 3;
+                } else {
+                    const int att = s.init_attempt + 1;
+                    s.init_attempt = att;
+                    if (att >= 100) s.phase = PH_FAILED;
+                    else next = 4;
+                }
+            } else if (ph0 == PH_EPS) {
+                // Stan base_hmc::init_stepsize
+                my_leaps += 1;
+                double h = -lp + kin;
+                if (isnan(h)) h = INFINITY;
+                const double dH = s.H0 - h;
+                const double thr = -0.2231435513142097557662950903;   // log(0.8)
+                bool finished = false;
+                const int trials = s.eps_trials;
+                const int edir = s.eps_dir;
+                double eps = s.eps;
+                if (trials == 0) {
+                    s.eps_dir = dH > thr ? 1 : -1;
+                } else {
+                    if (edir == 1 && !(dH > thr)) finished = true;
+                    else if (edir == -1 && !(dH < thr)) finished = true;
+                    else eps = edir == 1 ? 2.0 * eps : 0.5 * eps;
+                    if (!(eps > 1e-300) || eps > 1e7) finished = true;
+                    s.eps = eps;
+                }
+                s.eps_trials = trials + 1;
+                if (finished) {
+                    s.da_mu = s.iter == 0 ? log(10.0 * np.stepsize0) : log(10.0 * eps);
+                    s.da_counter = 0; s.da_sbar = 0.0; s.da_xbar = 0.0;
+                    s.phase = PH_TREE;
+                    next = 1;
+                } else {
+                    next = 3;
+                }
+            } else {   // PH_TREE: one new leaf
+                my_leaps += 1;
+                s.n_leap_iter = s.n_leap_iter + 1;
+                double h = -lp + kin;
+                if (isnan(h)) h = INFINITY;
+                const double H0 = s.H0;
+                const bool divergent = (h - H0) > np.max_deltaH;
+                const double w = H0 - h;
+                s.sum_metro = s.sum_metro + (w > 0.0 ? 1.0 : exp(w));
+                if (divergent) {
+                    endt = 2;
+                } else {
+                    const double lsw_new = log_sum_exp2(s.lsw_sub, w);
+                    const double u = rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
+                    if (leaf_now == 0 || u < exp(w - lsw_new)) { copyq = true; s.lpq = lp; }
+                    s.lsw_sub = lsw_new;
+                    tree = true;
+                    while ((leaf_now >> nm) & 1) ++nm;
+                    last = leaf_now == s.nleaves - 1;
+                }
+            }
+        }
+
+        // ---- D: proposal copy, checkpoints, U-turn tests, subtree close ----------------------------------------------------------
+        if ((copyq || cur2s) && own) {
+            const double th = TH[j];
+            if (copyq) { row(SV_THQ)[j] = th; row(SV_GQ)[j] = gj; }
+            if (cur2s) { row(SV_THS)[j] = th; row(SV_GS)[j] = gj; }
+        }
+        if (tree) {
+            // binary-counter bookkeeping of the new subtree: see nuts_kernel (level l: rho / first momentum of the completed
+            // left sub-subtree of 2^l leaves that waits for its sibling; level 0 keeps only the momentum)
+            double rc = p, cpl = p;
+            bool ok = true;
+            for (int l = 0; l < nm; ++l) {
+                double a0 = 0.0, a1 = 0.0;
+                if (own) {
+                    const double lpv = row(SV_CKP + l)[j];
+                    const double lr = l == 0 ? lpv : row(SV_CKC + l)[j];
+                    const double rho = lr + rc;
+                    a0 = mi * lpv * rho;
+                    a1 = mi * p * rho;
+                    rc = rho;
+                    cpl = lpv;
+                }
+                solo_block_sum2(a0, a1, red, slot, wave, lane);
+                ok = ok && (a0 > 0.0) && (a1 > 0.0);
+            }
+            if (ok && !last && own) {
+                row(SV_CKP + nm)[j] = cpl;
+                if (nm > 0) row(SV_CKC + nm)[j] = rc;
+            }
+            if (!ok) {
+                endt = 1;
+            } else if (last) {
+                double t0 = 0.0, t1 = 0.0;
+                if (own) {
+                    const double po = row(dir_now > 0 ? SV_PM : SV_PP)[j];     // momentum at the other end
+                    const double rt = row(SV_RHO)[j] + rc;
+                    row(SV_RHO)[j] = rt;
+                    row(dir_now > 0 ? SV_THP : SV_THM)[j] = TH[j];
+                    row(dir_now > 0 ? SV_PP : SV_PM)[j] = p;
+                    row(dir_now > 0 ? SV_GP : SV_GM)[j] = gj;
+                    t0 = mi * po * rt;
+                    t1 = mi * p * rt;
+                }
+                solo_block_sum2(t0, t1, red, slot, wave, lane);
+                const int depth = s.depth + 1;
+                s.depth = depth;
+                const double lsw = s.lsw, lsw_sub = s.lsw_sub;
+                bool take;
+                if (lsw_sub > lsw) take = true;
+                else take = rng_uniform(rng, 0, RNG_TOP, (uint32_t)depth, 0, (uint32_t)s.iter) < exp(lsw_sub - lsw);
+                if (take) { upds = true; s.lps = s.lpq; }
+                s.lsw = log_sum_exp2(lsw, lsw_sub);
+                const bool keep_going = (t0 > 0.0) && (t1 > 0.0);
+                if (!keep_going || depth >= np.max_depth) endt = 1;
+                else {
+                    s.dir = rng_uniform(rng, 0, RNG_DIRECTION, (uint32_t)depth, 0, (uint32_t)s.iter) > 0.5 ? 1 : -1;
+                    s.leaf = 0; s.nleaves = 1 << depth; s.lsw_sub = -INFINITY;
+                    next = 2;
+                }
+            } else {
+                s.leaf = leaf_now + 1;
+            }
+        }
+        if (endt) {
+            // end of transition (Stan adapt_diag_e_nuts::transition)
+            const int nli = s.n_leap_iter;
+            const double accept = s.sum_metro / (double)(nli > 0 ? nli : 1);
+            const int iter = s.iter;
+            const bool warm = iter < np.warmup;
+            s.n_leap_total = s.n_leap_total + nli;
+            if (!warm) {
+                s.n_post = s.n_post + 1;
+                s.sum_accept = s.sum_accept + accept;
+                if (endt == 2) s.n_div = s.n_div + 1;
+                if (s.depth >= np.max_depth) s.n_maxdepth = s.n_maxdepth + 1;
+                draw = iter - np.warmup;
+                if (a.lp_draws && tid == 0) a.lp_draws[(size_t)unit * np.n_draws + draw] = s.lps;
+            }
+            bool redo_eps = false;
+            if (warm) {
+                const int cnt = s.da_counter + 1;
+                s.da_counter = cnt;
+                const double acc1 = accept > 1.0 ? 1.0 : accept;
+                const double eta = 1.0 / (cnt + np.t0);
+                const double sbar = (1.0 - eta) * s.da_sbar + eta * (np.delta - acc1);
+                s.da_sbar = sbar;
+                const double x = s.da_mu - sbar * sqrt((double)cnt) / np.gamma;
+                const double x_eta = pow((double)cnt, -np.kappa);
+                s.da_xbar = (1.0 - x_eta) * s.da_xbar + x_eta * x;
+                s.eps = exp(x);
+                const int wc = s.win_counter;
+                const bool w_act = wc >= s.init_buffer && wc < np.warmup - s.term_buffer && wc != np.warmup;
+                const bool w_end = wc == s.next_window && wc != np.warmup;
+                int win_n = s.win_n;
+                if (w_act) { win_n += 1; welf = true; wn = win_n; }
+                if (w_end) {
+                    if (s.next_window != np.warmup - s.term_buffer - 1) {
+                        const int ws = s.win_size * 2;
+                        s.win_size = ws;
+                        int nw = wc + ws;
+                        if (nw != np.warmup - s.term_buffer - 1) {
+                            const int boundary = nw + 2 * ws;
+                            if (boundary >= np.warmup - s.term_buffer) nw = np.warmup - s.term_buffer - 1;
+                        }
+                        s.next_window = nw;
+                    }
+                    wend = true; wn = win_n;
+                    win_n = 0;
+                    redo_eps = true;
+                }
+                s.win_n = win_n;
+                s.win_counter = wc + 1;
+            }
+            s.iter = iter + 1;
+            if (warm && iter + 1 == np.warmup) s.eps = exp(s.da_xbar);       // complete_adaptation
+            if (iter + 1 >= np.warmup + np.n_draws) {
+                s.phase = PH_DONE;
+                next = 0;
+            } else if (redo_eps && iter + 1 < np.warmup) {
+                s.phase = PH_EPS; s.eps_dir = 0; s.eps_trials = 0;
+                next = 3;
+            } else {
+                next = 1;
+            }
+        }
+
+        // ---- A': the trajectory continues from the point just evaluated: half kick + drift of the next leapfrog ---------------------
+        if (next == 0 && s.phase == PH_TREE) {
+            const double e1 = s.dir * s.eps;
+            if (own) {
+                const double pk = p + 0.5 * e1 * gj;
+                Pm[j] = pk;
+                TH[j] = TH[j] + e1 * mi * pk;
+            }
+        }
+        // ---- E: sample update, metric adaptation, draw output, start of the next leapfrog when the trajectory does not simply
+        //      continue (new transition, next doubling, step-size search, re-initialisation) ------------------------------------------
+        if (upds || welf || wend || draw >= 0 || next) {
+            const uint32_t iter = (uint32_t)s.iter, trial = (uint32_t)s.eps_trials, att = (uint32_t)s.init_attempt;
+            double ths = 0.0, gs = 0.0;
+            if (own && (upds || welf || wend || draw >= 0 || next == 1 || next == 3)) {
+                ths = row(upds ? SV_THQ : SV_THS)[j]; gs = row(upds ? SV_GQ : SV_GS)[j];
+            }
+            if (upds && own) { row(SV_THS)[j] = ths; row(SV_GS)[j] = gs; }
+            if ((welf || wend) && own) {
+                double *WM = Vg + (size_t)SG_WMEAN * DS, *W2 = Vg + (size_t)SG_WM2 * DS;
+                double mean = WM[j], m2 = W2[j];
+                if (welf) {            // Welford (stan::math::welford_var_estimator)
+                    const double delta = ths - mean;
+                    mean += delta / wn;
+                    m2 += (ths - mean) * delta;
+                }
+                if (wend) {            // var_adaptation::learn_variance
+                    const double var = wn > 1.0 ? m2 / (wn - 1.0) : 0.0;
+                    mi = (wn / (wn + 5.0)) * var + 1e-3 * (5.0 / (wn + 5.0));
+                    MI[j] = mi;
+                    mean = 0.0; m2 = 0.0;
+                }
+                WM[j] = mean; W2[j] = m2;
+            }
+            if (draw >= 0 && own) a.draws[((size_t)unit * np.n_draws + draw) * D + j] = ths;
+            if (next == 1 || next == 3) {
+                // fresh momentum p ~ N(0, M): normals 2i, 2i+1 from one Philox block (same streams as nuts_kernel)
+                if (2 * tid < D) {
+                    double z0, z1;
+                    rng_normal_pair(rng, (uint32_t)tid, next == 1 ? RNG_MOMENTUM : RNG_EPS_MOMENTUM, next == 1 ? 0u : trial, iter, z0, z1);
+                    zrow[2 * tid] = z0; zrow[2 * tid + 1] = z1;
+                }
+                __syncthreads();
+                double pn = 0.0, kin0 = 0.0, dummy = 0.0;
+                if (own) { pn = zrow[j] / sqrt(mi); kin0 = mi * pn * pn; }
+                solo_block_sum2(kin0, dummy, red, slot, wave, lane);
+                s.H0 = -s.lps + 0.5 * kin0;
+                if (next == 1) {
+                    s.lsw = 0.0; s.lsw_sub = -INFINITY; s.depth = 0; s.leaf = 0; s.nleaves = 1;
+                    s.n_leap_iter = 0; s.sum_metro = 0.0;
+                    s.dir = rng_uniform(rng, 0, RNG_DIRECTION, 0, 0, (uint32_t)s.iter) > 0.5 ? 1 : -1;
+                }
+                const double e1 = next == 1 ? s.dir * s.eps : s.eps;
+                if (own) {
+                    if (next == 1) {
+                        row(SV_THM)[j] = ths; row(SV_THP)[j] = ths;
+                        row(SV_PM)[j] = pn; row(SV_PP)[j] = pn;
+                        row(SV_GM)[j] = gs; row(SV_GP)[j] = gs;
+                        row(SV_RHO)[j] = pn;
+                    }
+                    const double pk = pn + 0.5 * e1 * gs;
+                    Pm[j] = pk;
+                    TH[j] = ths + e1 * mi * pk;
+                }
+            } else if (next == 2) {
+                // continue from the trajectory end in the new direction
+                const int dir = s.dir;
+                const double e1 = dir * s.eps;
+                if (own) {
+                    double et, ep, eg;
+                    if (dir == dir_now) { et = TH[j]; ep = p; eg = gj; }
+                    else { et = row(dir > 0 ? SV_THP : SV_THM)[j]; ep = row(dir > 0 ? SV_PP : SV_PM)[j]; eg = row(dir > 0 ? SV_GP : SV_GM)[j]; }
+                    const double pk = ep + 0.5 * e1 * eg;
+                    Pm[j] = pk;
+                    TH[j] = et + e1 * mi * pk;
+                }
+            } else if (next == 4) {
+                if (own) {
+                    TH[j] = np.init_radius * (2.0 * rng_uniform(rng, (uint32_t)j, RNG_INIT, 0, att, 0) - 1.0);
+                    Pm[j] = 0.0;
+                }
+            }
+        }
+        __syncthreads();                                   // theta / momentum rows complete before the next evaluation
+    }
+
+    // ---- write the chain back ---------------------------------------------------------------------------------------------------
+    __syncthreads();
+    for (int v = 0; v < SV_COUNT; ++v)
+        if (own) Vg[(size_t)v * DS + j] = row(v)[j];
+    if (tid == 0) {
+        a.states[unit] = s;
+        if (my_leaps) atomicAdd(a.leap_counter, my_leaps);
+        const int ph = s.phase;
+        if (!(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)) atomicAdd(a.done_counter, 1);
+    }
+}
+
+// evaluator of the solo path on its own (parity tests): one workgroup per point, theta / grad [B x D] in global memory
+__global__ __launch_bounds__(SOLO_NT) void solo_eval_kernel(const DevProblem *__restrict__ Pp, SoloGeom g, const double *theta,
+                                                            const int *spec, int jacobian, double *lp, double *grad)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const DevProblem &P = *Pp;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    double *TH = smem + g.o_vec, *GR = TH + g.DSS, *lps = smem + g.o_scv + 12;
+    if (tid < g.DSS) { TH[tid] = tid < g.D ? theta[(size_t)b * g.D + tid] : 0.0; GR[tid] = 0.0; }
+    solo_eval_init(P, g, smem, tid);
+    const SoloEvalRegs er = solo_eval_setup(P, g, spec ? spec[b] : 0, tid);
+    __syncthreads();
+    solo_eval(P, g, smem, TH, GR, lps, er, jacobian, tid);
+    if (tid < g.D && grad) grad[(size_t)b * g.D + tid] = GR[tid];
+    if (tid == 0 && lp) lp[b] = *lps;
+}
+
 struct Sampler {
     Problem *prob = nullptr;
     NutsParams np;
@@ -1009,6 +1392,8 @@ struct Sampler {
     bool use_s1 = false;     // S1 evaluator with theta rows resident in LDS (MODE 2)
     bool s1_hbm = false;     // S1 evaluator, sampler state in HBM (MODE 3: outlier parameters, K near 192)
     bool hw = false;         // general half-wave evaluator (MODE 4: several distributions, parallel blocks)
+    bool solo = false;       // one chain per workgroup, state in LDS (bdrt_solo.h): few chains of the headline family
+    SoloGeom geom;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double ms_total = 0.0;
@@ -1075,14 +1460,20 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     memset(&S.args, 0, sizeof(S.args));
     S.prob = &P;
     S.n_units = n_units;
-    // chains per workgroup: fill every CU with one workgroup before putting a second chain on any wave
+    // few chains of the headline family on log-uniform grids: one chain per workgroup (bdrt_solo.h)
+    int n_cu = 256;
     {
         hipDeviceProp_t prop;
-        int n_cu = 256;
         if (hipGetDeviceProperties(&prop, P.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    }
+    S.solo = solo_capable(P.dev) && n_units <= 4 * n_cu;
+    if (const char *e = getenv("BDRT_SOLO")) S.solo = solo_capable(P.dev) && atoi(e) != 0;      // diagnostics: force / forbid
+    if (S.solo) S.geom = solo_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
+    // chains per workgroup: fill every CU with one workgroup before putting a second chain on any wave
+    {
         int cpw = (n_units + n_cu - 1) / n_cu;
         if (const char *e = getenv("BDRT_CHAINS_PER_WG")) cpw = atoi(e);     // diagnostics: force a packing
-        S.args.cpw = std::min(NC, std::max(1, cpw));
+        S.args.cpw = S.solo ? 1 : std::min(NC, std::max(1, cpw));
     }
     S.n_wg = (n_units + S.args.cpw - 1) / S.args.cpw;
     S.D = P.dev.D;
@@ -1106,10 +1497,14 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     for (int u = 0; u < n_units; ++u)
         if (spec && (spec[u] < 0 || spec[u] >= P.dev.n_spectra)) return fail("bdrt_sampler_create: spectrum index out of range");
 
-    const int DS = S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : 32 * 27);   // = 32*NJ of the kernel instantiation
+    // row stride of the state vectors = 32*NJ of the kernel instantiation; the solo kernel keeps [unit][row][ds] with one column
+    const int DS = S.solo ? S.geom.DSS : (S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : 32 * 27));
     if (S.D > 32 * 27) { set_error("bdrt_sampler_create: D = %d > 864 not supported", S.D); bdrt_sampler_destroy(s); return nullptr; }
     S.args.ds = DS;
-    const size_t nvec = (size_t)S.n_wg * V_COUNT * NC * DS;
+    const int ncol = S.solo ? 1 : NC, nrow = S.solo ? (int)SG_COUNT : (int)V_COUNT;
+    const int r_minv = S.solo ? (int)SV_MINV : (int)V_MINV, r_th = S.solo ? (int)SV_TH : (int)V_TH;
+    if (S.solo) S.lds_bytes = (size_t)S.geom.total * sizeof(double) + 64;
+    const size_t nvec = (size_t)S.n_wg * nrow * ncol * DS;
     std::vector<double> hv(nvec, 0.0);
     std::vector<ChainState> hs((size_t)n_units);
     for (int u = 0; u < n_units; ++u) {
@@ -1123,19 +1518,19 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         st.dir = 1;
         st.lsw_sub = -INFINITY;
         window_init(st, warmup, c.init_buffer, c.term_buffer, c.base_window);
-        const int wg = u / S.args.cpw, cc = slot_col(u % S.args.cpw);
-        double *V = hv.data() + (size_t)wg * V_COUNT * NC * DS;
+        const int wg = u / S.args.cpw, cc = S.solo ? 0 : slot_col(u % S.args.cpw);
+        double *V = hv.data() + (size_t)wg * nrow * ncol * DS;
         const Philox rng = {S.np.seed_lo, S.np.seed_hi, (uint32_t)st.chain_id};
         for (int j = 0; j < S.D; ++j) {
-            V[((size_t)V_MINV * NC + cc) * DS + j] = 1.0;
-            V[((size_t)V_TH * NC + cc) * DS + j] =
+            V[((size_t)r_minv * ncol + cc) * DS + j] = 1.0;
+            V[((size_t)r_th * ncol + cc) * DS + j] =
                 init_theta ? init_theta[(size_t)u * S.D + j]
                            : c.init_radius * (2.0 * rng_uniform(rng, (uint32_t)j, RNG_INIT, 0, 0, 0) - 1.0);
         }
         if (!init_theta) st.init_attempt = 0;
     }
     // unused columns (cpw < 16, last workgroup): finite placeholders
-    for (int wg = 0; wg < S.n_wg; ++wg)
+    for (int wg = 0; wg < S.n_wg && !S.solo; ++wg)
         for (int k = 0; k < NC; ++k) {
             if (k < S.args.cpw && wg * S.args.cpw + k < n_units) continue;
             double *V = hv.data() + (size_t)wg * V_COUNT * NC * DS;
@@ -1165,7 +1560,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
                                (const void *)nuts_kernel<11, 2>, (const void *)nuts_kernel<16, 2>,
                                (const void *)nuts_kernel<11, 3>, (const void *)nuts_kernel<16, 3>,
                                (const void *)nuts_kernel<11, 4>, (const void *)nuts_kernel<16, 4>, (const void *)nuts_kernel<27, 4>};
-        hipError_t e = hipSuccess;
+        hipError_t e = hipFuncSetAttribute((const void *)nuts_solo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         for (int i = 0; i < 13 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         return e;
@@ -1213,7 +1608,9 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             if (tp) hipLaunchKernelGGL((nuts_kernel<NJV, 1>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args); \
             else hipLaunchKernelGGL((nuts_kernel<NJV, 0>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);   \
         } while (0)
-        if (S.use_s1 && S.D <= 32 * 11)
+        if (S.solo)
+            hipLaunchKernelGGL(nuts_solo_kernel, dim3(S.n_units), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
+        else if (S.use_s1 && S.D <= 32 * 11)
             hipLaunchKernelGGL((nuts_kernel<11, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
         else if (S.use_s1)
             hipLaunchKernelGGL((nuts_kernel<16, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
@@ -1378,6 +1775,32 @@ const double *bdrt_sampler_draws_dev(bdrt_sampler *s)
     if (!s) return nullptr;
     hipStreamSynchronize(s->impl.stream);
     return s->impl.args.draws;
+}
+
+/* parity-test hook (not part of include/bdrt.h): the evaluator of the one-chain-per-workgroup path on B points */
+int bdrt_debug_solo_logp_grad(bdrt_problem *p, const double *theta, const int *spec, int B, int jacobian, double *lp, double *grad)
+{
+    if (!p || !theta || B < 1) { set_error("bdrt_debug_solo_logp_grad: bad arguments"); return -1; }
+    Problem &P = p->impl;
+    if (!solo_capable(P.dev)) { set_error("problem does not take the solo path"); return -2; }
+    BDRT_HIP(hipSetDevice(P.device));
+    const SoloGeom g = solo_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
+    const size_t lds = (size_t)g.total * sizeof(double) + 64;
+    BDRT_HIP(hipFuncSetAttribute((const void *)solo_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    double *dth = nullptr, *dlp = nullptr, *dg = nullptr;
+    int *dsp = nullptr;
+    const size_t nb = (size_t)B * P.dev.D * sizeof(double);
+    BDRT_HIP(hipMalloc((void **)&dth, nb)); BDRT_HIP(hipMalloc((void **)&dg, nb)); BDRT_HIP(hipMalloc((void **)&dlp, B * sizeof(double)));
+    BDRT_HIP(hipMemcpy(dth, theta, nb, hipMemcpyHostToDevice));
+    if (spec) { BDRT_HIP(hipMalloc((void **)&dsp, B * sizeof(int))); BDRT_HIP(hipMemcpy(dsp, spec, B * sizeof(int), hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(solo_eval_kernel, dim3(B), dim3(SOLO_NT), lds, 0, (const DevProblem *)P.d_dev, g, dth, dsp, jacobian, dlp, dg);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && lp) e = hipMemcpy(lp, dlp, B * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && grad) e = hipMemcpy(grad, dg, nb, hipMemcpyDeviceToHost);
+    hipFree(dth); hipFree(dg); hipFree(dlp); hipFree(dsp);
+    if (e != hipSuccess) { set_error("bdrt_debug_solo_logp_grad: %s", hipGetErrorString(e)); return -10; }
+    return 0;
 }
 
 int bdrt_sample(bdrt_problem *p, int n_units, const int *spec, const int *chain_id, int warmup, int n_draws,
