@@ -1054,7 +1054,17 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_solo_kernel(const DevProblem *__
         const double e = ph0 == PH_EPS ? s.eps : (ph0 == PH_TREE ? s.dir * s.eps : 0.0);
 
         // ---- B: log-posterior + gradient at the new point ------------------------------------------------------------------
-        solo_eval(P, g, smem, TH, G, lps_l, er, 1, tid);
+        long long *prof = a.prof ? a.prof + (size_t)unit * 32 : nullptr;
+        // the uniform that decides whether this leaf replaces the subtree's proposal depends on (leaf, depth, iteration)
+        // only: wave 7, which has no per-element work in the first phases of the evaluation, draws it now (Philox, ~200
+        // integer instructions) and publishes it through LDS, off the other waves' critical path
+        if (ph0 == PH_TREE && wave == SOLO_NW - 1) {
+            const double u = rng_uniform(rng, (uint32_t)s.leaf, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
+            if (lane == 0) lps_l[1] = u;
+        }
+        solo_eval(P, g, smem, TH, G, lps_l, er, 1, tid, prof);
+        long long tsp = (prof && tid == 0) ? clock64() : 0;
+#define BDRT_SOLO_NPROF(slot) do { if (prof && tid == 0) { const long long t_ = clock64(); prof[slot] += t_ - tsp; tsp = t_; } } while (0)
 
         // ---- C: second half kick, kinetic energy, finiteness of the gradient ----------------------------------------------------
         double p = 0.0, gj = 0.0, mi = 1.0;
@@ -1067,6 +1077,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_solo_kernel(const DevProblem *__
         }
         solo_block_sum2(kin, nonfin, red, slot, wave, lane);
         kin *= 0.5;
+        BDRT_SOLO_NPROF(5);
 
         // ---- S1: scalar logic after the evaluation (identical in every thread) ---------------------------------------------------
         bool copyq = false, cur2s = false, tree = false, last = false;
@@ -1132,7 +1143,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_solo_kernel(const DevProblem *__
                     endt = 2;
                 } else {
                     const double lsw_new = log_sum_exp2(s.lsw_sub, w);
-                    const double u = rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
+                    const double u = lps_l[1];                          // drawn by wave 7 before the evaluation
                     if (leaf_now == 0 || u < exp(w - lsw_new)) { copyq = true; s.lpq = lp; }
                     s.lsw_sub = lsw_new;
                     tree = true;
@@ -1142,6 +1153,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_solo_kernel(const DevProblem *__
             }
         }
 
+        BDRT_SOLO_NPROF(6);
         // ---- D: proposal copy, checkpoints, U-turn tests, subtree close ----------------------------------------------------------
         if ((copyq || cur2s) && own) {
             const double th = TH[j];
@@ -1268,6 +1280,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_solo_kernel(const DevProblem *__
             }
         }
 
+        BDRT_SOLO_NPROF(7);
         // ---- A': the trajectory continues from the point just evaluated: half kick + drift of the next leapfrog ---------------------
         if (next == 0 && s.phase == PH_TREE) {
             const double e1 = s.dir * s.eps;
@@ -1352,6 +1365,8 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_solo_kernel(const DevProblem *__
             }
         }
         __syncthreads();                                   // theta / momentum rows complete before the next evaluation
+        BDRT_SOLO_NPROF(8);
+#undef BDRT_SOLO_NPROF
     }
 
     // ---- write the chain back ---------------------------------------------------------------------------------------------------
