@@ -44,6 +44,12 @@ class OptReport(C.Structure):
                 ('grad_norm', C.c_double), ('newton_iterations', C.c_int), ('grad_inf', C.c_double)]
 
 
+class RidgeOptions(C.Structure):
+    _fields_ = [('n', C.c_int), ('K', C.c_int), ('off', C.c_int), ('penalty', C.c_int), ('max_iter', C.c_int),
+                ('hyper_lambda', C.c_int), ('zero_delta1', C.c_int), ('xtol', C.c_double), ('hl_fbeta', C.c_double),
+                ('reg_ord', C.c_double * 3)]
+
+
 class NutsControl(C.Structure):
     _fields_ = [('adapt_delta', C.c_double), ('adapt_t0', C.c_double), ('adapt_gamma', C.c_double),
                 ('adapt_kappa', C.c_double), ('max_treedepth', C.c_int), ('init_buffer', C.c_int),
@@ -66,7 +72,7 @@ SYMBOLS = [
     'bdrt_sampler_run', 'bdrt_sampler_results', 'bdrt_sampler_total_leapfrogs', 'bdrt_sampler_kernel_time',
     'bdrt_sampler_phase_profile',
     'bdrt_sample',
-    'bdrt_gram', 'bdrt_qp_box', 'bdrt_qp_box_batch',
+    'bdrt_gram', 'bdrt_qp_box', 'bdrt_qp_box_batch', 'bdrt_ridge',
     'bdrt_percentiles', 'bdrt_sampler_percentiles', 'bdrt_sampler_summary', 'bdrt_summary', 'bdrt_sampler_draws_dev',
     'bdrt_last_error', 'bdrt_device_count', 'bdrt_set_device', 'bdrt_version',
 ]
@@ -125,6 +131,7 @@ def load_library():
     lib.bdrt_gram.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.bdrt_qp_box.argtypes = [vp, vp, vp, C.c_int, vp, vp]
     lib.bdrt_qp_box_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    lib.bdrt_ridge.argtypes = [C.POINTER(RidgeOptions), C.c_int, C.c_int] + [vp] * 20
     lib.bdrt_percentiles.argtypes = [vp, C.c_int, C.c_int, C.c_long, vp, C.c_int, vp, vp, C.c_int, vp]
     lib.bdrt_sampler_percentiles.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
     lib.bdrt_sampler_summary.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]

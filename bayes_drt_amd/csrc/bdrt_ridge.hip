@@ -92,18 +92,38 @@ int bdrt_gram(const double *WA, const double *WZ, int nrows, int n, const double
     return 0;
 }
 
-// min 1/2 x'Px + q'x  s.t.  x >= lo.  Variables: slack s = x - lo > 0, multiplier z > 0.
-//   r_d = P x + q - z = 0 ;  s z = mu.
-// Newton step with (P + diag(z/s)) dx = -(r_d) + (sigma mu - s z)/s ... (Mehrotra predictor-corrector).
+// min 1/2 x'Px + q'x  s.t.  x >= lo  -- the QP of Inverter._convex_opt (reference inversion.py:1043-1067), solved the way
+// the reference's solver does.  cvxopt (setup.py:20, unpinned; not under /root/reference) documents `solvers.qp` as its
+// `coneqp` path-following method: Mehrotra predictor-corrector with Nesterov-Todd scaling, which for the nonnegative
+// orthant (G = -I, h = -lo) is the standard primal-dual Newton system.  Restated here in unscaled variables:
+//   start   (P + diag(b)) x = -q + b lo  (b = 1 on bounded variables);  s = x - lo, z = -s; each shifted into the interior by
+//           1 + max(-s) resp. 1 + max(-z) when not already interior (tolerance 1e-8 max(1, |.|))
+//   iterate r_x = P x + q - z,  r_z = s - (x - lo);  stop when |r_z| / max(1,|lo|) <= feastol, |r_x| / max(1,|q|) <= feastol
+//           and (gap <= abstol or gap / |cost| <= reltol), gap = s'z, at most 100 iterations;
+//           affine direction (sigma = 0):   (P + diag(z/s)) dx = -r_x + (r_c + z r_z) / s,  ds = dx - r_z,  dz = (r_c - z ds) / s
+//           with r_c = -s z;  step t = min(1, 1 / max(-ds/s, -dz/z));  sigma = clip(1 - t + t^2 ds'dz / gap, 0, 1)^3;
+//           corrector  r_c = -s z - ds_a dz_a + sigma gap / m;  step = min(1, 0.99 / max(-ds/s, -dz/z)).
+// The ridge problems are nearly flat (objective changes of 1e-7 relative move coefficients by 10 %), so the point on the
+// central path where the iteration stops is part of the reference's answer: tests/test_ridge_reference.py checks this
+// solver against solutions and objectives cvxopt itself produced (stored in the reference's pickled fits).
 int bdrt_qp_box(const double *P, const double *q, const double *lo, int n, double *x, double *primal_objective)
 {
     if (!P || !q || !x || n < 1) { set_error("bdrt_qp_box: bad arguments"); return -1; }
-    const double abstol = 1e-7, reltol = 1e-6, feastol = 1e-7;      // cvxopt.solvers defaults
+    const double abstol = 1e-7, reltol = 1e-6, feastol = 1e-7;      // cvxopt.solvers.options defaults
+    const int max_it = 100;                                          // cvxopt 'maxiters'
     std::vector<char> bounded(n);
-    std::vector<double> l(n), s(n), z(n), rd(n), rhs(n), dx(n), ds(n), dz(n), Px(n), M((size_t)n * n);
-    for (int i = 0; i < n; ++i) { bounded[i] = lo ? std::isfinite(lo[i]) : 0; l[i] = bounded[i] ? lo[i] : 0.0; }
-    // start: strictly feasible, unit slacks and multipliers
-    for (int i = 0; i < n; ++i) { x[i] = bounded[i] ? l[i] + 1.0 : 0.0; s[i] = 1.0; z[i] = bounded[i] ? 1.0 : 0.0; }
+    std::vector<double> l(n), s(n, 0.0), z(n, 0.0), rx(n), rz(n, 0.0), rhs(n), dx(n), ds(n, 0.0), dz(n, 0.0), dsa(n, 0.0), dza(n, 0.0),
+        Px(n), M((size_t)n * n), xv(n);
+    int nb = 0;
+    double qq = 0.0, hh = 0.0;
+    for (int i = 0; i < n; ++i) {
+        bounded[i] = lo ? std::isfinite(lo[i]) : 0;
+        l[i] = bounded[i] ? lo[i] : 0.0;
+        nb += bounded[i];
+        qq += q[i] * q[i];
+        hh += l[i] * l[i];
+    }
+    const double resx0 = std::max(1.0, std::sqrt(qq)), resz0 = std::max(1.0, std::sqrt(hh));
     auto matvec = [&](const std::vector<double> &v, std::vector<double> &out) {
         for (int i = 0; i < n; ++i) {
             double t = 0;
@@ -112,86 +132,106 @@ int bdrt_qp_box(const double *P, const double *q, const double *lo, int n, doubl
             out[i] = t;
         }
     };
-    std::vector<double> xv(x, x + n);
-    int nb = 0;
-    for (int i = 0; i < n; ++i) nb += bounded[i];
-    double qnorm = 0;
-    for (int i = 0; i < n; ++i) qnorm += q[i] * q[i];
-    qnorm = std::max(1.0, std::sqrt(qnorm));
-    int it = 0;
-    const int max_it = 200;
-    for (; it < max_it; ++it) {
-        matvec(xv, Px);
-        double pobj = 0, gap = 0, rdn = 0;
-        for (int i = 0; i < n; ++i) {
-            pobj += xv[i] * (0.5 * Px[i] + q[i]);
-            rd[i] = Px[i] + q[i] - z[i];
-            rdn += rd[i] * rd[i];
-            if (bounded[i]) gap += s[i] * z[i];
-        }
-        rdn = std::sqrt(rdn);
-        // dual objective = pobj - gap when r_d = 0
-        const double dobj = pobj - gap;
-        double relgap = INFINITY;
-        if (pobj < 0) relgap = gap / -pobj; else if (dobj > 0) relgap = gap / dobj;
-        if (rdn / qnorm <= feastol && (gap <= abstol || relgap <= reltol)) break;
-        const double mu = nb ? gap / nb : 0.0;
-        // factor M = P + diag(z/s)
+    // factor sym(P) + diag(dg) (+ reg I when only semi-definite); L receives the factor
+    std::vector<double> L;
+    auto factor = [&](const std::vector<double> &dg) -> bool {
         for (int i = 0; i < n; ++i)
             for (int j = 0; j <= i; ++j) M[(size_t)i * n + j] = 0.5 * (P[(size_t)i * n + j] + P[(size_t)j * n + i]);
-        for (int i = 0; i < n; ++i) if (bounded[i]) M[(size_t)i * n + i] += z[i] / s[i];
+        for (int i = 0; i < n; ++i) M[(size_t)i * n + i] += dg[i];
         double reg = 0.0;
-        std::vector<double> L = M;
-        while (!cholesky_lower(L, n)) {                 // P may be only semi-definite: regularise
+        L = M;
+        while (!cholesky_lower(L, n)) {
             reg = reg == 0.0 ? 1e-14 * (1.0 + std::fabs(M[0])) : reg * 100.0;
             L = M;
             for (int i = 0; i < n; ++i) L[(size_t)i * n + i] += reg;
-            if (reg > 1e6) { set_error("bdrt_qp_box: KKT matrix not positive definite"); return -3; }
+            if (reg > 1e6) return false;
         }
-        auto solve_dir = [&](double sigma_mu, const std::vector<double> *dsa, const std::vector<double> *dza) {
-            // complementarity residual rc_i = sigma_mu - s_i z_i (- dsa_i dza_i for the corrector)
+        return true;
+    };
+    // ---- starting point ----
+    {
+        std::vector<double> dg(n);
+        for (int i = 0; i < n; ++i) { dg[i] = bounded[i] ? 1.0 : 0.0; xv[i] = -q[i] + (bounded[i] ? l[i] : 0.0); }
+        if (!factor(dg)) { set_error("bdrt_qp_box: KKT matrix not positive definite"); return -3; }
+        cholesky_solve(L, n, xv);
+        double nrms = 0.0, ts = -INFINITY, tz = -INFINITY;
+        for (int i = 0; i < n; ++i)
+            if (bounded[i]) {
+                s[i] = xv[i] - l[i]; z[i] = -s[i];
+                nrms += s[i] * s[i];
+                ts = std::max(ts, -s[i]); tz = std::max(tz, -z[i]);
+            }
+        nrms = std::sqrt(nrms);                                     // |s| = |z|
+        if (nb && ts >= -1e-8 * std::max(nrms, 1.0)) for (int i = 0; i < n; ++i) if (bounded[i]) s[i] += 1.0 + ts;
+        if (nb && tz >= -1e-8 * std::max(nrms, 1.0)) for (int i = 0; i < n; ++i) if (bounded[i]) z[i] += 1.0 + tz;
+    }
+    int it = 0, status = 0;
+    for (;; ++it) {
+        matvec(xv, Px);
+        double f0a = 0, f0b = 0, gap = 0, resx = 0, resz = 0, zrz = 0;
+        for (int i = 0; i < n; ++i) {
+            const double r0 = Px[i] + q[i];
+            f0a += xv[i] * r0; f0b += xv[i] * q[i];
+            rx[i] = r0 - (bounded[i] ? z[i] : 0.0);
+            resx += rx[i] * rx[i];
+            if (bounded[i]) {
+                rz[i] = s[i] - (xv[i] - l[i]);
+                resz += rz[i] * rz[i];
+                zrz += z[i] * rz[i];
+                gap += s[i] * z[i];
+            }
+        }
+        resx = std::sqrt(resx); resz = std::sqrt(resz);
+        const double pcost = 0.5 * (f0a + f0b), dcost = pcost + zrz - gap;
+        double relgap = INFINITY;
+        if (pcost < 0) relgap = gap / -pcost; else if (dcost > 0) relgap = gap / dcost;
+        if (resz / resz0 <= feastol && resx / resx0 <= feastol && (gap <= abstol || relgap <= reltol)) break;
+        if (it == max_it) { status = -4; break; }
+        std::vector<double> dg(n);
+        for (int i = 0; i < n; ++i) dg[i] = bounded[i] ? z[i] / s[i] : 0.0;
+        if (!factor(dg)) { set_error("bdrt_qp_box: KKT matrix not positive definite"); return -3; }
+        const double mu = nb ? gap / nb : 0.0;
+        auto solve_dir = [&](double sigma_mu, bool corrector) {
             for (int i = 0; i < n; ++i) {
-                double rc = 0.0;
+                double t = 0.0;
                 if (bounded[i]) {
-                    rc = sigma_mu - s[i] * z[i];
-                    if (dsa) rc -= (*dsa)[i] * (*dza)[i];
+                    double rc = sigma_mu - s[i] * z[i];
+                    if (corrector) rc -= dsa[i] * dza[i];
+                    t = (rc + z[i] * rz[i]) / s[i];
                 }
-                rhs[i] = -rd[i] + (bounded[i] ? rc / s[i] : 0.0);
+                rhs[i] = -rx[i] + t;
             }
             dx = rhs;
             cholesky_solve(L, n, dx);
-            for (int i = 0; i < n; ++i) {
+            for (int i = 0; i < n; ++i)
                 if (bounded[i]) {
                     double rc = sigma_mu - s[i] * z[i];
-                    if (dsa) rc -= (*dsa)[i] * (*dza)[i];
-                    ds[i] = dx[i];
+                    if (corrector) rc -= dsa[i] * dza[i];
+                    ds[i] = dx[i] - rz[i];
                     dz[i] = (rc - z[i] * ds[i]) / s[i];
-                } else { ds[i] = 0; dz[i] = 0; }
-            }
+                }
         };
-        auto max_step = [&]() {
-            double a = 1.0;
-            for (int i = 0; i < n; ++i) {
-                if (!bounded[i]) continue;
-                if (ds[i] < 0) a = std::min(a, -s[i] / ds[i]);
-                if (dz[i] < 0) a = std::min(a, -z[i] / dz[i]);
-            }
-            return a;
+        auto boundary = [&]() {                                     // t = max(0, max -ds/s, max -dz/z)
+            double t = 0.0;
+            for (int i = 0; i < n; ++i)
+                if (bounded[i]) { t = std::max(t, -ds[i] / s[i]); t = std::max(t, -dz[i] / z[i]); }
+            return t;
         };
-        // predictor (affine scaling)
-        solve_dir(0.0, nullptr, nullptr);
-        const double a_aff = max_step();
-        double gap_aff = 0;
-        for (int i = 0; i < n; ++i) if (bounded[i]) gap_aff += (s[i] + a_aff * ds[i]) * (z[i] + a_aff * dz[i]);
-        double sigma = nb && gap > 0 ? std::pow(gap_aff / gap, 3.0) : 0.0;
+        solve_dir(0.0, false);
+        double dsdz = 0.0;
+        for (int i = 0; i < n; ++i) if (bounded[i]) dsdz += ds[i] * dz[i];
+        double t = boundary();
+        double step = t == 0.0 ? 1.0 : std::min(1.0, 1.0 / t);
+        double sigma = gap > 0 ? 1.0 - step + dsdz / gap * step * step : 0.0;
         sigma = std::min(1.0, std::max(0.0, sigma));
-        std::vector<double> dsa = ds, dza = dz;
-        // corrector
-        solve_dir(sigma * mu, &dsa, &dza);
-        const double a = std::min(1.0, 0.99 * max_step());
+        sigma = sigma * sigma * sigma;
+        dsa = ds; dza = dz;
+        solve_dir(sigma * mu, true);
+        t = boundary();
+        step = t == 0.0 ? 1.0 : std::min(1.0, 0.99 / t);
         for (int i = 0; i < n; ++i) {
-            xv[i] += a * dx[i];
-            if (bounded[i]) { s[i] += a * ds[i]; z[i] += a * dz[i]; s[i] = xv[i] - l[i] > 0 ? xv[i] - l[i] : s[i]; }
+            xv[i] += step * dx[i];
+            if (bounded[i]) { s[i] += step * ds[i]; z[i] += step * dz[i]; }
         }
     }
     memcpy(x, xv.data(), sizeof(double) * n);
@@ -201,7 +241,7 @@ int bdrt_qp_box(const double *P, const double *q, const double *lo, int n, doubl
         for (int i = 0; i < n; ++i) pobj += xv[i] * (0.5 * Px[i] + q[i]);
         *primal_objective = pobj;
     }
-    if (it >= max_it) { set_error("bdrt_qp_box: iteration limit"); return -4; }
+    if (status == -4) { set_error("bdrt_qp_box: iteration limit"); return -4; }
     return it;
 }
 

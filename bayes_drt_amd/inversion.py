@@ -10,6 +10,7 @@ with `from bayes_drt_amd.inversion import Inverter`.  What runs where:
 Out of scope (drift fits, MultiDist, fitY/SA, peak fitting, plotting, file loaders) raise
 NotImplementedError instead of silently doing something else.
 """
+import ctypes as C
 import os
 import warnings
 from copy import deepcopy
@@ -60,46 +61,66 @@ def _qp_batch(P, q, lo):
     return x, obj
 
 
-class _QPBatcher(object):
-    """Rendezvous of the independent ridge fits of a Re-Im cross-validation: each fit (one thread) hands in its QP and
-    waits; when every fit still running has handed one in, the last arrival solves them all in one batched launch.
-    A failed launch is delivered to every waiting fit (each re-raises it), never left pending."""
+class _PhaseOffsets(object):
+    """`correct_phase_offset` of ridge_fit (reference :302-338 initial estimate, :565-632 update inside the hyper-lambda loop):
+    one constant phase offset per current-range (IERange) step of the instrument, fitted between two QP solves by
+    minimising the phase residual against the current model plus an exponential prior on the offsets.  Frequencies are
+    expected in descending order (instrument order), as the reference's index arithmetic assumes."""
 
-    def __init__(self, n_workers):
-        import threading
-        self.cv = threading.Condition()
-        self.alive = n_workers
-        self.pending = []            # [P, q, lo, slot]
+    def __init__(self, frequencies, Z, IERange, lambda_phz, init_estimate):
+        self.lambda_phz = lambda_phz
+        self.phz_exp = np.angle(Z, deg=True)
+        # steps of IERange, walking from low to high frequency; the last index closes the last segment
+        self.steps = np.append(np.where(np.diff(np.asarray(IERange)[::-1]) != 0)[0] + 1, len(frequencies))
+        self.offsets = np.zeros(len(self.steps))
+        offset_vec = np.zeros(len(Z))
+        adj = self.phz_exp.copy()[::-1]
+        if init_estimate:
+            for i, idx in enumerate(self.steps[:-1]):
+                d = np.diff(adj)
+                guess = adj[idx - 1] + (d[idx - 2] + d[idx]) / 2          # interpolated first difference across the step
+                self.offsets[i] = guess - adj[idx]
+                offset_vec[idx:self.steps[i + 1]] += self.offsets[i]
+                adj[idx:self.steps[i + 1]] += self.offsets[i]
+        self._store(Z, adj[::-1], offset_vec[::-1])
+        self.Z = self.Z_adj.copy()                                        # what the loop treats as "the data" from here on
 
-    def _flush(self):
-        items, self.pending = self.pending, []
-        try:
-            x, obj = _qp_batch(np.stack([it[0] for it in items]), np.stack([it[1] for it in items]), items[0][2])
-            for k, it in enumerate(items):
-                it[3]['x'], it[3]['obj'] = x[k], obj[k]
-        except BaseException as e:                       # noqa: BLE001 -- handed to every waiter
-            for it in items:
-                it[3]['err'] = e
-        self.cv.notify_all()
+    def _store(self, Z, phz_adj, offset_vec):
+        mod = np.abs(Z)
+        self.phz_adj, self.offset_vec = phz_adj, offset_vec
+        self.Z_adj = mod * np.cos(np.deg2rad(phz_adj)) + 1j * mod * np.sin(np.deg2rad(phz_adj))
 
-    def solve(self, P, q, lo):
-        slot = {}
-        with self.cv:
-            self.pending.append([P, q, lo, slot])
-            if len(self.pending) == self.alive:
-                self._flush()
-            else:
-                while 'x' not in slot and 'err' not in slot:
-                    self.cv.wait()
-        if 'err' in slot:
-            raise slot['err']
-        return slot['x'], slot['obj']
+    def _shifted(self, x):
+        adj = self.phz_exp.copy()[::-1]
+        vec = np.zeros(len(adj))
+        for i, (idx, off) in enumerate(zip(self.steps[:-1], x)):
+            vec[idx:self.steps[i + 1]] = off
+            adj[idx:self.steps[i + 1]] += off
+        return adj, vec
 
-    def leave(self):
-        with self.cv:
-            self.alive -= 1
-            if self.pending and len(self.pending) == self.alive:
-                self._flush()
+    def update(self, Z_pred):
+        from scipy.optimize import minimize
+        pred = np.angle(Z_pred, deg=True)
+        var = np.var(np.angle(self.Z, deg=True) - pred)
+
+        def cost(x):
+            adj, _ = self._shifted(x)
+            return 0.5 * np.sum((adj - pred[::-1]) ** 2) / var + self.lambda_phz * np.sum(np.abs(x))
+        self.offsets = minimize(cost, x0=self.offsets)['x']
+        adj, vec = self._shifted(self.offsets)
+        self._store(self.Z, adj[::-1], vec[::-1])
+        return self.Z_adj
+
+    @staticmethod
+    def scale_ratio(st, inv):
+        """target_scaled / target of the reference (:628): the factor that takes an adjusted target to the fitted scale."""
+        if not st['scale_Z']:
+            return 1.0
+        return 1.0 / inv._Z_scale if st['series'] else inv._Z_scale
+
+    def snapshot(self):
+        return {'phase_offsets': self.offsets.copy(), 'offset_vec': self.offset_vec.copy(), 'Zphz_adj': self.phz_adj.copy(),
+                'Z_adj': self.Z_adj.copy()}
 
 
 def _dist_equal(a, b):
@@ -234,7 +255,12 @@ class Inverter:
                   hw_wbar=1, xtol=1e-3, max_iter=20, hyper_a=False, alpha_a=2, hl_beta_a=2, hyper_b=False, sb=1,
                   correct_phase_offset=False, IERange=None, lambda_phz=1, init_phase_offset=False, x0=None, dZ=False,
                   dZ_power=0.5):
-        """Hierarchical ridge fit of a single distribution (arguments as in the reference, :142-290)."""
+        """Hierarchical ridge fit of a single distribution (arguments as in the reference, :142-290).
+
+        Where it runs: the Gram matrices (bdrt_gram) and every QP on the GPU; the standard fits -- ordinary ridge and the
+        analytic hyper-lambda iteration, any penalty -- entirely on the GPU in one launch (bdrt_ridge); the rarely used
+        variants that need scipy's scalar optimisers between two QPs (dZ weighting, hyper_a / hyper_b, hl_solution='lm',
+        correct_phase_offset, hyper_weights) iterate on the host around the GPU QP."""
         if preset is not None:
             if preset not in ('Ciucci', 'Huang'):
                 raise ValueError('Invalid preset {}. Options are {}'.format(preset, ['Ciucci', 'Huang']))
@@ -242,35 +268,53 @@ class Inverter:
                 penalty, lambda_0, hl_fbeta = 'discrete', 'cv', 0.1
             else:
                 penalty, hl_beta, lambda_0, weights = 'integral', 2.5, 1e-2, 'modulus'
-        if penalty == 'discrete':
+        if penalty in ('discrete', 'cholesky'):
             if np.min(hl_beta) <= 1:
                 raise ValueError('hl_beta must be greater than 1 for penalty cholesky and discrete')
         elif penalty == 'integral':
             if np.min(hl_beta) <= 2:
                 raise ValueError('hl_beta must be greater than 2 for penalty integral')
-        elif penalty == 'cholesky':
-            raise NotImplementedError("penalty='cholesky' is not implemented (the reference does not recommend it)")
         else:
             raise ValueError(f'Invalid penalty argument {penalty}. Options are integral, discrete, and cholesky')
         if hyper_lambda and hyper_weights:
             raise ValueError('hyper_lambda and hyper_weights fits cannot be performed simultaneously')
         if len(self.distributions) > 1:
             raise ValueError('ridge_fit cannot be used to fit multiple distributions')
-        if correct_phase_offset or hyper_a or hyper_b or hl_solution != 'analytic':
-            raise NotImplementedError('correct_phase_offset / hyper_a / hyper_b / hl_solution="lm" are outside the '
-                                      'hot-path scope of this build')
+        if correct_phase_offset and IERange is None:
+            raise ValueError('IERange must be provided if correct_phase_offset==True')
+        if hl_solution not in ('analytic', 'lm'):
+            raise ValueError("hl_solution must be 'analytic' or 'lm'")
+        if part not in ('both', 'real', 'imag'):
+            raise ValueError(f"Invalid part {part}. Options are 'both', 'real', or 'imag'")
         self.distribution_fits = {}
+        Z = np.asarray(Z)
+        phase = None
+        if correct_phase_offset:
+            phase = _PhaseOffsets(np.asarray(frequencies), Z, IERange, lambda_phz, init_phase_offset)
+            Z = phase.Z_adj.copy()
         if isinstance(lambda_0, str) and lambda_0 == 'cv':
             lambda_0 = self.ridge_ReImCV(frequencies, Z, lambdas=cv_lambdas, penalty=penalty, hyper_lambda=hyper_lambda,
                                          hl_solution=hl_solution, hl_beta=hl_beta, hl_fbeta=hl_fbeta, reg_ord=reg_ord,
                                          L1_penalty=L1_penalty, x0=x0, weights=weights, xtol=xtol, max_iter=max_iter,
                                          scale_Z=scale_Z, nonneg=nonneg, dZ=dZ, dZ_power=dZ_power)
+        st = self._ridge_setup(frequencies, Z, part, penalty, reg_ord, L1_penalty, scale_Z, nonneg, weights, dZ)
+        device_loop = (not hyper_weights and not st['dZ'] and not hyper_a and not hyper_b and not correct_phase_offset
+                       and hl_solution == 'analytic' and not os.environ.get('BDRT_HOST_LAMBDA_LOOP'))
+        if device_loop:
+            res = self._ridge_solve_device([st], [0], [lambda_0], hyper_lambda, hl_beta, hl_fbeta, x0, xtol, max_iter)[0]
+        else:
+            res = self._ridge_solve_host(st, lambda_0, hyper_lambda, hl_solution, hl_beta, hl_fbeta, hyper_weights, hw_beta,
+                                         hw_wbar, xtol, max_iter, hyper_a, alpha_a, hl_beta_a, hyper_b, sb, phase, x0, dZ_power)
+        self._ridge_finish(st, res, hyper_lambda, hyper_weights, max_iter)
+
+    # ------------------------------------------------------------------ ridge: set-up shared by all solution paths
+    def _ridge_setup(self, frequencies, Z, part, penalty, reg_ord, L1_penalty, scale_Z, nonneg, weights, dZ):
+        """Matrices of one ridge problem (reference :370-470): augmented A, penalty bases, Gram matrix and q on the GPU."""
         name = list(self.distributions.keys())[0]
         info = self.distributions[name]
         if info['kernel'] != 'DRT' and dZ:
             warnings.warn('dZ should only be set to True for DRT recovery. Proceeding with dZ=False')
             dZ = False
-        Z = np.asarray(Z)
         series = info['dist_type'] == 'series'
         target = Z if series else 1 / Z
         frequencies, target_s, WT_re, WT_im, W_re, W_im, dist_mat = self._prep_matrices(frequencies, target, part, weights,
@@ -282,7 +326,6 @@ class Inverter:
             WT_re, WT_im = W_re @ target_s.real, W_im @ target_s.imag
         mats = dist_mat[name]
         A_re, A_im, B = mats['A_re'], mats['A_im'], mats['B']
-        tau, epsilon = info['tau'], info['epsilon']
         K = A_re.shape[1]
         off = 2 if series else 0                    # augmented unknowns [R_inf, L/1e-4, x] for series (:402-417)
         n = K + off
@@ -298,57 +341,117 @@ class Inverter:
         def pad(Mx):
             out = np.zeros((n, n)); out[off:, off:] = Mx
             return out
-        if penalty == 'integral':
+        Ls = None
+        if penalty in ('integral', 'cholesky'):
             base = [pad(mats['M%d' % o]) for o in (0, 1, 2)]
-            Ls = None
-        else:
+        if penalty in ('discrete', 'cholesky'):
             Ls = [np.hstack((np.zeros((K, off)), mats['L%d' % o])) for o in (0, 1, 2)]
+        if penalty == 'discrete':
             base = [L.T @ L for L in Ls]
         if isinstance(reg_ord, (int, np.integer)):
             ro = np.zeros(3); ro[int(reg_ord)] = 1
             reg_ord = ro
         reg_ord = np.asarray(reg_ord, dtype=float)
-        L1_vec = np.ones(n) * np.pi ** 0.5 / epsilon * L1_penalty
+        L1_vec = np.ones(n) * np.pi ** 0.5 / info['epsilon'] * L1_penalty
         if series:
             L1_vec[0:2] = 0
-        hl_beta = np.array([hl_beta] * 3, dtype=float) if np.ndim(hl_beta) == 0 else np.asarray(hl_beta, dtype=float)
-        a_list = hl_beta / 2
-        if penalty == 'integral':
-            b_list = 0.5 * (2 * a_list - 2) / lambda_0
-            lam0s = [(2 * a - 2) / (2 * b) * np.ones(n) for a, b in zip(a_list, b_list)]
-        else:
-            b_list = 0.5 * (2 * a_list - 1) / lambda_0
-            lam0s = [(2 * a - 1) / (2 * b) * np.ones(n) for a, b in zip(a_list, b_list)]
-        betas = [2 * a * np.ones(n) for a in a_list]
-
         lo = np.zeros(n) if nonneg else np.concatenate([np.zeros(min(2, n)), -10 * np.ones(n - min(2, n))])
-        use_re, use_im = part in ('both', 'real'), part in ('both', 'imag')
-        if part not in ('both', 'real', 'imag'):
-            raise ValueError(f"Invalid part {part}. Options are 'both', 'real', or 'imag'")
+        st = dict(name=name, info=info, series=series, part=part, penalty=penalty, reg_ord=reg_ord, L1_vec=L1_vec, lo=lo,
+                  frequencies=frequencies, target_s=target_s, W_re=W_re, W_im=W_im, A_re=A_re, A_im=A_im, B=B, K=K, off=off,
+                  n=n, base=base, Ls=Ls, scale_Z=scale_Z, dZ=dZ, tau=info['tau'],
+                  # the reference zeroes the relative change of entry 1 (the inductance) in its convergence test whenever
+                  # the inductance is not fitted -- for any distribution type (:733-734)
+                  zero_delta1=bool(self.fit_inductance == False or part == 'real'))
+        st['G'], st['g'] = self._ridge_gram(st, W_re, W_im, WT_re, WT_im)
+        return st
 
-        def gram(W_re_, W_im_, T_re_, T_im_):
-            """G = sum over the fitted parts of (W A)^T (W A), g = sum of (W A)^T (W T): on the GPU (bdrt_gram)."""
-            rows, tg = [], []
-            if use_re:
-                rows.append(W_re_ @ A_re); tg.append(T_re_)
-            if use_im:
-                rows.append(W_im_ @ A_im); tg.append(T_im_)
-            WA = np.ascontiguousarray(np.vstack(rows)); WT = np.ascontiguousarray(np.concatenate(tg))
-            lib = _lib.require_gpu()
-            G = np.empty((n, n)); g = np.empty(n)
-            _lib.check(lib.bdrt_gram(ptr(WA), ptr(WT), WA.shape[0], n, None, None, ptr(G), ptr(g)), 'bdrt_gram')
-            return G, -g                                   # bdrt_gram returns q = -(WA^T WT)
+    @staticmethod
+    def _ridge_gram(st, W_re, W_im, T_re, T_im):
+        """G = sum over the fitted parts of (W A)^T (W A), g = sum of (W A)^T (W T): on the GPU (bdrt_gram)."""
+        rows, tg = [], []
+        if st['part'] in ('both', 'real'):
+            rows.append(W_re @ st['A_re']); tg.append(T_re)
+        if st['part'] in ('both', 'imag'):
+            rows.append(W_im @ st['A_im']); tg.append(T_im)
+        WA = np.ascontiguousarray(np.vstack(rows)); WT = np.ascontiguousarray(np.concatenate(tg))
+        lib = _lib.require_gpu()
+        n = st['n']
+        G = np.empty((n, n)); g = np.empty(n)
+        _lib.check(lib.bdrt_gram(ptr(WA), ptr(WT), WA.shape[0], n, None, None, ptr(G), ptr(g)), 'bdrt_gram')
+        return G, -g                                   # bdrt_gram returns q = -(WA^T WT)
 
-        def solve(G, g, L2_mat):
+    @staticmethod
+    def _hyper_prior_terms(penalty, hl_beta, lambda_0):
+        """a, b of the gamma hyper-prior per derivative order and the implied lambda_0 / beta (reference :608-628)."""
+        hl_beta = np.array([hl_beta] * 3, dtype=float) if np.ndim(hl_beta) == 0 else np.asarray(hl_beta, dtype=float)
+        a = hl_beta / 2
+        if penalty == 'integral':
+            b = 0.5 * (2 * a - 2) / lambda_0
+            lam0 = (2 * a - 2) / (2 * b)
+        else:
+            b = 0.5 * (2 * a - 1) / lambda_0
+            lam0 = (2 * a - 1) / (2 * b)
+        return a, b, lam0, 2 * a
+
+    # ------------------------------------------------------------------ ridge: the whole fit on the GPU (bdrt_ridge)
+    def _ridge_solve_device(self, setups, sel, lambdas, hyper_lambda, hl_beta, hl_fbeta, x0, xtol, max_iter):
+        """A batch of ridge fits in ONE launch: fit j uses the data part setups[sel[j]] and lambda_0 = lambdas[j]."""
+        lib = _lib.require_gpu()
+        st0 = setups[0]
+        n, K, off, nb, ng = st0['n'], st0['K'], st0['off'], len(sel), len(setups)
+        o = _lib.RidgeOptions()
+        o.n, o.K, o.off = n, K, off
+        o.penalty = 1 if st0['penalty'] == 'integral' else 0
+        o.max_iter, o.hyper_lambda, o.zero_delta1 = int(max_iter), int(bool(hyper_lambda)), int(st0['zero_delta1'])
+        o.xtol = float(xtol)
+        o.hl_fbeta = float(hl_fbeta) if (hl_fbeta is not None and st0['penalty'] != 'integral') else 0.0
+        for i in range(3):
+            o.reg_ord[i] = float(st0['reg_ord'][i])
+        G = np.ascontiguousarray(np.stack([s['G'] for s in setups]))
+        qbase = np.ascontiguousarray(np.stack([-s['g'] + s['L1_vec'] for s in setups]))
+        base = np.ascontiguousarray(np.stack(st0['base']))
+        Ls = np.ascontiguousarray(np.stack(st0['Ls'])) if st0['Ls'] is not None else None
+        lam = np.ascontiguousarray(np.asarray(lambdas, dtype=np.float64))
+        terms = [self._hyper_prior_terms(st0['penalty'], hl_beta, l) for l in lam]
+        lam0s = np.ascontiguousarray(np.stack([t[2] for t in terms]))
+        betas = np.ascontiguousarray(np.stack([t[3] for t in terms]))
+        gsel = np.ascontiguousarray(np.asarray(sel, dtype=np.int32))
+        x0a = None
+        if x0 is not None:
+            x0a = np.ascontiguousarray(np.broadcast_to(np.asarray(x0, dtype=np.float64), (nb, n)))
+        coef = np.empty((nb, n)); lamv = np.empty((nb, 3, n)); cost = np.empty(nb); fun = np.empty(nb)
+        iters = np.zeros(nb, dtype=np.int32); flags = np.zeros(nb, dtype=np.int32)
+        mi = int(max_iter)
+        hc = np.zeros((nb, mi, n)); hl = np.zeros((nb, mi, 3, n)); hf = np.zeros((nb, mi)); hk = np.zeros((nb, mi))
+        rc = lib.bdrt_ridge(C.byref(o), nb, ng, ptr(G), ptr(qbase), ptr(gsel), ptr(base), ptr(Ls), ptr(f64(st0['lo'])), ptr(lam),
+                            ptr(lam0s), ptr(betas), ptr(x0a), ptr(coef), ptr(lamv), ptr(cost), ptr(fun), ptr(iters), ptr(flags),
+                            ptr(hc), ptr(hl), ptr(hf), ptr(hk))
+        _lib.check(rc, 'bdrt_ridge')
+        out = []
+        for j in range(nb):
+            if flags[j] & 4:
+                warnings.warn('bdrt_ridge: a QP reached its iteration limit; the last iterate is used')
+            hist = [{'lambda_vectors': [hl[j, t, i].copy() for i in range(3)], 'coef': hc[j, t].copy(), 'fun': hf[j, t],
+                     'cost': hk[j, t], 'result': _QPResult({'x': hc[j, t].copy(), 'primal objective': hf[j, t]}),
+                     'dZ_re': np.ones(n)} for t in range(int(iters[j]))]
+            out.append(dict(coef=coef[j].copy(), lambda_vectors=[lamv[j, i].copy() for i in range(3)], cost=cost[j],
+                            result=_QPResult({'x': coef[j].copy(), 'primal objective': float(fun[j])}), history=hist,
+                            converged=bool(flags[j] & 1), iterations=int(iters[j])))
+        return out
+
+    # ------------------------------------------------------------------ ridge: host iteration around the GPU QP (variants)
+    def _ridge_solve_host(self, st, lambda_0, hyper_lambda, hl_solution, hl_beta, hl_fbeta, hyper_weights, hw_beta, hw_wbar,
+                          xtol, max_iter, hyper_a, alpha_a, hl_beta_a, hyper_b, sb, phase, x0, dZ_power):
+        n, off, K, series, penalty = st['n'], st['off'], st['K'], st['series'], st['penalty']
+        base, Ls, reg_ord, lo, L1_vec = st['base'], st['Ls'], st['reg_ord'], st['lo'], st['L1_vec']
+        A_re, A_im, B, tau = st['A_re'], st['A_im'], st['B'], st['tau']
+        G, g = st['G'], st['g']
+
+        def solve(G_, g_, L2_mat):
             """cvxopt.solvers.qp(P, q, -I, -lo) of the reference (:1043-1067): interior point on the GPU (bdrt_qp.hip)."""
-            P = np.ascontiguousarray(G + L2_mat); q = np.ascontiguousarray(-g + L1_vec)
-            batcher = getattr(self, '_qp_batcher', None)
-            if batcher is not None:                        # Re-Im cross-validation: all fits solve in one launch
-                x, obj = batcher.solve(P, q, lo)
-            else:
-                x, obj = _qp_batch(P[None], q[None], lo)
-                x, obj = x[0], obj[0]
-            return _QPResult({'x': x, 'primal objective': float(obj)}), P, q
+            P = np.ascontiguousarray(G_ + L2_mat); q = np.ascontiguousarray(-g_ + L1_vec)
+            x, obj = _qp_batch(P[None], q[None], lo)
+            return _QPResult({'x': x[0], 'primal objective': float(obj[0])}), P, q
 
         def penalty_matrix(lams, dz):
             D = 1.0 / dz
@@ -359,25 +462,72 @@ class Inverter:
                     out += frac * (sc[:, None] * Mb * sc[None, :])
             return out
 
+        def converged(coef, prev):
+            with np.errstate(divide='ignore', invalid='ignore'):
+                delta = (coef - prev) / prev
+            if st['zero_delta1']:
+                delta[1] = 0
+            return np.mean(np.abs(delta)) < xtol
+
         dZ_re = np.ones(n)
         lam_vectors = [np.ones(n) * lambda_0 for _ in range(3)]
-        if hyper_lambda or hyper_weights:
-            self._iter_history = []
+        history = []
         if hyper_lambda:
-            G, g = gram(W_re, W_im, WT_re, WT_im)
-            coef = np.asarray(x0, dtype=float) if x0 is not None else np.zeros(n) + 1e-6
-            it = 0
+            a_list, b_list, lam0_list, beta_list = self._hyper_prior_terms(penalty, hl_beta, lambda_0)
+            hyper_as = [np.ones(n) * a for a in a_list]
+            hyper_bs = [np.ones(n) * b for b in b_list]
+            lam0s = [np.ones(n) * l for l in lam0_list]
+            betas = [np.ones(n) * bt for bt in beta_list]
+            alpha_a = [alpha_a] * 3 if np.ndim(alpha_a) == 0 else list(alpha_a)
+            hl_beta_a = [hl_beta_a] * 3 if np.ndim(hl_beta_a) == 0 else list(hl_beta_a)
+            sb = [sb] * 3 if np.ndim(sb) == 0 else list(sb)
+            hlb = np.array([hl_beta] * 3, dtype=float) if np.ndim(hl_beta) == 0 else np.asarray(hl_beta, dtype=float)
+            coef = np.asarray(x0, dtype=float).copy() if x0 is not None else np.zeros(n) + 1e-6
+            result, cost, ok, it = None, 0.0, False, 0
             while it < max_iter:
                 prev = coef.copy()
-                if dZ and it > 0:
+                prev_lam = [l.copy() for l in lam_vectors]
+                if st['dZ'] and it > 0:
                     dZ_raw = B @ prev / (np.mean(np.diff(np.log(tau))) / 0.23026)
                     dZ_re[off:] = np.abs(dZ_raw) ** dZ_power
                     dZ_re[np.abs(dZ_re < 1e-8)] = 1e-8      # (sic) the reference's mask, :527
+                if hyper_b and it > 0:                      # _hyper_b (:985-990): b ~ normal(0, sb)
+                    for i in range(3):
+                        if reg_ord[i] > 0:
+                            sl_, a_, s_ = np.sum(lam_vectors[i]), hyper_as[i], sb[i]
+                            hb = 0.25 * (np.sqrt(16 * a_ * K * s_ ** 2 + 4 * s_ ** 4 * sl_ ** 2) - 2 * sl_ * s_ ** 2)
+                            hb[hb < 1e-8] = 1e-8
+                            hyper_bs[i] = hb
+                            lam0s[i] = (2 * hyper_as[i] - 2) / hyper_bs[i]
+                if hyper_a and it > 0:                      # _hyper_a (:992-1008): a - 1 ~ gamma(alpha_a, beta_a), scalar a
+                    from scipy.optimize import minimize_scalar
+                    from scipy.special import loggamma
+                    for i in range(3):
+                        if reg_ord[i] > 0:
+                            slog = np.sum(np.log(hyper_bs[i] * lam_vectors[i]))
+                            a_new = minimize_scalar(lambda a_: -2 * a_ * slog + 2 * loggamma(a_) + 2 * hl_beta_a[i] * (a_ - 1)
+                                                    - 2 * (alpha_a[i] - 1) * np.log(a_ - 1), method='bounded', bounds=(1, 5))['x']
+                            hyper_as[i] = np.ones(n) * a_new
+                            lam0s[i] = (2 * hyper_as[i] - 2) / hyper_bs[i]
+                            betas[i] = 2 * hyper_as[i]
+                if phase is not None and it > 0:
+                    Z_adj = phase.update(A_re @ prev + 1j * (A_im @ prev))
+                    target_adj = (Z_adj if series else 1 / Z_adj) * phase.scale_ratio(st, self)
+                    G, g = self._ridge_gram(st, st['W_re'], st['W_im'], st['W_re'] @ target_adj.real, st['W_im'] @ target_adj.imag)
                 xs = prev / dZ_re
                 for i in range(3):
                     if reg_ord[i] <= 0:
                         continue
-                    if penalty == 'discrete':
+                    if penalty in ('discrete', 'cholesky'):
+                        if hl_solution == 'lm':             # :650-668
+                            from scipy.optimize import least_squares
+                            zeta = (hlb[i] - 1) / lambda_0
+                            Lx2 = (Ls[i] @ prev) ** 2
+                            r = least_squares(lambda x_: (Lx2 + zeta) * x_ - (hlb[i] - 1) * np.log(x_), prev_lam[i][off:],
+                                              jac=lambda x_: np.diag(Lx2 + zeta - (hlb[i] - 1) / x_), method='lm',
+                                              xtol=lambda_0 * 1e-3, max_nfev=100)
+                            lam_vectors[i] = np.hstack((prev_lam[i][:off], r['x']))
+                            continue
                         Lx2 = (Ls[i] @ xs) ** 2
                         if hl_fbeta is not None:           # _hyper_lambda_fbeta (:956-964)
                             lam = lambda_0 / (Lx2 / (np.max(Lx2) * hl_fbeta) + 1)
@@ -397,30 +547,28 @@ class Inverter:
                         lam = (Cv ** 2 - np.sign(Cv) * Cv * np.sqrt(4 * d * (2 * a - 2) + Cv ** 2) + 2 * d * (2 * a - 2)) / (2 * d ** 2)
                         lam[lam <= 0] = 1e-15
                         lam_vectors[i] = lam
-                L2_mat = penalty_matrix(lam_vectors, dZ_re)
-                result, P, q = solve(G, g, L2_mat)
+                result, P, q = solve(G, g, penalty_matrix(lam_vectors, dZ_re))
                 coef = np.array(result['x'])
                 cost = 0.5 * coef @ P @ coef + q @ coef
-                self._iter_history.append({'lambda_vectors': [l.copy() for l in lam_vectors], 'coef': coef.copy(),
-                                           'fun': result['primal objective'], 'cost': cost, 'result': result,
-                                           'dZ_re': dZ_re.copy()})
-                with np.errstate(divide='ignore', invalid='ignore'):
-                    delta = (coef - prev) / prev
-                if series and (self.fit_inductance == False or part == 'real'):
-                    delta[1] = 0
-                if np.mean(np.abs(delta)) < xtol:
-                    break
-                elif it == max_iter - 1:
-                    warnings.warn(f'Hyperparametric solution did not converge within {max_iter} iterations')
+                history.append({'lambda_vectors': [l.copy() for l in lam_vectors], 'coef': coef.copy(),
+                                'fun': result['primal objective'], 'cost': cost, 'result': result, 'dZ_re': dZ_re.copy(),
+                                'hyper_bs': [h.copy() for h in hyper_bs], 'hyper_lambda0s': [h.copy() for h in lam0s],
+                                'hyper_hl_betas': [h.copy() for h in betas]})
+                if phase is not None:
+                    history[-1].update(phase.snapshot())
                 it += 1
-            self.distribution_fits[name] = {'opt_result': result, 'coef': coef.copy(),
-                                            'lambda_vectors': [l.copy() for l in lam_vectors], 'cost': cost}
-        elif hyper_weights:
+                if converged(coef, prev):
+                    ok = True
+                    break
+            return dict(coef=coef, lambda_vectors=[l.copy() for l in lam_vectors], cost=cost, result=result, history=history,
+                        converged=ok, iterations=it)
+        if hyper_weights:
             coef = np.zeros(n) + 1e-6
-            wbar = self._format_weights(frequencies, target_s, hw_wbar, part)
+            target_s = st['target_s']
+            wbar = self._format_weights(st['frequencies'], target_s, hw_wbar, st['part'])
             w = wbar
             L2_mat = penalty_matrix(lam_vectors, dZ_re)
-            it = 0
+            result, cost, ok, it = None, 0.0, False, 0
             while it < max_iter:
                 prev = coef.copy()
                 if it > 0:                                 # _hyper_weights (:1010-1041)
@@ -428,45 +576,52 @@ class Inverter:
                     res = target_s - (A_re @ coef + 1j * (A_im @ coef))
                     w = (np.real(wbar) - 1 / zr) / (res.real ** 2 / zr + 1) + 1j * (np.imag(wbar) - 1 / zi) / (res.imag ** 2 / zi + 1)
                 Wr, Wi = np.diag(np.real(w)), np.diag(np.imag(w))
-                G, g = gram(Wr, Wi, Wr @ target_s.real, Wi @ target_s.imag)
+                G, g = self._ridge_gram(st, Wr, Wi, Wr @ target_s.real, Wi @ target_s.imag)
                 result, P, q = solve(G, g, L2_mat)
                 coef = np.array(result['x'])
                 cost = 0.5 * coef @ P @ coef + q @ coef
-                self._iter_history.append({'weights': w.copy(), 'coef': coef.copy(), 'fun': result['primal objective'],
-                                           'cost': cost, 'result': result, 'dZ_re': dZ_re.copy()})
-                with np.errstate(divide='ignore', invalid='ignore'):
-                    delta = (coef - prev) / prev
-                if series and self.fit_inductance == False:
-                    delta[1] = 0
-                if np.mean(np.abs(delta)) < xtol:
-                    break
-                elif it == max_iter - 1:
-                    warnings.warn(f'Hyperparametric solution did not converge within {max_iter} iterations')
+                history.append({'weights': w.copy(), 'coef': coef.copy(), 'fun': result['primal objective'], 'cost': cost,
+                                'result': result, 'dZ_re': dZ_re.copy()})
                 it += 1
-            self.distribution_fits[name] = {'opt_result': result, 'coef': coef.copy(), 'weights': w.copy(), 'cost': cost}
-        else:
-            G, g = gram(W_re, W_im, WT_re, WT_im)
-            result, P, q = solve(G, g, penalty_matrix(lam_vectors, dZ_re))
-            coef = np.array(result['x'])
-            self.distribution_fits[name] = {'opt_result': result, 'coef': coef.copy(),
-                                            'cost': 0.5 * coef @ P @ coef + q @ coef}
-        fitc = self.distribution_fits[name]['coef']
+                if converged(coef, prev):
+                    ok = True
+                    break
+            return dict(coef=coef, weights=w.copy(), cost=cost, result=result, history=history, converged=ok, iterations=it)
+        result, P, q = solve(G, g, penalty_matrix(lam_vectors, dZ_re))
+        coef = np.array(result['x'])
+        return dict(coef=coef, cost=0.5 * coef @ P @ coef + q @ coef, result=result, history=None, converged=True, iterations=1)
+
+    # ------------------------------------------------------------------ ridge: results -> attributes (reference :741-898)
+    def _ridge_finish(self, st, res, hyper_lambda, hyper_weights, max_iter):
+        name, info, series, part = st['name'], st['info'], st['series'], st['part']
+        if hyper_lambda or hyper_weights:
+            self._iter_history = res['history']
+            if not res['converged'] and res['iterations'] >= max_iter:
+                warnings.warn(f'Hyperparametric solution did not converge within {max_iter} iterations')
+        fit = {'opt_result': res['result'], 'coef': res['coef'].copy(), 'cost': res['cost']}
+        if hyper_lambda:
+            fit['lambda_vectors'] = [l.copy() for l in res['lambda_vectors']]
+        if hyper_weights:
+            fit['weights'] = res['weights']
+        self.distribution_fits[name] = fit
+        fitc = fit['coef']
+        target_s, A_re, A_im, frequencies = st['target_s'], st['A_re'], st['A_im'], st['frequencies']
         # the unfitted part's offset is recovered by least squares on the other part (:841-863); both are 1-D linear
         if part == 'imag' and series:
             fitc[0] = np.mean(target_s.real - A_re[:, 2:] @ fitc[2:])
         elif part == 'real' and series and self.fit_inductance:
             col = frequencies * 2 * np.pi * 1e-4
             fitc[1] = col @ (target_s.imag - A_im[:, 2:] @ fitc[2:]) / (col @ col)
-        if scale_Z:
-            self.distribution_fits[name]['scaled_coef'] = fitc.copy()
-            self.distribution_fits[name]['coef'] = self._rescale_coef(fitc, info['dist_type'])
-        fitc = self.distribution_fits[name]['coef']
+        if st['scale_Z']:
+            fit['scaled_coef'] = fitc.copy()
+            fit['coef'] = self._rescale_coef(fitc, info['dist_type'])
+        fitc = fit['coef']
         if series:
             fitc[1] *= 1e-4
             if not self.fit_inductance:
                 fitc[1] = 0
             self.R_inf, self.inductance = fitc[0], fitc[1]
-            self.distribution_fits[name]['coef'] = fitc[2:]
+            fit['coef'] = fitc[2:]
         else:
             self.R_inf, self.inductance = 0, 0
         self.fit_type = 'ridge'
@@ -474,14 +629,17 @@ class Inverter:
     def ridge_ReImCV(self, frequencies, Z, lambdas=np.logspace(-10, 5, 31), **kw):
         """Re-Im cross-validation for lambda_0 (reference :902-945).
 
-        The reference runs the 2 x len(lambdas) hierarchical ridge fits one after the other; they are independent, so here
-        they advance in lock step and every hyper-lambda iteration solves all their QPs in ONE batched GPU launch
-        (bdrt_qp_box_batch, one workgroup per fit).  Each fit performs exactly the arithmetic of a stand-alone
-        `ridge_fit(part=..., lambda_0=...)`: same numbers as the sequential loop (`BDRT_SEQUENTIAL_CV=1` runs that loop)."""
+        The reference runs the 2 x len(lambdas) hierarchical ridge fits one after the other.  They are independent and share
+        their matrices, so here ALL of them are one launch of bdrt_ridge (one workgroup per fit, the hyper-lambda loop on the
+        device).  Each fit performs exactly the arithmetic of a stand-alone `ridge_fit(part=..., lambda_0=...)`: same numbers
+        as the sequential loop (`BDRT_SEQUENTIAL_CV=1` runs that loop).  Variants that iterate on the host (dZ, hl_solution='lm')
+        take the sequential loop."""
         frequencies, Z = np.asarray(frequencies), np.asarray(Z)
         lambdas = np.asarray(lambdas, dtype=float)
         recv, imcv = np.zeros_like(lambdas), np.zeros_like(lambdas)
-        if os.environ.get('BDRT_SEQUENTIAL_CV'):
+        kw = dict(kw)
+        host_variant = kw.get('dZ', False) or kw.get('hl_solution', 'analytic') != 'analytic'
+        if os.environ.get('BDRT_SEQUENTIAL_CV') or os.environ.get('BDRT_HOST_LAMBDA_LOOP') or host_variant:
             for i, lam in enumerate(lambdas):
                 self.ridge_fit(frequencies, Z, part='real', lambda_0=lam, **kw)
                 Zi = np.imag(self.predict_Z(frequencies))
@@ -489,40 +647,32 @@ class Inverter:
                 Zr = np.real(self.predict_Z(frequencies))
                 recv[i], imcv[i] = np.sum((Z.real - Zr) ** 2), np.sum((Z.imag - Zi) ** 2)
         else:
-            import threading
-            jobs = [(i, part, lam) for i, lam in enumerate(lambdas) for part in ('real', 'imag')]
-            batcher = _QPBatcher(len(jobs))
-            workers = [deepcopy(self) for _ in jobs]
-            preds, errors = [None] * len(jobs), []
-
-            def run(j):
-                i, part, lam = jobs[j]
-                w = workers[j]
-                w._qp_batcher = batcher
-                try:
-                    with warnings.catch_warnings():
-                        warnings.simplefilter('ignore')
-                        w.ridge_fit(frequencies, Z, part=part, lambda_0=lam, **kw)
-                    preds[j] = w.predict_Z(frequencies)
-                except BaseException as e:               # noqa: BLE001 -- re-raised in the caller's thread
-                    errors.append(e)
-                finally:
-                    w._qp_batcher = None
-                    batcher.leave()
-            threads = [threading.Thread(target=run, args=(j,)) for j in range(len(jobs))]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-            if errors:
-                raise errors[0]
-            for j, (i, part, lam) in enumerate(jobs):
-                if part == 'real':
-                    imcv[i] = np.sum((Z.imag - np.imag(preds[j])) ** 2)
-                else:
-                    recv[i] = np.sum((Z.real - np.real(preds[j])) ** 2)
-            last = workers[-1]                            # the reference leaves the last fit (imag part, last lambda) in place
-            self.__dict__.update({k: v for k, v in last.__dict__.items() if k != '_qp_batcher'})
+            defaults = dict(penalty='discrete', reg_ord=2, L1_penalty=0, scale_Z=True, nonneg=True, weights=None,
+                            hyper_lambda=True, hl_beta=2.5, hl_fbeta=None, xtol=1e-3, max_iter=20, x0=None, dZ=False)
+            unknown = set(kw) - set(defaults) - {'hl_solution', 'dZ_power'}
+            if unknown:
+                raise TypeError('ridge_ReImCV: unexpected arguments %s' % sorted(unknown))
+            o = dict(defaults, **{k: v for k, v in kw.items() if k in defaults})
+            self.distribution_fits = {}
+            setups = {}
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                for part in ('real', 'imag'):
+                    setups[part] = self._ridge_setup(frequencies, Z, part, o['penalty'], o['reg_ord'], o['L1_penalty'],
+                                                     o['scale_Z'], o['nonneg'], o['weights'], o['dZ'])
+                jobs = [(i, part) for i in range(len(lambdas)) for part in ('real', 'imag')]
+                res = self._ridge_solve_device([setups['real'], setups['imag']], [0 if p == 'real' else 1 for _, p in jobs],
+                                               [lambdas[i] for i, _ in jobs], o['hyper_lambda'], o['hl_beta'], o['hl_fbeta'],
+                                               o['x0'], o['xtol'], o['max_iter'])
+                for (i, part), r in zip(jobs, res):
+                    self.distribution_fits = {}
+                    self._ridge_finish(setups[part], r, o['hyper_lambda'], False, o['max_iter'])
+                    Zp = self.predict_Z(frequencies)
+                    if part == 'real':
+                        imcv[i] = np.sum((Z.imag - np.imag(Zp)) ** 2)
+                    else:
+                        recv[i] = np.sum((Z.real - np.real(Zp)) ** 2)
+            # the reference leaves the last fit (imaginary part, last lambda) in place: so does the loop above
         tot = recv + imcv
         best = lambdas[np.argmin(tot)]
         if best == np.min(lambdas) or best == np.max(lambdas):
@@ -810,8 +960,15 @@ class Inverter:
             elif penalty == 'discrete':
                 for o in (0, 1, 2):
                     dist_mat[name]['L%d' % o] = construct_L(fb, tau=tau, basis=self.basis, epsilon=epsilon, order=o)
+            elif penalty == 'cholesky':
+                # M = L^T L with L upper triangular, so that x^T M x = ||L x||^2 (reference :2309-2317)
+                from scipy.linalg import cholesky
+                for o in (0, 1, 2):
+                    M = construct_M(fb, basis=self.basis, order=o, epsilon=epsilon)
+                    dist_mat[name]['M%d' % o] = M
+                    dist_mat[name]['L%d' % o] = cholesky(M)
             else:
-                raise NotImplementedError("penalty='cholesky' is not implemented")
+                raise ValueError(f'Invalid penalty argument {penalty}. Options are integral, discrete, and cholesky')
             store.update(dist_mat[name])
             dist_mat[name].update({'A_re': A_re, 'A_im': A_im, 'WA_re': W_re @ A_re, 'WA_im': W_im @ A_im, 'B': B})
         self._recalc_mat = False

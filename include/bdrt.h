@@ -200,6 +200,42 @@ int bdrt_qp_box(const double *P, const double *q, const double *lo, int n, doubl
 int bdrt_qp_box_batch(const double *P, const double *q, const double *lo, int n, int nb, double *x,
                       double *primal_objective, int *iterations);
 
+/* The whole hierarchical ridge fit of Inverter.ridge_fit (reference inversion.py:518-740) for a batch of nb independent
+ * fits in ONE launch (one workgroup per fit): the hyper-lambda outer loop -- lambda update (:947-983), penalty matrix
+ * (:695-700), the QP of _convex_opt (:1043-1067), convergence test (:730-736) -- runs on the device.  ridge_ReImCV
+ * (:902-945) is one call with nb = 2 x len(lambdas).
+ *   unknowns: n (series: [R_inf, L/1e-4, x[K]], off = 2; parallel: x[K], off = 0)
+ *   G [ng][n][n], qbase [ng][n]: Gram matrices WA^T WA and q = -WA^T WZ + L1_vec of the ng distinct data parts
+ *     (Re-Im CV: real part, imaginary part); gsel[nb] picks one per fit
+ *   base [3][n][n]: padded M0, M1, M2 (penalty 1 = 'integral') or L_o^T L_o (penalty 0 = 'discrete');
+ *     Ls [3][K][n]: the padded L_o themselves (discrete only)
+ *   lambda0[nb]; lam0s[nb][3], betas[nb][3]: (2a-2)/(2b) resp. (2a-1)/(2b) and 2a of the reference's prior terms (:608-628)
+ *   per iteration, from the previous coefficients x:
+ *     discrete:  lambda_o = 1 / ((L_o x)^2 / (beta_o - 1) + 1 / lam0_o)            (:947-954), or with hl_fbeta > 0
+ *                lambda_o = lambda0 / ((L_o x)^2 / (max (L_o x)^2 * hl_fbeta) + 1)  (:956-964); 1 for the off leading unknowns
+ *     integral:  c = factor_o x (100, 10, 1), C_j = sum_{r != j} c_r sqrt(lambda_r) M_rj c_j, d = c^2 diag(M) + 2b,
+ *                lambda = (C^2 - sign(C) C sqrt(4 d (2a-2) + C^2) + 2 d (2a-2)) / (2 d^2), floored at 1e-15  (:973-983)
+ *     P = G + sum_o reg_ord[o] sqrt(lambda_o) base_o sqrt(lambda_o);  x = argmin 1/2 x'Px + q'x, x >= lo
+ *     stop when mean |(x - x_prev) / x_prev| < xtol (entry 1 excluded when zero_delta1)
+ *   hyper_lambda = 0: one QP with lambda = lambda0 (ordinary ridge).
+ * Outputs: coef [nb][n], lam [nb][3][n], cost = 1/2 x'Px + q'x, fun = the QP's primal objective, iters (outer iterations),
+ * flags (bit 0 converged, bit 2 a QP reached its iteration limit); optional per-iteration history (all four or none):
+ * hist_coef [nb][max_iter][n], hist_lam [nb][max_iter][3][n], hist_fun / hist_cost [nb][max_iter]. */
+typedef struct {
+    int n, K, off;
+    int penalty;            /* 0 discrete, 1 integral */
+    int max_iter;
+    int hyper_lambda;
+    int zero_delta1;
+    double xtol;
+    double hl_fbeta;        /* <= 0: analytic discrete update */
+    double reg_ord[3];
+} bdrt_ridge_options;
+int bdrt_ridge(const bdrt_ridge_options *opt, int nb, int ng, const double *G, const double *qbase, const int *gsel,
+               const double *base, const double *Ls, const double *lo, const double *lambda0, const double *lam0s,
+               const double *betas, const double *x0, double *coef, double *lam, double *cost, double *fun, int *iters,
+               int *flags, double *hist_coef, double *hist_lam, double *hist_fun, double *hist_cost);
+
 /* ---- (4) posterior post-processing on the device ------------------------------------
  * Replaces the numpy reductions applied to the HMC draws right after `sampling`:
  *   np.percentile(samples, q, axis=0)            reference bayes_drt/inversion.py:2560 (coef_percentile), :2702

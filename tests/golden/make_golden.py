@@ -353,7 +353,51 @@ def gen_host():
     save('host_scale_parallel', freq=fz, Z=Zz, **sc)
 
 
+def gen_ridge():
+    """Ridge artefacts of the reference: code_EchemActa/comparisons/hyper-ridge/results, produced by
+    `hyper-ridge run fits.ipynb` (cell 4) with the paper snapshot's ridge_fit and cvxopt: Re-Im cross-validation over
+    lambda_0 = logspace(-15, 0, 61) (ordinary ridge), then hyper-lambda fits (hl_fbeta) at the best lambda_0.
+    Stored per spectrum: the CV curves, the recovered gamma for three f_beta values, and -- from the pickled fit object --
+    the matrices of the fit and the complete iteration history: every QP the reference handed to cvxopt (via its
+    lambda vector) together with cvxopt's solution and primal objective.  These are known-answer vectors for the QP solver
+    that replaces cvxopt."""
+    import pandas as pd
+    sys.path.append(os.path.join(REF, 'code_EchemActa/bayes-drt_20201113'))
+    res = os.path.join(REF, 'code_EchemActa/comparisons/hyper-ridge/results')
+    for stem in ('2ZARC_uniform_0.25', '2ZARC_Orazem_0.25', '2ZARC_Macdonald_0.25'):
+        f, Z = read_Z(os.path.join(REF, 'data/simulated/Z_%s.csv' % stem))
+        out = {'freq': f, 'Z': Z, 'epsilon': np.array(2.0)}
+        for fb in ('0.1', '1', '10'):
+            g = pd.read_csv(os.path.join(res, 'Gout_%s_fbeta=%s.csv' % (stem, fb)))
+            out['tau_plot'] = g['tau'].values
+            out['gamma_fbeta_' + fb] = g['gamma'].values
+            with open(os.path.join(res, 'obj_%s_fbeta=%s.pkl' % (stem, fb)), 'rb') as fh:
+                o = pickle.load(fh)
+            d = o.__dict__
+            out['coef_fbeta_' + fb] = np.asarray(d['coef_'], dtype=float)
+            out['lam2_fbeta_' + fb] = np.asarray(d['lambda_vectors_'][2], dtype=float)
+            out['cost_fbeta_' + fb] = np.array(float(d['cost_']))
+            out['n_iter_fbeta_' + fb] = np.array(len(d['_iter_history']))
+            if fb == '1':
+                cv = d['cv_result']
+                for k in ('lambda', 'recv', 'imcv', 'totcv'):
+                    out['cv_' + k] = cv[k].values.astype(float)
+                out['A_re'], out['A_im'] = np.asarray(d['A_re']), np.asarray(d['A_im'])
+                out['L2'] = np.asarray(d['L2'])
+                out['f_train'] = np.asarray(d['f_train'])
+                out['tau'] = np.asarray(d['tau'])
+                hist = d['_iter_history']
+                pick = sorted(set(i for i in (0, 1, 2, 5, 10, 20, len(hist) - 1) if 0 <= i < len(hist)))
+                out['hist_iter'] = np.array(pick)
+                out['hist_lam2'] = np.stack([np.asarray(hist[i]['lambda_vectors'][2], dtype=float) for i in pick])
+                out['hist_coef'] = np.stack([np.asarray(hist[i]['coef'], dtype=float) for i in pick])
+                out['hist_fun'] = np.array([float(hist[i]['fun']) for i in pick])
+                out['hist_cost'] = np.array([float(hist[i]['cost']) for i in pick])
+                out['hist_status'] = np.array([str(hist[i]['result']['status']) for i in pick])
+        save('ridge_' + stem, **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['matrices', 'ddt', 'dat', 'kats', 'csv', 'predict', 'host']
+    which = sys.argv[1:] or ['matrices', 'ddt', 'dat', 'kats', 'csv', 'predict', 'host', 'ridge']
     for w in which:
         globals()['gen_' + w]()

@@ -140,56 +140,6 @@ def test_weights(inv_mod):
         inv._format_weights(f, Z, np.ones(3), 'both')
 
 
-def test_qp_batcher_delivers_a_failed_launch_to_every_waiter(monkeypatch):
-    """A batched QP launch that fails (non-PD KKT matrix at tiny lambda_0, ...) must reach every fit of the lock-step
-    cross-validation: no thread may stay blocked in the rendezvous."""
-    import threading
-    from bayes_drt_amd import inversion
-
-    def boom(P, q, lo):
-        raise inversion._lib.BdrtError('KKT matrix not positive definite')
-    monkeypatch.setattr(inversion, '_qp_batch', boom)
-    n = 5
-    b = inversion._QPBatcher(n)
-    seen = []
-
-    def run(k):
-        try:
-            b.solve(np.eye(3), np.ones(3), np.zeros(3))
-        except inversion._lib.BdrtError as e:
-            seen.append((k, str(e)))
-        finally:
-            b.leave()
-    ts = [threading.Thread(target=run, args=(k,), daemon=True) for k in range(n)]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join(timeout=10)
-    assert not any(t.is_alive() for t in ts)
-    assert len(seen) == n
-
-
-def test_qp_batcher_flush_on_leave(monkeypatch):
-    """A fit that converges (leaves) while the others wait triggers the launch for the rest."""
-    import threading, time
-    from bayes_drt_amd import inversion
-    monkeypatch.setattr(inversion, '_qp_batch', lambda P, q, lo: (np.zeros(q.shape) + 7.0, np.arange(len(q), dtype=float)))
-    b = inversion._QPBatcher(3)
-    out = {}
-
-    def waiter(k):
-        out[k] = b.solve(np.eye(2), np.ones(2), np.zeros(2))
-        b.leave()
-    ts = [threading.Thread(target=waiter, args=(k,), daemon=True) for k in range(2)]
-    for t in ts:
-        t.start()
-    time.sleep(0.2)
-    b.leave()                                   # the third fit finished without another QP
-    for t in ts:
-        t.join(timeout=10)
-    assert not any(t.is_alive() for t in ts) and len(out) == 2 and all(np.all(v[0] == 7.0) for v in out.values())
-
-
 def test_format_weights_matches_reference(inv_mod):
     """Every named scheme / scalar form x part against the reference's own _format_weights (golden host_weights.npz);
     array weights (which the reference itself cannot take under numpy >= 1.25) by their documented meaning."""
