@@ -111,7 +111,7 @@ def test_ridge_fit_and_cv():
     g = inv.predict_distribution(eval_tau=TAU_PLOT)
     assert rel_l2(g, true) < 0.35
     assert np.sqrt(np.mean(np.abs(inv.predict_Z(f) - Z) ** 2)) < 0.02
-    assert np.all(inv.distribution_fits['DRT']['coef'] > 0)          # interior-point solution: strictly positive
+    assert np.all(inv.distribution_fits['DRT']['coef'] > -1e-6)      # cvxopt-style interior point: x >= 0 to its feasibility tolerance
     inv.ridge_fit(f, Z, preset='Huang')
     gh = inv.predict_distribution(eval_tau=TAU_PLOT)
     assert rel_l2(gh, true) < 0.35
