@@ -691,9 +691,8 @@ class Inverter:
         if fitY or SA or SASY:
             raise NotImplementedError('fitY / SA / SASY are experimental flags of the reference ("for testing only") and '
                                       'are not part of this build')
-        if part != 'both':
-            raise NotImplementedError("fit() supports part='both' (the reference's Stan data for other parts is "
-                                      "inconsistent with its model files)")
+        if part not in ('both', 'real', 'imag'):
+            raise ValueError(f"Invalid part {part}. Options are 'both', 'real', or 'imag'")
         if mode not in ('optimize', 'sample'):
             raise ValueError("mode must be 'optimize' or 'sample'")
         if init_from_ridge:
@@ -824,10 +823,19 @@ class Inverter:
                 return m['L0'], m['L1'], 0.75 * m['L2']
             return (1.5 * (0.36 if kind == 'parallel_multi' else 0.24)) * m['L0'], 1.5 * 0.16 * m['L1'], 1.5 * 0.08 * m['L2']
 
+        # part = 'real' / 'imag' (reference :1892-1905, :1973-...): the multi-distribution models keep N = 2 Nf and zero the
+        # rows of the part that is not fitted, in A and in Z alike
+        keep_re, keep_im = float(part != 'imag'), float(part != 'real')
+
         def stack(m):
-            return np.concatenate((m['A_re'], m['A_im']))
-        Z_stack = np.concatenate((Z.real, Z.imag))
+            return np.concatenate((keep_re * m['A_re'], keep_im * m['A_im']))
+        Z_stack = np.concatenate((keep_re * Z.real, keep_im * Z.imag))
         nf = len(frequencies)
+        if part != 'both' and model_type in ['Series', 'Parallel']:
+            # the reference hands Stan an Nf-row A and Z together with N = 2 Nf here (:1718-1723, :1739): pystan rejects that
+            # data ("mismatch in dimension declared and found in context"), so there is no behaviour to reproduce
+            raise ValueError("fit(part='%s') is only defined for multi-distribution models: for a single distribution the "
+                             "reference's Stan data is dimensionally inconsistent and pystan rejects it" % part)
         common = {'N': 2 * nf, 'freq': frequencies, 'Z': Z_stack, 'N_tilde': 2 * nf, 'freq_tilde': frequencies,
                   'sigma_min': sigma_min, 'ups_alpha': ups_alpha, 'ups_beta': ups_beta, 'induc_scale': inductance_scale}
         if model_type in ['Series', 'Parallel']:

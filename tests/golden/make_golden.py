@@ -351,6 +351,22 @@ def gen_host():
         Zr = iv._scale_Z(Zz, 'ridge')
         sc['scale_ridge_' + bc] = np.array(iv._Z_scale)
     save('host_scale_parallel', freq=fz, Z=Zz, **sc)
+    # fit(part='real' / 'imag') for a two-distribution model: the Stan data keeps N = 2 Nf with the other part zeroed
+    # (inversion.py:1892-1905).  Small basis (K = 20, off the frequency grid) to keep the fixture small.
+    f2, Z2 = read_Z(os.path.join(REF, 'data/simulated/Z_DRT-2-TpDDT_uniform_0.25.csv'))
+    bf = np.logspace(6.3, -2.3, 20)
+    dists = {'DRT': {'kernel': 'DRT'},
+             'TP-DDT': {'kernel': 'DDT', 'symmetry': 'planar', 'bc': 'transmissive', 'dist_type': 'parallel', 'x_scale': 0.8}}
+    out = {'freq': f2, 'Z': Z2, 'basis_freq': bf}
+    for part in ('real', 'imag'):
+        iv = Inverter(basis_freq=bf, distributions=dists)
+        fs, Zs, _, _, _, _, dm = iv._prep_matrices(f2, Z2, part, weights=None, dZ=False, scale_Z=True, penalty='discrete',
+                                                   fit_type='map')
+        dat = iv._prep_stan_data(fs, Zs, part, 'Series-Parallel', dm, False, 0.002, mode='optimize', inductance_scale=1,
+                                 outlier_lambda=None, fitY=False, SA=False, SASY=False)
+        for k in ('N', 'Z', 'As', 'Ap'):
+            out['%s_%s' % (part, k)] = np.asarray(dat[k])
+    save('host_dat_parts', **out)
 
 
 def gen_ridge():

@@ -199,3 +199,30 @@ def test_scale_Z_admittance_branch_matches_reference(inv_mod):
         assert np.allclose(Zs, g['Zs_' + bc], rtol=1e-14, atol=0)
         iv._scale_Z(g['Z'], 'ridge')
         assert abs(iv._Z_scale - float(g['scale_ridge_' + bc])) <= 1e-14 * abs(float(g['scale_ridge_' + bc]))
+
+
+def test_stan_data_for_single_part_fits_matches_reference(inv_mod):
+    """fit(part='real' / 'imag'): the two-distribution models keep N = 2 Nf and zero the rows of the part that is not
+    fitted (reference inversion.py:1892-1905; golden host_dat_parts.npz); for a single distribution the reference's data is
+    dimensionally inconsistent (pystan would reject it), which is an error here too."""
+    g = load('host_dat_parts')
+    dists = {'DRT': {'kernel': 'DRT'},
+             'TP-DDT': {'kernel': 'DDT', 'symmetry': 'planar', 'bc': 'transmissive', 'dist_type': 'parallel', 'x_scale': 0.8}}
+    for part in ('real', 'imag'):
+        inv = inv_mod.Inverter(basis_freq=g['basis_freq'], distributions=dists)
+        fs, Zs, _, _, _, _, dm = inv._prep_matrices(g['freq'], g['Z'], part, weights=None, dZ=False, scale_Z=True,
+                                                    penalty='discrete', fit_type='map')
+        dat = inv._prep_stan_data(fs, Zs, part, 'Series-Parallel', dm, False, 0.002, mode='optimize', inductance_scale=1,
+                                  outlier_lambda=None, fitY=False, SA=False, SASY=False)
+        assert int(dat['N']) == int(g[part + '_N'])
+        for k in ('Z', 'As', 'Ap'):
+            assert np.allclose(dat[k], g['%s_%s' % (part, k)], rtol=1e-10, atol=1e-13), (part, k)
+        half = len(fs)
+        zero = slice(half, None) if part == 'real' else slice(0, half)
+        assert not np.any(dat['Z'][zero]) and not np.any(dat['As'][zero]) and not np.any(dat['Ap'][zero])
+    inv = inv_mod.Inverter(basis_freq=g['basis_freq'])
+    fs, Zs, _, _, _, _, dm = inv._prep_matrices(g['freq'], g['Z'], 'real', weights=None, dZ=False, scale_Z=True,
+                                                penalty='discrete', fit_type='map')
+    with pytest.raises(ValueError):
+        inv._prep_stan_data(fs, Zs, 'real', 'Series', dm, False, 0.002, mode='optimize', inductance_scale=1,
+                            outlier_lambda=None, fitY=False, SA=False, SASY=False)
