@@ -85,6 +85,10 @@ int post_percentiles_device(const double *dX, int rows, int K, long ldx, const d
                             const double *q, int nq, double *out, const unsigned char *expcol = nullptr,
                             double *mean = nullptr);
 
+// Levenberg-Marquardt Newton polish of n_fits points on the device (bdrt_newton.hip); x0 / x_out [n_fits][D] on the host
+int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fits, int max_iter, double tol, double *x_out,
+                         double *lp_out, double *ginf_out, int *iters_out, int *rc_out, int *n_evals_out);
+
 }  // namespace bdrt
 
 struct bdrt_problem {

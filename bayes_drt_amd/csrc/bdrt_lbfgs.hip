@@ -5,9 +5,10 @@
 // Stan's five termination tests (tol_obj, tol_rel_obj, tol_grad, tol_rel_grad, tol_param).
 // Stan's exact iterate path is not reproducible (its source is not in the reference; H1), only its contract.
 //
-// MI355X design: the optimiser is a per-fit state machine on the host; every log_prob+gradient it asks for is
+// MI355X design: the L-BFGS phase is a per-fit state machine on the host; every log_prob+gradient it asks for is
 // evaluated on the GPU, and all fits (spectra / restarts) advance in lock-step so that one kernel launch serves
-// the whole batch (one 16-column MFMA tile per 16 fits).
+// the whole batch (one 16-column MFMA tile per 16 fits).  The second-order polish that follows runs on the device
+// (bdrt_newton.hip): Hessian probes, blocked MFMA Cholesky, damped step and acceptance test without leaving HBM.
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -24,10 +25,9 @@ namespace bdrt {
 
 struct FitDriver {
     LbfgsFit L;
-    NewtonFit N;
-    int stage = 0;     // 0 L-BFGS, 1 Newton, 2 done
-    int nreq() const { return stage == 0 ? 1 : (stage == 1 ? N.n_requests() : 0); }
-    const double *req(int i) const { return stage == 0 ? L.trial() : N.request(i); }
+    int stage = 0;     // 0 L-BFGS, 2 done (the Newton polish runs afterwards, on the device: bdrt_newton.hip)
+    int nreq() const { return stage == 0 ? 1 : 0; }
+    const double *req(int) const { return L.trial(); }
 };
 
 }  // namespace bdrt
@@ -59,11 +59,7 @@ int bdrt_optimize(bdrt_problem *p, const double *init_theta, const int *spec, in
         if (ol.max_iter <= 0) { fits[i].L.phase = LbfgsFit::DONE; }
     }
     auto advance_stage = [&](FitDriver &F) {
-        if (F.stage == 0 && F.L.phase == LbfgsFit::DONE) {
-            if (o.newton_max_iter > 0 && F.L.rc >= 0) { F.N.init(D, F.L.x.data(), o.newton_max_iter, o.newton_tol); F.stage = 1; }
-            else F.stage = 2;
-        }
-        if (F.stage == 1 && F.N.phase == NewtonFit::DONE) F.stage = 2;
+        if (F.stage == 0 && F.L.phase == LbfgsFit::DONE) F.stage = 2;
     };
     for (auto &F : fits) advance_stage(F);
 
@@ -108,26 +104,43 @@ int bdrt_optimize(bdrt_problem *p, const double *init_theta, const int *spec, in
             if (F.stage == 2) continue;
             const double *lps = &fit_lp[off[i]];
             const double *grs = &fit_grad[off[i] * D];
-            if (F.stage == 0) F.L.feed_any(lps[0], grs);
-            else F.N.consume(lps, grs);
+            F.L.feed_any(lps[0], grs);
             advance_stage(F);
         }
     }
+    // ---- second phase: Newton polish of every fit whose L-BFGS phase ended normally, all on the device ----
+    std::vector<int> nw_idx;
+    for (int i = 0; i < n_fits; ++i)
+        if (o.newton_max_iter > 0 && fits[i].L.rc >= 0) nw_idx.push_back(i);
+    const int nn = (int)nw_idx.size();
+    std::vector<double> nx((size_t)nn * D), nout((size_t)nn * D), nlp(nn), ngi(nn);
+    std::vector<int> nit(nn), nrc(nn), nev(nn), nspec(nn);
+    if (nn > 0) {
+        for (int a = 0; a < nn; ++a) {
+            memcpy(&nx[(size_t)a * D], fits[nw_idx[a]].L.x.data(), D * sizeof(double));
+            nspec[a] = spec ? spec[nw_idx[a]] : 0;
+        }
+        if ((rc = newton_polish_device(P, nx.data(), nspec.data(), nn, o.newton_max_iter, o.newton_tol, nout.data(), nlp.data(),
+                                       ngi.data(), nit.data(), nrc.data(), nev.data())))
+            return rc;
+    }
+    std::vector<int> slot((size_t)n_fits, -1);
+    for (int a = 0; a < nn; ++a) slot[nw_idx[a]] = a;
     for (int i = 0; i < n_fits; ++i) {
         FitDriver &F = fits[i];
-        const bool newton = o.newton_max_iter > 0 && F.N.D == D;
-        const std::vector<double> &x = newton ? F.N.x : F.L.x;
-        memcpy(theta_out + (size_t)i * D, x.data(), D * sizeof(double));
+        const int a = slot[i];
+        const double *x = a >= 0 ? &nout[(size_t)a * D] : F.L.x.data();
+        memcpy(theta_out + (size_t)i * D, x, D * sizeof(double));
         if (reports) {
             bdrt_opt_report &R = reports[i];
             R.iterations = F.L.iters;
-            R.n_evals = F.L.n_evals + (newton ? F.N.n_evals : 0);
-            R.newton_iterations = newton ? F.N.iters : 0;
-            if (newton) {
-                R.return_code = F.N.phase == NewtonFit::DONE ? F.N.rc : 1;
-                R.lp = F.N.lp;
-                R.grad_norm = std::sqrt(LbfgsFit::dot(F.N.g, F.N.g));
-                R.grad_inf = F.N.grad_inf();
+            R.n_evals = F.L.n_evals + (a >= 0 ? nev[a] : 0);
+            R.newton_iterations = a >= 0 ? nit[a] : 0;
+            if (a >= 0) {
+                R.return_code = nrc[a];
+                R.lp = nlp[a];
+                R.grad_inf = ngi[a];
+                R.grad_norm = ngi[a];                  // the polish tracks the max-norm only
             } else {
                 R.return_code = F.L.phase == LbfgsFit::DONE ? F.L.rc : 1;
                 R.lp = -F.L.f;

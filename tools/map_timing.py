@@ -1,0 +1,24 @@
+"""MAP timing on the GPU box: Inverter.fit(mode='optimize') on the reference's 2-ZARC spectrum at K = 81 / 101 / 161
+(L-BFGS 1000 iterations + device Newton polish), and the Stan-style iterate (algorithm='LBFGS', no polish) beside it, both
+against the reference's committed MAP curve (map_results/Gout_2ZARC_uniform_0.25.csv)."""
+import os, sys, time, warnings
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.helpers import load, rel_l2
+from bayes_drt_amd.inversion import Inverter
+
+c = load('csv_2ZARC_uniform_0.25')
+f, Z = c['Z'][:, 0], c['Z'][:, 1] + 1j * c['Z'][:, 2]
+tau_plot = np.logspace(-7, 2, 200)
+ref, true = c['Gout_map'][:, 1], c['gamma_true'][:, 1]
+for K, bf in ((81, f), (101, None), (161, np.logspace(10, -6, 161))):
+    inv = Inverter(basis_freq=bf)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        inv.fit(f, Z, nonneg=True, mode='optimize')                       # first-use costs out of the timing
+        t0 = time.time(); inv.fit(f, Z, nonneg=True, mode='optimize'); t1 = time.time()
+    r = inv._opt_report
+    g = inv.predict_distribution('DRT', eval_tau=tau_plot)
+    print('K=%d: fit(mode=optimize) %.3f s  (L-BFGS %d it + Newton %d it, %d evals), lp %.4f, |grad|_inf %.1e, rc %d; '
+          'gamma vs reference MAP rel-L2 %.4f, vs true %.4f' % (K, t1 - t0, r['iterations'], r['newton_iterations'], r['n_evals'],
+                                                                 r['lp'], r['grad_inf'], r['return_code'], rel_l2(g, ref), rel_l2(g, true)))
