@@ -157,7 +157,12 @@ struct NewtonFit {
         }
         bool fin = std::isfinite(lpn);
         for (int j = 0; j < D && fin; ++j) fin = std::isfinite(grads[j]);
-        if (fin && lpn - lp >= 1e-4 * pred && lpn >= lp - 1e-12 * std::fabs(lp)) {
+        // (close to the optimum the predicted increase drops below the resolution of lp: judge the step by the gradient then)
+        const double noise = 64.0 * 2.220446049250313e-16 * std::max(1.0, std::fabs(lp));
+        double ginf_t = 0.0;
+        for (int j = 0; j < D && fin; ++j) ginf_t = std::max(ginf_t, std::fabs(grads[j]));
+        const bool by_grad = fin && pred < noise && lpn >= lp - noise && ginf_t < grad_inf();
+        if (fin && ((lpn - lp >= 1e-4 * pred && lpn >= lp - 1e-12 * std::fabs(lp)) || by_grad)) {
             const double rho = pred > 0.0 ? (lpn - lp) / pred : 0.0;
             x = xt; lp = lpn;
             memcpy(g.data(), grads, sizeof(double) * D);
