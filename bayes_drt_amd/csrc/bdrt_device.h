@@ -24,7 +24,7 @@ constexpr int NW = NT / 64;   // waves per workgroup
 constexpr int NG = NT / NC;   // row groups in the element-wise phases
 constexpr int MAXB = 3;
 constexpr int NRED = 8;       // max quantities per block reduction
-constexpr int MAXBW = 8;      // half bandwidth handled by the structured (banded Toeplitz) L path
+constexpr int MAXBW = 6;      // half bandwidth of the structured (banded Toeplitz) L path: at the reference's default shape parameter (epsilon = 1 / mean spacing of ln tau) the diagonals beyond +-6 are below 1e-19 of the largest entry (e^-49); wider bands (smaller epsilon) take the dense MFMA path
 constexpr int MIN_LR = 192;    // the NUTS kernel borrows the Lr buffer (>= 8*22*16 doubles) for its reductions
 constexpr double LOG_015 = -1.8971199848858813;   // log(0.15): ups = 0.15*ups_raw
 

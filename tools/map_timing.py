@@ -22,3 +22,12 @@ for K, bf in ((81, f), (101, None), (161, np.logspace(10, -6, 161))):
     print('K=%d: fit(mode=optimize) %.3f s  (L-BFGS %d it + Newton %d it, %d evals), lp %.4f, |grad|_inf %.1e, rc %d; '
           'gamma vs reference MAP rel-L2 %.4f, vs true %.4f' % (K, t1 - t0, r['iterations'], r['newton_iterations'], r['n_evals'],
                                                                  r['lp'], r['grad_inf'], r['return_code'], rel_l2(g, ref), rel_l2(g, true)))
+    # the Stan-style iterate beside it: L-BFGS(5) with Stan's termination tests, iter = 50000, no second-order polish
+    from bayes_drt_amd.engine import StanModel
+    m = StanModel(inv.stan_model_name)
+    t0 = time.time(); res = m.optimizing(inv._stan_input, iter=50000, seed=1234, algorithm='LBFGS'); t1 = time.time()
+    tau = inv.distributions['DRT']['tau']; eps = inv.distributions['DRT']['epsilon']
+    gs = np.exp(-(eps * np.log(tau_plot[:, None] / tau[None, :])) ** 2) @ (res['x'] * inv._Z_scale)
+    r = m.last_report
+    print('      Stan-style L-BFGS only: %.3f s, %d iterations, lp %.4f, |grad|_inf %.1e; gamma vs reference MAP rel-L2 %.4f, '
+          'vs the polished MAP %.4f' % (t1 - t0, r['iterations'], r['lp'], r['grad_inf'], rel_l2(gs, ref), rel_l2(gs, g)))
