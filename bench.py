@@ -256,6 +256,28 @@ def main():
         print('half-waves per round in stage E (new start point): %.2f of 16' % (cyc[24] / n_wg / rounds_total * 2), file=sys.stderr)
     smp.close()
 
+    # ---- raw log-posterior+gradient kernel at B = 1 .. 4096 points, inputs resident in HBM; outside the timed region
+    sweep = None
+    if rank == 0 and args.gpus == 1:
+        sweep = []
+        ts = torch.cuda.Stream()
+        for B in (1, 4, 32, 512, 4096):
+            th = torch.empty(B, prob.D, dtype=torch.float64, device='cuda').uniform_(-2, 2)
+            gr = torch.empty_like(th); lpv = torch.empty(B, dtype=torch.float64, device='cuda')
+            sp = torch.randint(0, prob.n_spectra, (B,), dtype=torch.int32, device='cuda')
+            torch.cuda.synchronize()
+            with torch.cuda.stream(ts):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                for it in range(13):
+                    if it == 3:
+                        e0.record(ts)
+                    check(lib.bdrt_logp_grad_dev(prob.handle, th.data_ptr(), sp.data_ptr(), B, 1, lpv.data_ptr(), gr.data_ptr(),
+                                                 ts.cuda_stream), 'bdrt_logp_grad_dev')
+                e1.record(ts)
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 10 * 1e3
+            sweep.append({'B': B, 'us_per_launch': us, 'evals_per_s': B / us * 1e6})
+
     # ---- N > 1: one complete sample_sharded call (broadcast + short run + summary gather), timed apart from the rate ----
     roundtrip = None
     if use_dist:
@@ -282,11 +304,14 @@ def main():
         avg_ms = ms_total / launches
         evals_per_launch = (n1 - n0) / launches                       # this rank's launches
         achieved = evals_per_launch * FLOP_PER_EVAL / (avg_ms * 1e-3) / 1e12
+        # HBM bytes per launch of the sampler kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+        # collected separately, gfx950 correction applied: tools/profile_bench.sh), scaled to this run's launch length
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get('nuts_kernel_hbm_bytes_per_launch')
+                per_round = json.load(open(pmc)).get('hbm_bytes_per_round_corrected')
+                traffic = per_round * args.rounds if per_round else None
             except Exception:
                 traffic = None
         line = {
@@ -308,6 +333,8 @@ def main():
         }
         if roundtrip is not None:
             line['config']['dist_roundtrip'] = roundtrip
+        if sweep is not None:
+            line['config']['raw_logp_grad_kernel_sweep'] = sweep
         if cpu is not None:
             line['cpu_baseline'] = cpu
         print(json.dumps(line))

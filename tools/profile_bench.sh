@@ -6,7 +6,8 @@ TAG=${1:-r01}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="--steps 500 --warmup 300 --no-cpu-baseline $*"
+# the driver's own command line (bench.py --gpus 1 --steps 20 --warmup 5): 25 launches of 1000 leapfrog rounds
+ARGS="--gpus 1 --steps 20 --warmup 5 --no-cpu-baseline $*"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
 grep '"metric"' $OUT/trace.log > $OUT/bench_line.json
 DB=$(find $OUT/trace -name '*.db' | head -1)
@@ -16,6 +17,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   DB=$(find $OUT/pmc_$C -name '*.db' | head -1)
   if [ -n "$DB" ]; then python3 tools/rocpd_pmc.py "$DB" $C > $OUT/pmc_$C.txt 2>&1; fi
 done
+python3 tools/make_traffic_json.py $OUT > $OUT/pmc_traffic.json 2>/dev/null
 ls -la $OUT
 head -5 $OUT/kernel_stats.txt; for C in FETCH_SIZE WRITE_SIZE; do [ -f $OUT/pmc_$C.txt ] && head -8 $OUT/pmc_$C.txt; done
 find $OUT -name '*.db' -size +20M -delete
