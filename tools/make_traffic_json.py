@@ -12,7 +12,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         continue
     cur = sqlite3.connect(db[0]).cursor()
     rows = cur.execute("select value from counters_collection where kernel_name like '%nuts_kernel%' and counter_name = ? "
-                       "order by rowid", (c,)).fetchall()
+                       "order by start", (c,)).fetchall()
     v = [r[0] for r in rows][-20:]                  # the 20 timed launches (the first 5 are warm-up)
     vals[c] = sum(v) / max(len(v), 1)
 line = json.load(open(os.path.join(out, 'bench_line.json')))
