@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
+#include <cstdio>
 
 #include "bdrt_host.h"
 
@@ -24,7 +26,7 @@ constexpr int NW_NT = 512;
 
 struct NewtonState {            // one per fit, in device memory
     double lp, lam, pred, lp_trial, grad_inf;
-    int iters, rc, done, need_hess, n_evals, max_iter, pad0, pad1;
+    int iters, rc, done, need_hess, n_evals, max_iter, hbad, pad1;      // hbad: non-finite Hessian entry seen by the build kernel
     double tol;
 };
 
@@ -35,7 +37,16 @@ struct NewtonBufs {
     double *probes, *pgrad;     // [n_fits][2 D][D]
     double *plp;                // [n_fits][2 D]
     NewtonState *st;            // [n_fits]
+    long long *prof;            // BDRT_NEWTON_PROF=1: cycle counters of the solve kernel's phases (nullptr otherwise)
 };
+
+// phase counters: thread 0 of workgroup 0 adds the core-clock cycles since the previous mark to slot k
+struct NewtonProf {
+    long long *p, t;
+    __device__ NewtonProf(long long *p_) : p(blockIdx.x == 0 && threadIdx.x == 0 ? p_ : nullptr), t(0) { if (p) t = clock64(); }
+    __device__ void mark(int k) { if (p) { const long long n = clock64(); p[k] += n - t; t = n; } }
+};
+enum { NP_HESS = 0, NP_BUILD, NP_DIAG, NP_PANEL, NP_TRAIL, NP_SOLVE, NP_PRED, NP_WALL, NP_CALLS, NP_COUNT };
 
 __global__ void newton_probe_kernel(NewtonBufs b, const int *active, int n_active)
 {
@@ -49,9 +60,14 @@ __global__ void newton_probe_kernel(NewtonBufs b, const int *active, int n_activ
     for (int k = threadIdx.x; k < D; k += blockDim.x) p[k] = x[k] + (k == j ? ((row & 1) ? -h : h) : 0.0);
 }
 
+__device__ __forceinline__ double bcast_lane(double v, int l)        // value of lane l (l uniform), as a scalar operand
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 // In-place blocked Cholesky of the lower triangle of the Dp x Dp row-major matrix M (Dp a multiple of 16).
 // lds: 16*17 (diagonal block) + 16 (reciprocal pivots) + Dp*17 (panel) + 1 (flag) doubles.  Returns false when not positive definite.
-__device__ inline bool chol_blocked(double *M, int Dp, double *lds)
+__device__ inline bool chol_blocked(double *M, int Dp, double *lds, NewtonProf &pf)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *Dg = lds, *rinv = Dg + 16 * 17, *Pn = rinv + 16;
@@ -65,30 +81,28 @@ __device__ inline bool chol_blocked(double *M, int Dp, double *lds)
         if (tid < 256) Dg[(tid >> 4) * 17 + (tid & 15)] = M[(size_t)(j0 + (tid >> 4)) * Dp + j0 + (tid & 15)];
         __syncthreads();
         if (wave == 0) {
-            // lane i keeps row i of the block in registers; column j of the factor travels through LDS (one write, then
-            // independent reads): no read-modify-write chains through LDS
+            // lane i keeps row i of the block in registers.  Column j of the factor is read out of the lanes that own it
+            // (v_readlane -> SGPR operand of the multiply-add): no LDS round trips, no branches inside the 16 steps; a
+            // non-positive pivot poisons the block with NaNs and is reported after the last step.
             const int i = lane & 15;
             double row[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) row[k] = Dg[i * 17 + k];
-            double *colb = rinv;                                      // 16 doubles, rewritten with 1 / L[j][j] at the end
             bool okb = true;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(row[j]), j),
-                                                  __builtin_amdgcn_readlane(__double2loint(row[j]), j));
-                if (!(d > 0.0) || !isfinite(d)) { okb = false; break; }
-                const double dj = sqrt(d), inv = 1.0 / dj;
-                const double lij = i == j ? dj : row[j] * inv;
+                const double d = bcast_lane(row[j], j);
+                okb = okb && d > 0.0 && isfinite(d);
+                double rs = __builtin_amdgcn_rsq(d);                      // 1 / sqrt(d): hardware estimate + two Newton steps
+                rs = rs * (1.5 - 0.5 * d * rs * rs);
+                rs = rs * (1.5 - 0.5 * d * rs * rs);
+                const double lij = i == j ? d * rs : row[j] * rs;
                 row[j] = lij;
-                if (lane < 16) colb[i] = lij;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                 for (int k = j + 1; k < 16; ++k) {
-                    const double lkj = colb[k];
-                    if (i > j && k <= i) row[k] -= lij * lkj;
+                    const double lkj = bcast_lane(lij, k);                // L[k][j], owned by lane k
+                    row[k] -= (i > j && k <= i) ? lij * lkj : 0.0;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
             if (!okb) { if (lane == 0) *bad = 1; }
             else if (lane < 16) {
@@ -98,12 +112,24 @@ __device__ inline bool chol_blocked(double *M, int Dp, double *lds)
             }
         }
         __syncthreads();
+        pf.mark(NP_DIAG);
         if (*bad) return false;
         if (tid < 256 && (tid & 15) <= (tid >> 4)) M[(size_t)(j0 + (tid >> 4)) * Dp + j0 + (tid & 15)] = Dg[(tid >> 4) * 17 + (tid & 15)];
         // (b) panel below the block: x L11^T = a, one row per thread.  The m x 16 panel moves between global memory and
         // LDS with coalesced accesses (16 lanes per 128-byte row segment); the solve itself works on the LDS copy.
         const int m = Dp - j0 - 16;
-        for (int e = tid; e < m * 16; e += NW_NT) Pn[(size_t)(e >> 4) * 17 + (e & 15)] = M[(size_t)(j0 + 16 + (e >> 4)) * Dp + j0 + (e & 15)];
+        {
+            const double *src = M + (size_t)(j0 + 16 + (tid >> 4)) * Dp + j0 + (tid & 15);
+            double *dst = Pn + (tid >> 4) * 17 + (tid & 15);
+            const int nrow = NW_NT / 16;                                  // rows per pass
+            int r = tid >> 4;
+            for (; r + 3 * nrow < m; r += 4 * nrow) {                    // four row-passes per trip: the loads overlap
+                const double v0 = src[0], v1 = src[(size_t)nrow * Dp], v2 = src[(size_t)2 * nrow * Dp], v3 = src[(size_t)3 * nrow * Dp];
+                dst[0] = v0; dst[nrow * 17] = v1; dst[2 * nrow * 17] = v2; dst[3 * nrow * 17] = v3;
+                src += (size_t)4 * nrow * Dp; dst += 4 * nrow * 17;
+            }
+            for (; r < m; r += nrow) { dst[0] = src[0]; src += (size_t)nrow * Dp; dst += nrow * 17; }
+        }
         __syncthreads();
         for (int r = tid; r < m; r += NW_NT) {
             double *row = Pn + (size_t)r * 17;
@@ -116,12 +142,14 @@ __device__ inline bool chol_blocked(double *M, int Dp, double *lds)
 #pragma unroll
                 for (int u = 0; u < k; ++u) t -= xk[u] * Dg[k * 17 + u];
                 xk[k] = t * rinv[k];
+                __builtin_amdgcn_sched_barrier(0);        // one row of L11 at a time: hoisting all 120 LDS operands costs 240 VGPRs
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) row[k] = xk[k];
         }
         __syncthreads();
         for (int e = tid; e < m * 16; e += NW_NT) M[(size_t)(j0 + 16 + (e >> 4)) * Dp + j0 + (e & 15)] = Pn[(size_t)(e >> 4) * 17 + (e & 15)];
+        pf.mark(NP_PANEL);
         // (c) trailing update C -= P P^T on 16 x 16 tiles of the lower triangle (tiles on the diagonal are computed in full)
         const int mb = m / 16, ntile = mb * (mb + 1) / 2;
         const int col = lane & 15, kq = lane >> 4;
@@ -131,34 +159,44 @@ __device__ inline bool chol_blocked(double *M, int Dp, double *lds)
             while (I * (I + 1) / 2 > t) --I;
             Jc = t - I * (I + 1) / 2;
         };
-        // two tiles per trip: the loads of the second overlap the MFMAs of the first
-        for (int t = wave; t < ntile; t += 2 * (NW_NT / 64)) {
-            const int t2 = t + NW_NT / 64;
-            const bool two = t2 < ntile;
-            int I0, J0, I1, J1;
-            tile_of(t, I0, J0);
-            tile_of(two ? t2 : t, I1, J1);
-            double *C0 = M + (size_t)(j0 + 16 + 16 * I0) * Dp + j0 + 16 + 16 * J0;
-            double *C1 = M + (size_t)(j0 + 16 + 16 * I1) * Dp + j0 + 16 + 16 * J1;
-            d4 a0, a1;
+        // four tiles per trip and wavefront: the global loads of all four are in flight before the first MFMA issues
+        constexpr int NWV = NW_NT / 64, TPT = 4;
+        for (int t = wave; t < ntile; t += TPT * NWV) {
+            double *C[TPT];
+            int Ib[TPT], Jb[TPT];
+            d4 acc[TPT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { a0[r] = C0[(size_t)(kq + 4 * r) * Dp + col]; a1[r] = C1[(size_t)(kq + 4 * r) * Dp + col]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                a0 = mfma_f64(-Pn[(size_t)(16 * I0 + col) * 17 + 4 * u + kq], Pn[(size_t)(16 * J0 + col) * 17 + 4 * u + kq], a0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                a1 = mfma_f64(-Pn[(size_t)(16 * I1 + col) * 17 + 4 * u + kq], Pn[(size_t)(16 * J1 + col) * 17 + 4 * u + kq], a1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) C0[(size_t)(kq + 4 * r) * Dp + col] = a0[r];
-            if (two) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) C1[(size_t)(kq + 4 * r) * Dp + col] = a1[r];
+            for (int q = 0; q < TPT; ++q) {
+                const int tq = t + q * NWV;
+                tile_of(tq < ntile ? tq : t, Ib[q], Jb[q]);
+                C[q] = M + (size_t)(j0 + 16 + 16 * Ib[q] + kq) * Dp + j0 + 16 + 16 * Jb[q] + col;
             }
+#pragma unroll
+            for (int q = 0; q < TPT; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[q][r] = C[q][(size_t)(4 * r) * Dp];
+#pragma unroll
+            for (int q = 0; q < TPT; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[q] = mfma_f64(-Pn[(size_t)(16 * Ib[q] + col) * 17 + 4 * u + kq], Pn[(size_t)(16 * Jb[q] + col) * 17 + 4 * u + kq], acc[q]);
+#pragma unroll
+            for (int q = 0; q < TPT; ++q)
+                if (q == 0 || t + q * NWV < ntile) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) C[q][(size_t)(4 * r) * Dp] = acc[q][r];
+                }
         }
         __syncthreads();
+        pf.mark(NP_TRAIL);
     }
     return true;
+}
+
+__device__ __forceinline__ double sum16(double t)                  // sum over each aligned group of 16 lanes (valid in the group's lane 0)
+{
+    t += dpp_perm<0xB1>(t); t += dpp_perm<0x4E>(t); t += dpp_perm<0x141>(t); t += dpp_perm<0x140>(t);
+    return t;
 }
 
 // v <- (L L^T)^-1 v, L = lower triangle of the row-major Dp x Dp matrix M (Dp a multiple of 16, identity on the padding);
@@ -183,7 +221,7 @@ __device__ inline void chol_blocked_solve(const double *M, int Dp, double *v, do
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const double c = t * rd;
-                const double yk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c), k), __builtin_amdgcn_readlane(__double2loint(c), k));
+                const double yk = bcast_lane(c, k);
                 if (j > k) t -= Lr[k] * yk;
                 if (j == k) t = yk * Lr[j];                           // keeps t / L[j][j] = y_j for the store below
             }
@@ -193,10 +231,19 @@ __device__ inline void chol_blocked_solve(const double *M, int Dp, double *v, do
         // rows below: v_i -= L[i][j0 .. j0+16) . y  -- 16 lanes per row
         const int lane16 = tid & 15;
         const double yk = v[j0 + lane16];
-        for (int i = j0 + 16 + (tid >> 4); i < Dp; i += NW_NT / 16) {
-            double t = M[(size_t)i * Dp + j0 + lane16] * yk;
-            t += dpp_perm<0xB1>(t); t += dpp_perm<0x4E>(t); t += dpp_perm<0x141>(t); t += dpp_perm<0x140>(t);   // sum over the 16-lane row
-            if (lane16 == 0) v[i] -= t;
+        {
+            constexpr int NR = NW_NT / 16;
+            int i = j0 + 16 + (tid >> 4);
+            for (; i + 3 * NR < Dp; i += 4 * NR) {
+                const double *mp = M + (size_t)i * Dp + j0 + lane16;
+                double t0 = mp[0] * yk, t1 = mp[(size_t)NR * Dp] * yk, t2 = mp[(size_t)2 * NR * Dp] * yk, t3 = mp[(size_t)3 * NR * Dp] * yk;
+                t0 = sum16(t0); t1 = sum16(t1); t2 = sum16(t2); t3 = sum16(t3);
+                if (lane16 == 0) { v[i] -= t0; v[i + NR] -= t1; v[i + 2 * NR] -= t2; v[i + 3 * NR] -= t3; }
+            }
+            for (; i < Dp; i += NR) {
+                const double t = sum16(M[(size_t)i * Dp + j0 + lane16] * yk);
+                if (lane16 == 0) v[i] -= t;
+            }
         }
         __syncthreads();
     }
@@ -215,7 +262,7 @@ __device__ inline void chol_blocked_solve(const double *M, int Dp, double *v, do
 #pragma unroll
             for (int k = 15; k >= 0; --k) {
                 const double c = t * rd;
-                const double xk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c), k), __builtin_amdgcn_readlane(__double2loint(c), k));
+                const double xk = bcast_lane(c, k);
                 if (j < k) t -= Lc[k] * xk;
                 if (j == k) t = xk * Lc[j];
             }
@@ -230,6 +277,52 @@ __device__ inline void chol_blocked_solve(const double *M, int Dp, double *v, do
             v[k] -= t;
         }
         __syncthreads();
+    }
+}
+
+// H (symmetrised central differences of the probe gradients, when the fit asked for a fresh Hessian) and the damped
+// matrix M = -H + lam I of every active fit: 16 rows of one fit per workgroup, so the 2 D^2 probe gradients are read at
+// the whole chip's bandwidth instead of one CU's load latency (the solve kernel spent 0.4 M of its 1.9 M cycles here at D = 331).
+__global__ __launch_bounds__(256) void newton_build_kernel(NewtonBufs b, const int *active, int n_active)
+{
+    const int a = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = active[a], D = b.D, Dp = b.Dp;
+    NewtonState &S = b.st[f];
+    if (S.done) return;
+    double *H = b.H + (size_t)f * Dp * Dp, *M = b.M + (size_t)f * Dp * Dp;
+    const double lam = S.lam;
+    const int r0 = 16 * blockIdx.x;
+    if (S.need_hess) {
+        // (a < n_hess by construction: the fits that need a Hessian are listed first and own probe slot a)
+        const double *pg = b.pgrad + (size_t)a * 2 * D * D, *hs = b.hstep + (size_t)f * D;
+        int bad = 0;
+        for (int i = r0 + wv; i < r0 + 16; i += 4) {
+            if (i >= D) {
+                for (int k = lane; k < Dp; k += 64) M[(size_t)i * Dp + k] = i == k ? 1.0 : 0.0;
+                continue;
+            }
+            const double ri = 0.5 / hs[i];
+            for (int k = lane; k < Dp; k += 64) {
+                double m = 0.0;
+                if (k < D) {
+                    const double hik = (pg[(size_t)(2 * i) * D + k] - pg[(size_t)(2 * i + 1) * D + k]) * ri;
+                    const double hki = (pg[(size_t)(2 * k) * D + i] - pg[(size_t)(2 * k + 1) * D + i]) * (0.5 / hs[k]);
+                    const double h = 0.5 * (hik + hki);
+                    if (!isfinite(h)) bad = 1;
+                    H[(size_t)i * Dp + k] = h;
+                    m = -h + (i == k ? lam : 0.0);
+                }
+                M[(size_t)i * Dp + k] = m;
+            }
+        }
+        if (__syncthreads_or(bad) && tid == 0) atomicOr(&S.hbad, 1);
+    } else {
+        for (int i = r0 + wv; i < r0 + 16; i += 4)
+            for (int k = lane; k < Dp; k += 64) {
+                double m = i == k ? 1.0 : 0.0;
+                if (i < D && k < D) m = -H[(size_t)i * Dp + k] + (i == k ? lam : 0.0);
+                M[(size_t)i * Dp + k] = m;
+            }
     }
 }
 
@@ -248,42 +341,34 @@ __global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const
     double *red = v + Dp;                         // 64 doubles
     double *cl = red + 64;                        // Cholesky scratch
     __shared__ int s_fin;
+    NewtonProf pf(b.prof);
+    const long long wall0 = b.prof ? wall_clock64() : 0;
+    // H (when new probe gradients arrived) and M = -H + lam I were written by newton_build_kernel
     if (S.need_hess) {
-        const double *pg = b.pgrad + (size_t)a * 2 * D * D;
-        int fin = 1;
-        for (size_t e = tid; e < (size_t)D * D; e += NW_NT) {
-            const int j = (int)(e / D), k = (int)(e - (size_t)j * D);
-            const double hv = (pg[(size_t)(2 * j) * D + k] - pg[(size_t)(2 * j + 1) * D + k]) / (2.0 * hs[j]);
-            H[(size_t)j * Dp + k] = hv;
-            if (!isfinite(hv)) fin = 0;
-        }
-        fin = __syncthreads_and(fin);
-        if (!fin) { if (tid == 0) { S.rc = 2; S.done = 1; } return; }
-        for (size_t e = tid; e < (size_t)D * D; e += NW_NT) {        // symmetrise (each pair by the thread of its lower element)
-            const int j = (int)(e / D), k = (int)(e - (size_t)j * D);
-            if (k < j) {
-                const double m = 0.5 * (H[(size_t)j * Dp + k] + H[(size_t)k * Dp + j]);
-                H[(size_t)j * Dp + k] = m; H[(size_t)k * Dp + j] = m;
-            }
-        }
+        if (S.hbad) { if (tid == 0) { S.rc = 2; S.done = 1; } return; }
         __syncthreads();
         if (tid == 0) { S.need_hess = 0; S.n_evals += 2 * D; }
     }
+    pf.mark(NP_HESS);
     double lam = S.lam;
-    bool ok = false;
+    bool ok = false, rebuilt = true;
     while (lam <= 1e12) {
-        for (size_t e = tid; e < (size_t)Dp * Dp; e += NW_NT) {
-            const int i = (int)(e / Dp), k = (int)(e - (size_t)i * Dp);
-            double m = 0.0;
-            if (i < D && k < D) m = -H[e] + (i == k ? lam : 0.0);
-            else if (i == k) m = 1.0;                              // identity on the padding
-            M[e] = m;
+        if (!rebuilt) {                                            // more damping after a failed factorisation: M again from H
+            for (int i = tid >> 6; i < Dp; i += NW_NT / 64)
+                for (int k = tid & 63; k < Dp; k += 64) {
+                    double m = i == k ? 1.0 : 0.0;                 // identity on the padding
+                    if (i < D && k < D) m = -H[(size_t)i * Dp + k] + (i == k ? lam : 0.0);
+                    M[(size_t)i * Dp + k] = m;
+                }
+            __syncthreads();
         }
-        __syncthreads();
-        if (chol_blocked(M, Dp, cl)) {
+        rebuilt = false;
+        pf.mark(NP_BUILD);
+        if (chol_blocked(M, Dp, cl, pf)) {
             for (int i = tid; i < Dp; i += NW_NT) v[i] = i < D ? g[i] : 0.0;
             __syncthreads();
             chol_blocked_solve(M, Dp, v, cl);
+            pf.mark(NP_SOLVE);
             int fin = 1;
             for (int i = tid; i < D; i += NW_NT) {
                 const double t = x[i] + v[i];
@@ -299,25 +384,22 @@ __global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const
         __syncthreads();
     }
     if (!ok) { if (tid == 0) { S.rc = 2; S.done = 1; S.lam = lam; } return; }
-    // trial point and predicted increase g.s + 1/2 s^T H s
-    double pred = 0.0;
-    for (int i = tid; i < D; i += NW_NT) { s[i] = v[i]; xt[i] = x[i] + v[i]; }
-    __syncthreads();
+    // trial point and the model's predicted increase g.s + 1/2 s^T H s.  With (-H + lam I) s = g this is
+    // 1/2 (g.s + lam s.s): no product with H is needed (the difference is the residual of the backward-stable solve).
+    double gs = 0.0, ss = 0.0;
+    for (int i = tid; i < D; i += NW_NT) { const double si = v[i]; s[i] = si; xt[i] = x[i] + si; gs += g[i] * si; ss += si * si; }
     const int lane = tid & 63, wave = tid >> 6;
-    for (int j = wave; j < D; j += NW_NT / 64) {
-        const double *rowj = H + (size_t)j * Dp;
-        double t = 0.0;
-        for (int k = lane; k < D; k += 64) t += rowj[k] * v[k];
-        t = sum32(t); t += __shfl_xor(t, 32);
-        if (lane == 0) pred += v[j] * (g[j] + 0.5 * t);
-    }
-    if (lane == 0) red[wave] = pred;
+    gs = sum32(gs); gs += __shfl_xor(gs, 32);
+    ss = sum32(ss); ss += __shfl_xor(ss, 32);
+    if (lane == 0) { red[wave] = gs; red[8 + wave] = ss; }
     __syncthreads();
     if (tid == 0) {
-        double p = 0.0;
-        for (int w = 0; w < NW_NT / 64; ++w) p += red[w];
-        S.pred = p; S.lam = lam;
+        double p = 0.0, q = 0.0;
+        for (int w = 0; w < NW_NT / 64; ++w) { p += red[w]; q += red[8 + w]; }
+        S.pred = 0.5 * (p + lam * q); S.lam = lam;
     }
+    pf.mark(NP_PRED);
+    if (pf.p) { pf.p[NP_WALL] += wall_clock64() - wall0; pf.p[NP_CALLS] += 1; }
 }
 
 // consume the trial evaluation (lp_t, grad_t in gt): accept / reject (bdrt_newton.h NewtonFit::consume, NEED_TRIAL)
@@ -425,6 +507,12 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
     NW_HIP(alloc((size_t)n_fits * 2 * D * D * sizeof(double), (void **)&b.pgrad));
     NW_HIP(alloc((size_t)n_fits * 2 * D * sizeof(double), (void **)&b.plp));
     NW_HIP(alloc((size_t)n_fits * sizeof(NewtonState), (void **)&b.st));
+    b.prof = nullptr;
+    const char *prof_env = getenv("BDRT_NEWTON_PROF");
+    if (prof_env && prof_env[0] == '1') {
+        NW_HIP(alloc(NP_COUNT * sizeof(long long), (void **)&b.prof));
+        NW_HIP(hipMemset(b.prof, 0, NP_COUNT * sizeof(long long)));
+    }
     int *d_active = nullptr, *d_spec1 = nullptr, *d_specp = nullptr;
     double *d_lpt = nullptr;
     NW_HIP(alloc((size_t)n_fits * sizeof(int), (void **)&d_active));
@@ -463,6 +551,7 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
             hipLaunchKernelGGL(newton_probe_kernel, dim3(2 * D, n_hess), dim3(128), 0, st, b, (const int *)d_active, n_hess);
             if ((rc = launch_logp_grad(&P, b.probes, d_specp, n_hess * 2 * D, 0, b.plp, b.pgrad, nullptr, nullptr, nullptr, st))) { cleanup(); return rc; }
         }
+        hipLaunchKernelGGL(newton_build_kernel, dim3(Dp / 16, n_active), dim3(256), 0, st, b, (const int *)d_active, n_active);
         hipLaunchKernelGGL(newton_solve_kernel, dim3(n_active), dim3(NW_NT), lds_solve, st, b, (const int *)d_active, n_active);
         // trial points of the active fits, gathered into contiguous rows of gt / lp_t: evaluate xt of fit hact[a] into slot a
         // (xt rows are per fit; the evaluator wants a dense batch: copy the active rows)
@@ -482,6 +571,15 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
         if (iters_out) iters_out[i] = hst[i].iters;
         if (rc_out) rc_out[i] = hst[i].done ? hst[i].rc : 1;
         if (n_evals_out) n_evals_out[i] = hst[i].n_evals;
+    }
+    if (b.prof) {
+        long long hp[NP_COUNT];
+        NW_HIP(hipMemcpy(hp, b.prof, sizeof(hp), hipMemcpyDeviceToHost));
+        const double n = hp[NP_CALLS] ? (double)hp[NP_CALLS] : 1.0;
+        fprintf(stderr, "[bdrt newton prof] D %d, %lld solve launches (workgroup 0); core cycles per launch: hessian %.0f, build %.0f, "
+                "chol diag %.0f / panel %.0f / trailing %.0f, solve %.0f, pred %.0f; wall %.1f us per launch\n", D, hp[NP_CALLS],
+                hp[NP_HESS] / n, hp[NP_BUILD] / n, hp[NP_DIAG] / n, hp[NP_PANEL] / n, hp[NP_TRAIL] / n, hp[NP_SOLVE] / n, hp[NP_PRED] / n,
+                hp[NP_WALL] / n / 100.0);
     }
 #undef NW_HIP
     cleanup();

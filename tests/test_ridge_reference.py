@@ -184,6 +184,27 @@ def test_device_hyper_lambda_loop_equals_host_iteration(kw, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_device_loop_with_the_kkt_triangle_in_global_memory(monkeypatch):
+    """n = 203 unknowns (K = 201): the packed KKT triangle no longer fits in LDS and is factored in a global work buffer;
+    same iteration, same answer as the host-driven loop."""
+    from bayes_drt_amd.inversion import Inverter
+    c = load('csv_2ZARC_uniform_0.25')
+    f, Z = c['Z'][:, 0], c['Z'][:, 1] + 1j * c['Z'][:, 2]
+    import warnings
+    res = []
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv('BDRT_HOST_LAMBDA_LOOP', '1')
+        inv = Inverter(basis_freq=np.logspace(8, -4, 201))
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            inv.ridge_fit(f, Z, max_iter=6)
+        res.append((inv.distribution_fits['DRT']['coef'].copy(), len(inv._iter_history)))
+    assert res[0][1] == res[1][1] and len(res[0][0]) == 201
+    assert np.max(np.abs(res[0][0] - res[1][0])) <= 1e-7 * np.max(np.abs(res[1][0]))
+
+
+@pytest.mark.gpu
 def test_qp_at_the_cv_problem_size_against_an_exact_active_set_answer():
     """n = 163 (R_inf, L, 161 coefficients), the P / q of the real-part fits of a Re-Im cross-validation at K = 161:
     the interior-point answer against NNLS on a Cholesky factor of P (an independent, exact active-set method)."""
