@@ -243,6 +243,7 @@ enum { S_RINF = 0, S_INDUC, S_SRES, S_AP, S_AR, S_AI, S_D0 /* 9 slots */, S_XSUM
 struct TileIO {
     const double *theta;   // unconstrained parameters
     long t_sc, t_sj;       // strides: chain, parameter
+    const int *t_off;      // optional per-chain extra offset (doubles) of the theta row: the sampler's ping-pong rows; nullptr: none
     double *grad;          // may be nullptr
     long g_sc, g_sj;
     double *lp;            // [16] (global or LDS), stride 1; may be nullptr
@@ -285,7 +286,7 @@ __device__ inline void logp_grad_tile(const DevProblem &P, const TileIO &io, dou
     double *sc = red + NW * NRED * NC;
     const bool cache_x = P.XCR > 0;
 
-    const double *th = io.theta + (long)cc * io.t_sc;
+    const double *th = io.theta + (long)cc * io.t_sc + (io.t_off ? io.t_off[cc] : 0);
     auto TH = [&](int j) -> double { return th[(long)j * io.t_sj]; };
     double *gr = io.grad ? io.grad + (long)cc * io.g_sc : nullptr;
     auto GW = [&](int j, double v) { if (gr && valid) gr[(long)j * io.g_sj] = v; };

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restr
     const int c0 = blockIdx.x * NC;
     TileIO io;
     io.theta = theta + (size_t)c0 * P.D;
-    io.t_sc = P.D; io.t_sj = 1;
+    io.t_sc = P.D; io.t_sj = 1; io.t_off = nullptr;
     io.grad = grad ? grad + (size_t)c0 * P.D : nullptr;
     io.g_sc = P.D; io.g_sj = 1;
     io.lp = lp ? lp + c0 : nullptr;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(1024) void logp_grad_kernel_wide(const DevProblem *
     const int c0 = blockIdx.x * NC;
     TileIO io;
     io.theta = theta + (size_t)c0 * P.D;
-    io.t_sc = P.D; io.t_sj = 1;
+    io.t_sc = P.D; io.t_sj = 1; io.t_off = nullptr;
     io.grad = grad ? grad + (size_t)c0 * P.D : nullptr;
     io.g_sc = P.D; io.g_sj = 1;
     io.lp = lp ? lp + c0 : nullptr;

@@ -33,7 +33,9 @@ static_assert(NW * NQ_CHK * NC <= MIN_LR * NC, "Lr buffer too small for the NUTS
 
 // state vectors per workgroup, each [D][16]
 enum { V_TH = 0, V_P, V_G, V_THM, V_PM, V_GM, V_THP, V_PP, V_GP, V_THS, V_GS, V_THQ, V_GQ, V_RHO, V_RHOC, V_MINV,
-       V_WMEAN, V_WM2, V_ZN /* normals of the next transition's momentum, produced ahead of time */, V_CKC /* MAXD */, V_CKP = V_CKC + MAXD /* MAXD */, V_COUNT = V_CKP + MAXD };
+       V_WMEAN, V_WM2, V_ZN /* normals of the next transition's momentum, produced ahead of time */,
+       V_TH2 /* second theta row of the wide-vector path (ping-pong with V_TH) */,
+       V_PF /* wide-vector path: momentum after the full step of a leaf that merges more than two levels */, V_CKC /* MAXD */, V_CKP = V_CKC + MAXD /* MAXD */, V_COUNT = V_CKP + MAXD };
 
 // chain k of a workgroup <-> column (half-wave) of the 16-column tile: k = 0..7 -> columns 0, 2, .., 14 (one wave each),
 // k = 8..15 -> columns 1, 3, .., 15
@@ -100,6 +102,9 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     ChainState *sts = reinterpret_cast<ChainState *>(lpn + NC);
     int *spec = reinterpret_cast<int *>(sts + NC);
     volatile int *slow = spec + NC;     // set by a chain that is about to do something long this round (see stage Z)
+    int *thoff = spec + NC + 4;         // wide-vector path: offset of each chain's live theta row (0 or V_TH2 - V_TH rows)
+    constexpr bool SPEC = NJ > 16 || (NJ > 11 && MODE < 2);      // (== CHUNKED below)
+    const int TH2OFF = (V_TH2 - V_TH) * NC * DS;
 
     double *V = a.vecs + (size_t)wg * V_COUNT * NC * DS;
     auto row = [&](int v) -> double * { return V + ((size_t)v * NC + c) * DS; };   // this chain's row of vector v
@@ -109,6 +114,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         if (k < nvalid) sts[tid] = a.states[c0 + k];
         else { memset(&sts[tid], 0, sizeof(ChainState)); sts[tid].phase = PH_DONE; }
         spec[tid] = k < nvalid ? sts[tid].spec : 0;
+        thoff[tid] = (SPEC && sts[tid].thsel) ? TH2OFF : 0;
     }
     __syncthreads();
     ChainState &s = sts[c];
@@ -116,6 +122,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 
     TileIO io;
     io.theta = V + (size_t)V_TH * NC * DS; io.t_sc = DS; io.t_sj = 1;
+    io.t_off = SPEC ? thoff : nullptr;
     io.grad = V + (size_t)V_G * NC * DS; io.g_sc = DS; io.g_sj = 1;
     if (MODE == 2) {
         // fast S1 path: theta lives in LDS for the whole launch (read by the tile, updated in place by the leapfrog), and
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 #define BDRT_WAVE_PROF(slot) do { if (io.prof && lane == 0) { const long long t_ = clock64(); atomicAdd((unsigned long long *)&io.prof[slot], (unsigned long long)(t_ - twv)); twv = t_; } } while (0)
 
     unsigned long long my_leaps = 0;
-    double *TH = row(V_TH), *Pm = row(V_P), *G = row(V_G), *MI = row(V_MINV);
+    double *TH = row(V_TH) + (SPEC && s.thsel ? TH2OFF : 0), *Pm = row(V_P), *G = row(V_G), *MI = row(V_MINV);
 
     // half kick + drift of the first evaluation of a freshly created sampler (afterwards every loop body ends with the
     // kick/drift of the NEXT evaluation, reusing p, g, Minv from registers: stage A' below)
@@ -188,6 +195,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         constexpr int NA = CHUNKED ? 1 : NJ;
         constexpr int MB = !CHUNKED ? NJ : (NJ % 8 == 0 ? 8 : 9);
         static_assert(NJ % MB == 0, "chunk size must divide NJ");
+        static_assert(SPEC == CHUNKED, "the ping-pong theta rows belong to the chunked path");
         double p_[NA], g_[NA], mi_[NA];
 #pragma unroll
         for (int m = 0; m < NA; ++m) { p_[m] = 0.0; g_[m] = 0.0; mi_[m] = 1.0; }
@@ -205,29 +213,92 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         else { logp_grad_tile<MODE == 1>(P, io, smem); load_state(); }
         if (io.prof && tid == 0) tnp = clock64();
         BDRT_WAVE_PROF(17);
+        const long long t_post0 = (io.prof && MODE == 4) ? clock64() : 0;      // (experiment) post-evaluation time of this wave by event class
 
         // ---- C: second half kick, kinetic energy, finiteness of the gradient -----------------------------
         // (p, g, Minv of this chain stay in registers from here to the end of stage D)
         double kin = 0.0, nonfin = 0.0;
+        const int dir_now = s.dir;
+        const int leaf_now = s.leaf;
+        // (chunked path) U-turn dot products of merge levels 0 and 1, produced by the same pass as the half kick
+        double um0a = 0.0, um0b = 0.0, um1a = 0.0, um1b = 0.0;
+        bool specd = false;                                     // the next leapfrog's kick + drift was done ahead (chunked path)
         if constexpr (CHUNKED) {
             if (act) {
+                // A tree leaf knows before its evaluation which sub-subtrees it closes (nmf = trailing one bits of its index),
+                // so the pass that finishes the leapfrog (second half kick, kinetic energy) also runs the two lowest merge
+                // levels and files the resulting sub-subtree: one trip through the rows, all loads of a chunk in flight
+                // together, instead of one dependent trip per stage.  7 of 8 leaves need nothing else before the next
+                // leapfrog.  Element by element the arithmetic is that of the staged form below (levels >= 2 continue from
+                // the V_RHOC row).  Stores made before the U-turn / divergence verdict go to rows nobody reads if the
+                // verdict is negative: level nmf has no waiting sibling (bit nmf of the leaf index is 0).
+                const bool treeph = ph0 == PH_TREE;
+                int nmf = 0;
+                if (treeph) { while ((leaf_now >> nmf) & 1) ++nmf; }
+                const bool lastf = treeph && leaf_now == s.nleaves - 1;
+                const bool m0 = nmf > 0, m1 = nmf > 1;
+                const double *PL0 = row(V_CKP), *RL1 = row(V_CKC + 1), *PL1 = row(V_CKP + 1);
+                // running sum: to the carry row when more levels follow or the subtree closes, else it is the new checkpoint
+                double *RHD = (nmf > 2 || lastf) ? row(V_RHOC) : row(V_CKC + (nmf > 0 ? nmf : 1));
+                double *FRD = row(V_CKP + (nmf > 2 ? 0 : nmf));
+                const bool st_rho = m0, st_first = treeph && !lastf && nmf <= 2;
+                // Such a leaf (not the last of its subtree, nothing left to merge afterwards) continues with the next leapfrog
+                // of the same trajectory unless the transition ends with it -- and then neither its theta nor its momentum is
+                // looked at again.  So the pass also does the half kick + drift of the NEXT leapfrog: momentum in place, theta
+                // into the chain's other theta row (the evaluated point stays readable for the proposal copy); the rows swap
+                // roles once the verdict is in.  Same arithmetic as stage A'.
+                // (a leaf that merges more than two levels keeps its full-step momentum in the V_PF row for the later levels)
+                specd = treeph && !lastf;
+                const bool keep_pf = specd && nmf > 2;
+                double *THN = row(V_TH) + (s.thsel ? 0 : TH2OFF), *PF = row(V_PF);
 #pragma unroll 1
                 for (int mb = 0; mb < NJ; mb += MB) {
-                    double a_[MB], b_[MB], c_[MB];
+                    double a_[MB], b_[MB], c_[MB], l0_[MB], r1_[MB], l1_[MB], t_[MB];
 #pragma unroll
-                    for (int mm = 0; mm < MB; ++mm) { const int j = l32 + 32 * (mb + mm); a_[mm] = Pm[j]; b_[mm] = G[j]; c_[mm] = MI[j]; }
+                    for (int mm = 0; mm < MB; ++mm) {
+                        const int j = l32 + 32 * (mb + mm);
+                        a_[mm] = Pm[j]; b_[mm] = G[j]; c_[mm] = MI[j];
+                        t_[mm] = 0.0;
+                        if (specd) t_[mm] = TH[j];
+                        l0_[mm] = 0.0; r1_[mm] = 0.0; l1_[mm] = 0.0;
+                        if (m0) l0_[mm] = PL0[j];
+                        if (m1) { r1_[mm] = RL1[j]; l1_[mm] = PL1[j]; }
+                    }
 #pragma unroll
                     for (int mm = 0; mm < MB; ++mm) {
                         const int j = l32 + 32 * (mb + mm);
                         if (j < D) {
                             const double p = a_[mm] + 0.5 * e * b_[mm];
-                            Pm[j] = p;                        // from here on the row holds the momentum after the full step
                             kin += c_[mm] * p * p;
                             nonfin += isfinite(b_[mm]) ? 0.0 : 1.0;
+                            if (specd) {
+                                const double pn = p + 0.5 * e * b_[mm];
+                                Pm[j] = pn;
+                                THN[j] = t_[mm] + e * c_[mm] * pn;
+                                if (keep_pf) PF[j] = p;
+                            } else {
+                                Pm[j] = p;                    // from here on the row holds the momentum after the full step
+                            }
+                            double rho = p, first = p;
+                            if (m0) {
+                                rho = l0_[mm] + p;
+                                um0a += c_[mm] * l0_[mm] * rho;
+                                um0b += c_[mm] * p * rho;
+                                first = l0_[mm];
+                            }
+                            if (m1) {
+                                rho = r1_[mm] + rho;
+                                um1a += c_[mm] * l1_[mm] * rho;
+                                um1b += c_[mm] * p * rho;
+                                first = l1_[mm];
+                            }
+                            if (st_rho) RHD[j] = rho;
+                            if (st_first) FRD[j] = first;
                         }
                     }
                 }
             }
+            um0a = half_sum(um0a); um0b = half_sum(um0b); um1a = half_sum(um1a); um1b = half_sum(um1b);
         } else if (act) {
 #pragma unroll
             for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; g_[m] = G[j]; }
@@ -252,8 +323,6 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         bool upds = false, welf = false, wend = false;
         int nm = 0, endt = 0, next = 0, draw = -1;
         double wn = 0.0;
-        const int dir_now = s.dir;
-        const int leaf_now = s.leaf;
         if (act) {
             const double lp = lpn[c];
             const bool finite_pt = isfinite(lp) && nonfin == 0.0;
@@ -328,7 +397,10 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         BDRT_WAVE_PROF(19);
 
         // ---- D: proposal copy, checkpoints, running rho, U-turn tests, subtree close ----------------------------
-        if (copyq || cur2s) {
+        // (chunked path) the proposal copy of a leaf that is not the last of its subtree rides on the pass of stage A', which
+        // reads theta and the gradient anyway; if that pass does not happen the subtree was discarded and so is its proposal
+        const bool copy_later = CHUNKED && copyq && !last;
+        if ((copyq || cur2s) && !copy_later) {
             double *THQ = row(V_THQ), *GQ = row(V_GQ), *THS = row(V_THS), *GS = row(V_GS);
             if constexpr (CHUNKED) {
 #pragma unroll 1
@@ -369,73 +441,57 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             double rc_[NA], cpl_[NA];                  // rho / first momentum of the sub-subtree that ends at this leaf
             bool ok = true;
             if constexpr (CHUNKED) {
-                // running sum of the merged sub-subtree in the V_RHOC row (level 0 merges read the momentum row itself)
+                // levels 0 and 1 were merged by the pass of stage C (which also filed the sub-subtree when nm <= 2); higher
+                // levels continue from the running sum in the V_RHOC row, two levels per trip, and the last trip files the
+                // sub-subtree of 2^nm leaves that ends here as the waiting left sibling of level nm
                 double *RC = row(V_RHOC);
-                if (nm > 0) {
-                    // level 0: the waiting sibling is a single leaf (rho = its momentum) and the running sum is this leaf's
-                    // momentum: three rows instead of five
-                    const double *PL = row(V_CKP);
-                    double a0 = 0.0, a1 = 0.0;
+                const double *PFr = specd ? row(V_PF) : Pm;       // this leaf's momentum after the full step
+                if (nm > 0) ok = ok && (um0a > 0.0) && (um0b > 0.0);
+                if (nm > 1) ok = ok && (um1a > 0.0) && (um1b > 0.0);
+                for (int l = 2; l < nm; l += 2) {
+                    const long long t_lv0 = io.prof ? clock64() : 0;       // (experiment) cost of one level-pair pass
+                    const bool two = l + 1 < nm, fin = l + 2 >= nm;
+                    const double *RLa = row(V_CKC + l), *PLa = row(V_CKP + l);
+                    const double *RLb = row(V_CKC + (two ? l + 1 : l)), *PLb = row(V_CKP + (two ? l + 1 : l));
+                    const bool file = fin && !last;
+                    double *RHD = file ? row(V_CKC + nm) : RC;
+                    double *FRD = row(V_CKP + (file ? nm : 0));
+                    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
 #pragma unroll 1
                     for (int mb = 0; mb < NJ; mb += MB) {
-                        double lp_[MB], pp_[MB], mm_[MB];
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) { const int j = l32 + 32 * (mb + mm); lp_[mm] = PL[j]; pp_[mm] = Pm[j]; mm_[mm] = MI[j]; }
+                        double lr_[MB], lp_[MB], lr2_[MB], lp2_[MB], rr_[MB], pp_[MB], mm_[MB];
 #pragma unroll
                         for (int mm = 0; mm < MB; ++mm) {
                             const int j = l32 + 32 * (mb + mm);
-                            if (j < D) {
-                                const double rho = lp_[mm] + pp_[mm];
-                                a0 += mm_[mm] * lp_[mm] * rho;
-                                a1 += mm_[mm] * pp_[mm] * rho;
-                                RC[j] = rho;
-                            }
-                        }
-                    }
-                    a0 = half_sum(a0); a1 = half_sum(a1);
-                    ok = ok && (a0 > 0.0) && (a1 > 0.0);
-                }
-                for (int l = 1; l < nm; ++l) {
-                    const double *RL = row(V_CKC + l), *PL = row(V_CKP + l);
-                    const double *RCs = RC;
-                    double a0 = 0.0, a1 = 0.0;
-#pragma unroll 1
-                    for (int mb = 0; mb < NJ; mb += MB) {
-                        double lr_[MB], lp_[MB], rr_[MB], pp_[MB], mm_[MB];
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            lr_[mm] = RL[j]; lp_[mm] = PL[j]; rr_[mm] = RCs[j]; pp_[mm] = Pm[j]; mm_[mm] = MI[j];
+                            lr_[mm] = RLa[j]; lp_[mm] = PLa[j]; rr_[mm] = RC[j]; pp_[mm] = PFr[j]; mm_[mm] = MI[j];
+                            lr2_[mm] = 0.0; lp2_[mm] = 0.0;
+                            if (two) { lr2_[mm] = RLb[j]; lp2_[mm] = PLb[j]; }
                         }
 #pragma unroll
                         for (int mm = 0; mm < MB; ++mm) {
                             const int j = l32 + 32 * (mb + mm);
                             if (j < D) {
-                                const double rho = lr_[mm] + rr_[mm];
+                                double rho = lr_[mm] + rr_[mm];
                                 a0 += mm_[mm] * lp_[mm] * rho;
                                 a1 += mm_[mm] * pp_[mm] * rho;
-                                RC[j] = rho;
+                                double first = lp_[mm];
+                                if (two) {
+                                    rho = lr2_[mm] + rho;
+                                    b0 += mm_[mm] * lp2_[mm] * rho;
+                                    b1 += mm_[mm] * pp_[mm] * rho;
+                                    first = lp2_[mm];
+                                }
+                                RHD[j] = rho;
+                                if (file) FRD[j] = first;
                             }
                         }
                     }
-                    a0 = half_sum(a0); a1 = half_sum(a1);
+                    a0 = half_sum(a0); a1 = half_sum(a1); b0 = half_sum(b0); b1 = half_sum(b1);
                     ok = ok && (a0 > 0.0) && (a1 > 0.0);
-                }
-                if (ok && !last) {
-                    // the sub-subtree of 2^nm leaves that ends here becomes the waiting left sibling of level nm; its first
-                    // momentum is the one of the last level merged (or this leaf's own)
-                    double *PLn = row(V_CKP + nm), *RLn = row(V_CKC + nm);
-                    const double *SRC = nm == 0 ? Pm : row(V_CKP + nm - 1);
-#pragma unroll 1
-                    for (int mb = 0; mb < NJ; mb += MB) {
-                        double a_[MB], b_[MB];
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) { const int j = l32 + 32 * (mb + mm); a_[mm] = SRC[j]; b_[mm] = nm > 0 ? RC[j] : 0.0; }
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            if (j < D) { PLn[j] = a_[mm]; if (nm > 0) RLn[j] = b_[mm]; }
-                        }
+                    if (two) ok = ok && (b0 > 0.0) && (b1 > 0.0);
+                    if (io.prof && l32 == 0) {
+                        atomicAdd((unsigned long long *)&io.prof[8], (unsigned long long)(clock64() - t_lv0));
+                        atomicAdd((unsigned long long *)&io.prof[9], 1ull);
                     }
                 }
             } else {
@@ -619,9 +675,30 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 
         // ---- A' (common case): the trajectory continues from the point just evaluated: half kick + drift of the NEXT
         //      leapfrog with p, g, Minv still in registers (theta is the only vector read; p is written once per leapfrog)
-        if (act && next == 0 && s.phase == PH_TREE) {
+        if (specd && act && next == 0 && s.phase == PH_TREE) {
+            // the trajectory continues and its next leapfrog is already in place: the other theta row becomes the live one
+            if (copy_later) {
+                double *THQ = row(V_THQ), *GQ = row(V_GQ);
+#pragma unroll 1
+                for (int mb = 0; mb < NJ; mb += MB) {
+                    double a_[MB], b_[MB];
+#pragma unroll
+                    for (int mm = 0; mm < MB; ++mm) { const int j = l32 + 32 * (mb + mm); a_[mm] = TH[j]; b_[mm] = G[j]; }
+#pragma unroll
+                    for (int mm = 0; mm < MB; ++mm) {
+                        const int j = l32 + 32 * (mb + mm);
+                        if (j < D) { THQ[j] = a_[mm]; GQ[j] = b_[mm]; }
+                    }
+                }
+            }
+            const int sel = s.thsel ^ 1;
+            s.thsel = sel;
+            TH = row(V_TH) + (sel ? TH2OFF : 0);
+            thoff[c] = sel ? TH2OFF : 0;
+        } else if (act && next == 0 && s.phase == PH_TREE) {
             const double e1 = s.dir * s.eps;
             if constexpr (CHUNKED) {
+                double *THQ = row(V_THQ), *GQ = row(V_GQ);
 #pragma unroll 1
                 for (int mb = 0; mb < NJ; mb += MB) {
                     double pp_[MB], gg_[MB], mm_[MB], th_[MB];
@@ -634,7 +711,10 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     for (int mm = 0; mm < MB; ++mm) {
                         const int j = l32 + 32 * (mb + mm);
                         const double p = pp_[mm] + 0.5 * e1 * gg_[mm];
-                        if (j < D) { Pm[j] = p; TH[j] = th_[mm] + e1 * mm_[mm] * p; }
+                        if (j < D) {
+                            if (copy_later) { THQ[j] = th_[mm]; GQ[j] = gg_[mm]; }
+                            Pm[j] = p; TH[j] = th_[mm] + e1 * mm_[mm] * p;
+                        }
                     }
                 }
             } else {
@@ -973,6 +1053,17 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         BDRT_NUTS_PROF(16);
 
         BDRT_WAVE_PROF(22);
+        if (io.prof && MODE == 4) {
+            // classes: 0 plain leaf, 1 leaf merging > 2 levels, 2 subtree closed (doubling), 3 transition end / other
+            int cls = 0;
+            if (act) { if (endt || (next != 0 && next != 2) || ph0 != PH_TREE) cls = 3; else if (last) cls = 2; else if (nm > 2) cls = 1; }
+            const int other = __shfl_xor(cls, 32);
+            cls = cls > other ? cls : other;
+            if (lane == 0) {
+                atomicAdd((unsigned long long *)&io.prof[2 * cls], (unsigned long long)(clock64() - t_post0));
+                atomicAdd((unsigned long long *)&io.prof[2 * cls + 1], 1ull);
+            }
+        }
         if (io.prof && lane == 0 && next) atomicAdd((unsigned long long *)&io.prof[24], 1ull);
         {
             const int ph = s.phase;
@@ -1424,7 +1515,7 @@ static size_t nuts_lds_bytes(const DevProblem &P, bool s1)
 {
     const int nj = P.D <= 32 * 11 ? 11 : 16;
     const size_t tile = s1 ? s1_lds_doubles(P) + (size_t)NC * 32 * nj : lds_doubles(P);   // s1: + theta rows
-    return (tile + (size_t)NC) * sizeof(double) + NC * sizeof(ChainState) + NC * sizeof(int) + 16;
+    return (tile + (size_t)NC) * sizeof(double) + NC * sizeof(ChainState) + 2 * NC * sizeof(int) + 16;
 }
 
 }  // namespace bdrt
@@ -1504,7 +1595,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     S.hw = P.dev.fast_hw && P.dev.D <= 32 * 27;
     if (S.s1_hbm || S.hw)
         S.lds_bytes = ((S.hw ? hw_lds_doubles(P.dev) : s1_lds_doubles(P.dev)) + (size_t)NC) * sizeof(double) + NC * sizeof(ChainState) +
-                      NC * sizeof(int) + 16;
+                      2 * NC * sizeof(int) + 16;
     else
         S.lds_bytes = nuts_lds_bytes(P.dev, S.use_s1);
     auto fail = [&](const char *msg) -> bdrt_sampler * { set_error("%s", msg); bdrt_sampler_destroy(s); return nullptr; };

@@ -107,6 +107,7 @@ struct ChainState {
     int spec, chain_id;
     int kicked;           // the half kick + drift of the upcoming evaluation has already been applied
     int z_iter;           // iteration whose momentum normals are already stored in the chain's V_ZN row (-1: none)
+    int thsel;            // which of the two theta rows (V_TH / V_TH2) is live (wide-vector path: speculative drift, see stage C)
     double eps;           // nominal step size
     double H0, lsw, lsw_sub, lps, lpq, sum_metro;
     double da_sbar, da_xbar, da_mu;

@@ -42,7 +42,7 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
     double *xrow = Yp + (size_t)P.npar * TA * NC + (size_t)c * (2 * RW);      // the chain's private row
     double *wrow = xrow + RW;
 
-    const double *th = io.theta + (long)cc * io.t_sc;
+    const double *th = io.theta + (long)cc * io.t_sc + (io.t_off ? io.t_off[cc] : 0);
     auto TH = [&](int j) -> double { return th[(long)j * io.t_sj]; };
     double *gr = (io.grad && valid) ? io.grad + (long)cc * io.g_sc : nullptr;
     auto GW = [&](int j, double v) { if (gr) gr[(long)j * io.g_sj] = v; };

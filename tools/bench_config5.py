@@ -47,4 +47,8 @@ if prof:
     nwg = (n_units + 15) // 16
     for k, nm in enumerate(names): print('PHASE %-18s %9.0f cycles/round' % (nm, cyc[k] / nwg / 600))
     for k, nm in enumerate(['tile', 'C', 'S1', 'D', "A'", 'E', 'wait']): print('WAVE-AVG %-6s %9.0f' % (nm, cyc[17 + k] / nwg / 600 / 8))
+    for k, nm in enumerate(['plain leaf', 'leaf merging > 2 levels', 'subtree closed', 'transition end / other']):
+        if cyc[2 * k + 1]: print('WAVE-CLASS %-24s %5.1f %% of wave-rounds, %8.0f cycles after the evaluation' % (
+            nm, 100.0 * cyc[2 * k + 1] / (nwg * 600 * 8), cyc[2 * k] / cyc[2 * k + 1]))
+    if prof and cyc[9]: print('LEVEL-PAIR PASS: %.0f cycles each (%d passes)' % (cyc[8] / cyc[9], cyc[9]))
 lib.bdrt_sampler_destroy(h)
