@@ -32,10 +32,9 @@ constexpr int NQ_CHK = 2 * MAXD + 2;
 static_assert(NW * NQ_CHK * NC <= MIN_LR * NC, "Lr buffer too small for the NUTS reduction scratch");
 
 // state vectors per workgroup, each [D][16]
-enum { V_TH = 0, V_P, V_G, V_THM, V_PM, V_GM, V_THP, V_PP, V_GP, V_THS, V_GS, V_THQ, V_GQ, V_RHO, V_RHOC, V_MINV,
+enum { V_TH = 0, V_P, V_G, V_THM, V_PM, V_GM, V_THP, V_PP, V_GP, V_THS, V_GS, V_THQ, V_GQ, V_RHO, V_MINV,
        V_WMEAN, V_WM2, V_ZN /* normals of the next transition's momentum, produced ahead of time */,
-       V_TH2 /* second theta row of the wide-vector path (ping-pong with V_TH) */,
-       V_PF /* wide-vector path: momentum after the full step of a leaf that merges more than two levels */, V_CKC /* MAXD */, V_CKP = V_CKC + MAXD /* MAXD */, V_COUNT = V_CKP + MAXD };
+       V_TH2 /* second theta row of the wide-vector path (ping-pong with V_TH) */, V_CKC /* MAXD */, V_CKP = V_CKC + MAXD /* MAXD */, V_COUNT = V_CKP + MAXD };
 
 // chain k of a workgroup <-> column (half-wave) of the 16-column tile: k = 0..7 -> columns 0, 2, .., 14 (one wave each),
 // k = 8..15 -> columns 1, 3, .., 15
@@ -68,6 +67,8 @@ struct NutsArgs {
     long long *prof;       // optional [n_wg][32] cycle counters (phase profile)
 };
 
+#include "bdrt_nuts_wide.h"
+
 // Thread mapping of the bookkeeping stages: chain c of the workgroup lives in ONE half-wave (wave c/2, lanes
 // 32*(c%2)..+31); its D-vectors are contiguous rows, lane l handles elements l, l+32, ...  Per-chain dot products are
 // 5-step xor-shuffle reductions, the per-chain scalar logic runs redundantly in the 32 lanes of the half-wave (state
@@ -99,11 +100,13 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     constexpr int DSL = 32 * NJ;                    // LDS row stride of the theta rows
     double *thl = smem + tile_doubles;
     double *lpn = thl + (MODE == 2 ? (size_t)NC * DSL : 0);
-    ChainState *sts = reinterpret_cast<ChainState *>(lpn + NC);
+    double *hvk = lpn + NC;             // wide-vector path: [NC][2] results of a chain's own pass handed to the cooperative phase
+    ChainState *sts = reinterpret_cast<ChainState *>(hvk + 2 * NC);
     int *spec = reinterpret_cast<int *>(sts + NC);
     volatile int *slow = spec + NC;     // set by a chain that is about to do something long this round (see stage Z)
     int *thoff = spec + NC + 4;         // wide-vector path: offset of each chain's live theta row (0 or V_TH2 - V_TH rows)
-    constexpr bool SPEC = NJ > 16 || (NJ > 11 && MODE < 2);      // (== CHUNKED below)
+    int *hvy = thoff + NC;              // wide-vector path: chains that the cooperative phase finishes (bdrt_nuts_wide.h)
+    constexpr bool SPEC = NJ > 16 || (NJ > 11 && MODE < 2);      // wide-vector path (the S1 evaluator leaves room for 16 elements per lane)
     const int TH2OFF = (V_TH2 - V_TH) * NC * DS;
 
     double *V = a.vecs + (size_t)wg * V_COUNT * NC * DS;
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         // keep per-lane address arithmetic inside the loop (see the note in bdrt_tile_s1.h): hoisted, it is spilled
         __asm__ volatile("" : "+v"(c), "+v"(l32));
         if (tid == 0) *slow = 0;
+        if (SPEC && tid < NC) hvy[tid] = 0;
         const int ph0 = s.phase;
         const bool act = ph0 == PH_INIT || ph0 == PH_EPS || ph0 == PH_TREE;
         if (!any_act) break;
@@ -187,20 +191,14 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         // state of this chain that the stages after the evaluation need: momentum, inverse metric, and (odd leaves) the
         // momentum of the previous leaf.  The fast path issues these loads from inside the evaluation, right before its
         // backward GEMM; otherwise stage C loads them.
-        // Wide parameter vectors (NJ > 11: outlier error model, several distributions) do not fit in registers next to
-        // the evaluator: for them every stage below streams the chain's rows in chunks of MB elements per lane and keeps
-        // nothing in registers between stages (the momentum is stored back after the second half kick, the running
-        // sub-tree sum lives in the V_RHOC row).  Same arithmetic, element by element, as the register version.
-        constexpr bool CHUNKED = NJ > 16 || (NJ > 11 && MODE < 2);   // (the S1 evaluator leaves room for 16 elements per lane)
-        constexpr int NA = CHUNKED ? 1 : NJ;
-        constexpr int MB = !CHUNKED ? NJ : (NJ % 8 == 0 ? 8 : 9);
-        static_assert(NJ % MB == 0, "chunk size must divide NJ");
-        static_assert(SPEC == CHUNKED, "the ping-pong theta rows belong to the chunked path");
+        // Wide parameter vectors (SPEC: outlier error model, several distributions) do not fit in registers next to the
+        // evaluator: they take the wide-vector path below, which streams the chain's rows from HBM.
+        constexpr int NA = SPEC ? 1 : NJ;
         double p_[NA], g_[NA], mi_[NA];
 #pragma unroll
         for (int m = 0; m < NA; ++m) { p_[m] = 0.0; g_[m] = 0.0; mi_[m] = 1.0; }
         auto load_state = [&]() {
-            if constexpr (!CHUNKED) {
+            if constexpr (!SPEC) {
                 if (act) {
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; p_[m] = Pm[j]; mi_[m] = MI[j]; }
@@ -213,93 +211,161 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         else { logp_grad_tile<MODE == 1>(P, io, smem); load_state(); }
         if (io.prof && tid == 0) tnp = clock64();
         BDRT_WAVE_PROF(17);
-        const long long t_post0 = (io.prof && MODE == 4) ? clock64() : 0;      // (experiment) post-evaluation time of this wave by event class
+        const long long t_post0 = (io.prof && SPEC) ? clock64() : 0;      // wide-vector path: post-evaluation time of this wave (slots 0..3)
+        if constexpr (SPEC) {
+            // ================= wide-vector path (see bdrt_nuts_wide.h) ======================================================
+            // Phase P, per chain: a tree leaf that is not the last of its subtree and closes at most two sub-subtrees (7 of 8
+            // non-final leaves; all of this is known from the leaf index before the evaluation) is finished by its own
+            // half-wave in ONE pass over the chain's rows: second half kick, kinetic energy, the merges of levels 0 and 1 with
+            // their U-turn dot products, the new checkpoint, and -- speculatively -- the half kick + drift of the NEXT leapfrog
+            // (momentum in place, theta into the chain's other theta row, so that the evaluated point stays readable for the
+            // proposal copy).  If the verdict is "continue" the two theta rows swap roles.  If not (divergence or U-turn: the
+            // transition ends, nothing of this leaf's theta / momentum is looked at again, and the checkpoint written ahead
+            // sits in a level that had no waiting sibling) the chain joins the others in phase H.
+            const int dir_now = s.dir;
+            const int leaf_now = s.leaf;
+            (void)dir_now;
+            constexpr int MB = NJ % 8 == 0 ? 8 : 9;
+            static_assert(NJ % MB == 0, "chunk size must divide NJ");
+            if (act) {
+                const bool treeph = ph0 == PH_TREE;
+                int nmf = 0;
+                if (treeph) { while ((leaf_now >> nmf) & 1) ++nmf; }
+                const bool lastf = treeph && leaf_now == s.nleaves - 1;
+                if (treeph && !lastf && nmf <= 2) {
+                    const bool m0 = nmf > 0, m1 = nmf > 1;
+                    // unconditional loads (a conditional load splits the batch: the compiler waits for everything in flight at
+                    // the join): rows that are not needed alias the momentum row
+                    const double *PL0 = m0 ? row(V_CKP) : Pm, *RL1 = m1 ? row(V_CKC + 1) : Pm, *PL1 = m1 ? row(V_CKP + 1) : Pm;
+                    double *RHD = row(V_CKC + (nmf > 0 ? nmf : 1)), *FRD = row(V_CKP + nmf);
+                    double *THN = row(V_TH) + (s.thsel ? 0 : TH2OFF);
+                    double kin = 0.0, nonfin = 0.0, um0a = 0.0, um0b = 0.0, um1a = 0.0, um1b = 0.0;
+#pragma unroll 1
+                    for (int mb = 0; mb < NJ; mb += MB) {
+                        double a_[MB], b_[MB], c_[MB], l0_[MB], r1_[MB], l1_[MB], t_[MB];
+#pragma unroll
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            a_[mm] = Pm[j]; b_[mm] = G[j]; c_[mm] = MI[j]; t_[mm] = TH[j];
+                            l0_[mm] = PL0[j]; r1_[mm] = RL1[j]; l1_[mm] = PL1[j];
+                        }
+#pragma unroll
+                        for (int mm = 0; mm < MB; ++mm) {
+                            const int j = l32 + 32 * (mb + mm);
+                            if (j < D) {
+                                const double p = a_[mm] + 0.5 * e * b_[mm];
+                                kin += c_[mm] * p * p;
+                                nonfin += isfinite(b_[mm]) ? 0.0 : 1.0;
+                                const double pn = p + 0.5 * e * b_[mm];
+                                Pm[j] = pn;
+                                THN[j] = t_[mm] + e * c_[mm] * pn;
+                                double rho = p, first = p;
+                                if (m0) {
+                                    rho = l0_[mm] + p;
+                                    um0a += c_[mm] * l0_[mm] * rho;
+                                    um0b += c_[mm] * p * rho;
+                                    first = l0_[mm];
+                                }
+                                if (m1) {
+                                    rho = r1_[mm] + rho;
+                                    um1a += c_[mm] * l1_[mm] * rho;
+                                    um1b += c_[mm] * p * rho;
+                                    first = l1_[mm];
+                                }
+                                if (m0) RHD[j] = rho;
+                                FRD[j] = first;
+                            }
+                        }
+                    }
+                    kin = 0.5 * half_sum(kin);
+                    nonfin = half_sum(nonfin);
+                    um0a = half_sum(um0a); um0b = half_sum(um0b); um1a = half_sum(um1a); um1b = half_sum(um1b);
+                    // verdict (Stan base_nuts::build_tree: divergence test at the leaf, compute_criterion at every merge)
+                    const double lp = lpn[c];
+                    double h = -lp + kin;
+                    if (isnan(h)) h = INFINITY;
+                    const double H0 = s.H0;
+                    const bool divergent = (h - H0) > np.max_deltaH;
+                    const bool ok = (!m0 || (um0a > 0.0 && um0b > 0.0)) && (!m1 || (um1a > 0.0 && um1b > 0.0));
+                    if (!divergent && ok) {
+                        if (l32 == 0) my_leaps += 1;
+                        s.n_leap_iter = s.n_leap_iter + 1;
+                        const double w = H0 - h;
+                        s.sum_metro = s.sum_metro + (w > 0.0 ? 1.0 : exp(w));
+                        const double lsw_new = log_sum_exp2(s.lsw_sub, w);
+                        // uniform sampling inside the new subtree: keep leaf i with probability w_i / W_i
+                        const double u = rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
+                        const bool copyq = leaf_now == 0 || u < exp(w - lsw_new);
+                        s.lsw_sub = lsw_new;
+                        s.leaf = leaf_now + 1;
+                        if (copyq) {
+                            s.lpq = lp;
+                            double *THQ = row(V_THQ), *GQ = row(V_GQ);
+#pragma unroll 1
+                            for (int mb = 0; mb < NJ; mb += MB) {
+                                double a_[MB], b_[MB];
+#pragma unroll
+                                for (int mm = 0; mm < MB; ++mm) { const int j = l32 + 32 * (mb + mm); a_[mm] = TH[j]; b_[mm] = G[j]; }
+#pragma unroll
+                                for (int mm = 0; mm < MB; ++mm) __asm__ volatile("" : "+v"(a_[mm]), "+v"(b_[mm]));
+#pragma unroll
+                                for (int mm = 0; mm < MB; ++mm) {
+                                    const int j = l32 + 32 * (mb + mm);
+                                    if (j < D) { THQ[j] = a_[mm]; GQ[j] = b_[mm]; }
+                                }
+                            }
+                        }
+                        const int sel = s.thsel ^ 1;               // the drifted theta row becomes the live one
+                        s.thsel = sel;
+                        TH = row(V_TH) + (sel ? TH2OFF : 0);
+                        thoff[c] = sel ? TH2OFF : 0;
+                    } else {
+                        hvy[c] = 2;
+                        hvk[2 * c] = kin; hvk[2 * c + 1] = nonfin;
+                    }
+                } else {
+                    hvy[c] = 1;
+                }
+            }
+            BDRT_WAVE_PROF(18);
+            __syncthreads();
+            // Phase H: the chains with more to do, one after the other, each by all 512 threads
+            {
+                WideCtx wx;
+                wx.P = Pp; wx.np = &np; wx.a = &a; wx.V = V; wx.smem = smem; wx.sts = sts; wx.lpn = lpn; wx.hvy = hvy; wx.hvk = hvk;
+                wx.prof = io.prof; wx.D = D; wx.DS = DS; wx.TH2OFF = TH2OFF; wx.c0 = c0; wx.nvalid = nvalid;
+                for (int hc = 0; hc < NC; ++hc) {
+                    const int kind = hvy[hc];
+                    if (kind) wide_coop_tail<(NJ * 32 + WIDE_NT - 1) / WIDE_NT>(wx, hc, kind == 2, my_leaps, tid);
+                }
+            }
+            TH = row(V_TH) + (s.thsel ? TH2OFF : 0);
+            BDRT_WAVE_PROF(20);
+            if (io.prof) {
+                int cls = hvy[c] ? 1 : 0;
+                const int other = __shfl_xor(cls, 32);
+                cls = cls > other ? cls : other;
+                if (lane == 0) {
+                    atomicAdd((unsigned long long *)&io.prof[2 * cls], (unsigned long long)(clock64() - t_post0));
+                    atomicAdd((unsigned long long *)&io.prof[2 * cls + 1], 1ull);
+                }
+            }
+            {
+                // (also separates this round's reads of hvy from the reset at the top of the next round)
+                const int ph = sts[c].phase;
+                any_act = __syncthreads_or(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE);
+            }
+            BDRT_WAVE_PROF(23);
+            BDRT_NUTS_PROF(10);
+        } else {
+        // ================= register path: the chain's p, g, Minv stay in the registers of its half-wave ====================
 
         // ---- C: second half kick, kinetic energy, finiteness of the gradient -----------------------------
         // (p, g, Minv of this chain stay in registers from here to the end of stage D)
         double kin = 0.0, nonfin = 0.0;
         const int dir_now = s.dir;
         const int leaf_now = s.leaf;
-        // (chunked path) U-turn dot products of merge levels 0 and 1, produced by the same pass as the half kick
-        double um0a = 0.0, um0b = 0.0, um1a = 0.0, um1b = 0.0;
-        bool specd = false;                                     // the next leapfrog's kick + drift was done ahead (chunked path)
-        if constexpr (CHUNKED) {
-            if (act) {
-                // A tree leaf knows before its evaluation which sub-subtrees it closes (nmf = trailing one bits of its index),
-                // so the pass that finishes the leapfrog (second half kick, kinetic energy) also runs the two lowest merge
-                // levels and files the resulting sub-subtree: one trip through the rows, all loads of a chunk in flight
-                // together, instead of one dependent trip per stage.  7 of 8 leaves need nothing else before the next
-                // leapfrog.  Element by element the arithmetic is that of the staged form below (levels >= 2 continue from
-                // the V_RHOC row).  Stores made before the U-turn / divergence verdict go to rows nobody reads if the
-                // verdict is negative: level nmf has no waiting sibling (bit nmf of the leaf index is 0).
-                const bool treeph = ph0 == PH_TREE;
-                int nmf = 0;
-                if (treeph) { while ((leaf_now >> nmf) & 1) ++nmf; }
-                const bool lastf = treeph && leaf_now == s.nleaves - 1;
-                const bool m0 = nmf > 0, m1 = nmf > 1;
-                const double *PL0 = row(V_CKP), *RL1 = row(V_CKC + 1), *PL1 = row(V_CKP + 1);
-                // running sum: to the carry row when more levels follow or the subtree closes, else it is the new checkpoint
-                double *RHD = (nmf > 2 || lastf) ? row(V_RHOC) : row(V_CKC + (nmf > 0 ? nmf : 1));
-                double *FRD = row(V_CKP + (nmf > 2 ? 0 : nmf));
-                const bool st_rho = m0, st_first = treeph && !lastf && nmf <= 2;
-                // Such a leaf (not the last of its subtree, nothing left to merge afterwards) continues with the next leapfrog
-                // of the same trajectory unless the transition ends with it -- and then neither its theta nor its momentum is
-                // looked at again.  So the pass also does the half kick + drift of the NEXT leapfrog: momentum in place, theta
-                // into the chain's other theta row (the evaluated point stays readable for the proposal copy); the rows swap
-                // roles once the verdict is in.  Same arithmetic as stage A'.
-                // (a leaf that merges more than two levels keeps its full-step momentum in the V_PF row for the later levels)
-                specd = treeph && !lastf;
-                const bool keep_pf = specd && nmf > 2;
-                double *THN = row(V_TH) + (s.thsel ? 0 : TH2OFF), *PF = row(V_PF);
-#pragma unroll 1
-                for (int mb = 0; mb < NJ; mb += MB) {
-                    double a_[MB], b_[MB], c_[MB], l0_[MB], r1_[MB], l1_[MB], t_[MB];
-#pragma unroll
-                    for (int mm = 0; mm < MB; ++mm) {
-                        const int j = l32 + 32 * (mb + mm);
-                        a_[mm] = Pm[j]; b_[mm] = G[j]; c_[mm] = MI[j];
-                        t_[mm] = 0.0;
-                        if (specd) t_[mm] = TH[j];
-                        l0_[mm] = 0.0; r1_[mm] = 0.0; l1_[mm] = 0.0;
-                        if (m0) l0_[mm] = PL0[j];
-                        if (m1) { r1_[mm] = RL1[j]; l1_[mm] = PL1[j]; }
-                    }
-#pragma unroll
-                    for (int mm = 0; mm < MB; ++mm) {
-                        const int j = l32 + 32 * (mb + mm);
-                        if (j < D) {
-                            const double p = a_[mm] + 0.5 * e * b_[mm];
-                            kin += c_[mm] * p * p;
-                            nonfin += isfinite(b_[mm]) ? 0.0 : 1.0;
-                            if (specd) {
-                                const double pn = p + 0.5 * e * b_[mm];
-                                Pm[j] = pn;
-                                THN[j] = t_[mm] + e * c_[mm] * pn;
-                                if (keep_pf) PF[j] = p;
-                            } else {
-                                Pm[j] = p;                    // from here on the row holds the momentum after the full step
-                            }
-                            double rho = p, first = p;
-                            if (m0) {
-                                rho = l0_[mm] + p;
-                                um0a += c_[mm] * l0_[mm] * rho;
-                                um0b += c_[mm] * p * rho;
-                                first = l0_[mm];
-                            }
-                            if (m1) {
-                                rho = r1_[mm] + rho;
-                                um1a += c_[mm] * l1_[mm] * rho;
-                                um1b += c_[mm] * p * rho;
-                                first = l1_[mm];
-                            }
-                            if (st_rho) RHD[j] = rho;
-                            if (st_first) FRD[j] = first;
-                        }
-                    }
-                }
-            }
-            um0a = half_sum(um0a); um0b = half_sum(um0b); um1a = half_sum(um1a); um1b = half_sum(um1b);
-        } else if (act) {
+        if (act) {
 #pragma unroll
             for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; g_[m] = G[j]; }
 #pragma unroll
@@ -397,27 +463,9 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         BDRT_WAVE_PROF(19);
 
         // ---- D: proposal copy, checkpoints, running rho, U-turn tests, subtree close ----------------------------
-        // (chunked path) the proposal copy of a leaf that is not the last of its subtree rides on the pass of stage A', which
-        // reads theta and the gradient anyway; if that pass does not happen the subtree was discarded and so is its proposal
-        const bool copy_later = CHUNKED && copyq && !last;
-        if ((copyq || cur2s) && !copy_later) {
+        if (copyq || cur2s) {
             double *THQ = row(V_THQ), *GQ = row(V_GQ), *THS = row(V_THS), *GS = row(V_GS);
-            if constexpr (CHUNKED) {
-#pragma unroll 1
-                for (int mb = 0; mb < NJ; mb += MB) {
-                    double a_[MB], b_[MB];
-#pragma unroll
-                    for (int mm = 0; mm < MB; ++mm) { const int j = l32 + 32 * (mb + mm); a_[mm] = TH[j]; b_[mm] = G[j]; }
-#pragma unroll
-                    for (int mm = 0; mm < MB; ++mm) {
-                        const int j = l32 + 32 * (mb + mm);
-                        if (j < D) {
-                            if (copyq) { THQ[j] = a_[mm]; GQ[j] = b_[mm]; }
-                            if (cur2s) { THS[j] = a_[mm]; GS[j] = b_[mm]; }
-                        }
-                    }
-                }
-            } else {
+            {
                 double th_[NJ];
 #pragma unroll
                 for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; th_[m] = TH[j]; }
@@ -440,61 +488,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             // associate exactly like the recursion does.
             double rc_[NA], cpl_[NA];                  // rho / first momentum of the sub-subtree that ends at this leaf
             bool ok = true;
-            if constexpr (CHUNKED) {
-                // levels 0 and 1 were merged by the pass of stage C (which also filed the sub-subtree when nm <= 2); higher
-                // levels continue from the running sum in the V_RHOC row, two levels per trip, and the last trip files the
-                // sub-subtree of 2^nm leaves that ends here as the waiting left sibling of level nm
-                double *RC = row(V_RHOC);
-                const double *PFr = specd ? row(V_PF) : Pm;       // this leaf's momentum after the full step
-                if (nm > 0) ok = ok && (um0a > 0.0) && (um0b > 0.0);
-                if (nm > 1) ok = ok && (um1a > 0.0) && (um1b > 0.0);
-                for (int l = 2; l < nm; l += 2) {
-                    const long long t_lv0 = io.prof ? clock64() : 0;       // (experiment) cost of one level-pair pass
-                    const bool two = l + 1 < nm, fin = l + 2 >= nm;
-                    const double *RLa = row(V_CKC + l), *PLa = row(V_CKP + l);
-                    const double *RLb = row(V_CKC + (two ? l + 1 : l)), *PLb = row(V_CKP + (two ? l + 1 : l));
-                    const bool file = fin && !last;
-                    double *RHD = file ? row(V_CKC + nm) : RC;
-                    double *FRD = row(V_CKP + (file ? nm : 0));
-                    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-#pragma unroll 1
-                    for (int mb = 0; mb < NJ; mb += MB) {
-                        double lr_[MB], lp_[MB], lr2_[MB], lp2_[MB], rr_[MB], pp_[MB], mm_[MB];
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            lr_[mm] = RLa[j]; lp_[mm] = PLa[j]; rr_[mm] = RC[j]; pp_[mm] = PFr[j]; mm_[mm] = MI[j];
-                            lr2_[mm] = 0.0; lp2_[mm] = 0.0;
-                            if (two) { lr2_[mm] = RLb[j]; lp2_[mm] = PLb[j]; }
-                        }
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            if (j < D) {
-                                double rho = lr_[mm] + rr_[mm];
-                                a0 += mm_[mm] * lp_[mm] * rho;
-                                a1 += mm_[mm] * pp_[mm] * rho;
-                                double first = lp_[mm];
-                                if (two) {
-                                    rho = lr2_[mm] + rho;
-                                    b0 += mm_[mm] * lp2_[mm] * rho;
-                                    b1 += mm_[mm] * pp_[mm] * rho;
-                                    first = lp2_[mm];
-                                }
-                                RHD[j] = rho;
-                                if (file) FRD[j] = first;
-                            }
-                        }
-                    }
-                    a0 = half_sum(a0); a1 = half_sum(a1); b0 = half_sum(b0); b1 = half_sum(b1);
-                    ok = ok && (a0 > 0.0) && (a1 > 0.0);
-                    if (two) ok = ok && (b0 > 0.0) && (b1 > 0.0);
-                    if (io.prof && l32 == 0) {
-                        atomicAdd((unsigned long long *)&io.prof[8], (unsigned long long)(clock64() - t_lv0));
-                        atomicAdd((unsigned long long *)&io.prof[9], 1ull);
-                    }
-                }
-            } else {
+            {
 #pragma unroll
                 for (int m = 0; m < NJ; ++m) { rc_[m] = p_[m]; cpl_[m] = p_[m]; }
                 for (int l = 0; l < nm; ++l) {
@@ -542,30 +536,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 double *GE = row(dir_now > 0 ? V_GP : V_GM);
                 const double *PO = row(dir_now > 0 ? V_PM : V_PP);     // momentum at the other end
                 double t0 = 0.0, t1 = 0.0;
-                if constexpr (CHUNKED) {
-                    const double *SUB = nm > 0 ? row(V_RHOC) : Pm;     // rho of the completed subtree
-#pragma unroll 1
-                    for (int mb = 0; mb < NJ; mb += MB) {
-                        double r0_[MB], po_[MB], th_[MB], pp_[MB], gg_[MB], mm_[MB], rs_[MB];
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            r0_[mm] = RHO[j]; po_[mm] = PO[j]; th_[mm] = TH[j]; pp_[mm] = Pm[j]; gg_[mm] = G[j]; mm_[mm] = MI[j];
-                            rs_[mm] = SUB[j];
-                        }
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            if (j < D) {
-                                const double rt = r0_[mm] + rs_[mm];
-                                RHO[j] = rt;
-                                THE[j] = th_[mm]; PE[j] = pp_[mm]; GE[j] = gg_[mm];
-                                t0 += mm_[mm] * po_[mm] * rt;
-                                t1 += mm_[mm] * pp_[mm] * rt;
-                            }
-                        }
-                    }
-                } else {
+                {
                     double rt_[NJ], po_[NJ], th_[NJ];
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) {
@@ -675,49 +646,9 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 
         // ---- A' (common case): the trajectory continues from the point just evaluated: half kick + drift of the NEXT
         //      leapfrog with p, g, Minv still in registers (theta is the only vector read; p is written once per leapfrog)
-        if (specd && act && next == 0 && s.phase == PH_TREE) {
-            // the trajectory continues and its next leapfrog is already in place: the other theta row becomes the live one
-            if (copy_later) {
-                double *THQ = row(V_THQ), *GQ = row(V_GQ);
-#pragma unroll 1
-                for (int mb = 0; mb < NJ; mb += MB) {
-                    double a_[MB], b_[MB];
-#pragma unroll
-                    for (int mm = 0; mm < MB; ++mm) { const int j = l32 + 32 * (mb + mm); a_[mm] = TH[j]; b_[mm] = G[j]; }
-#pragma unroll
-                    for (int mm = 0; mm < MB; ++mm) {
-                        const int j = l32 + 32 * (mb + mm);
-                        if (j < D) { THQ[j] = a_[mm]; GQ[j] = b_[mm]; }
-                    }
-                }
-            }
-            const int sel = s.thsel ^ 1;
-            s.thsel = sel;
-            TH = row(V_TH) + (sel ? TH2OFF : 0);
-            thoff[c] = sel ? TH2OFF : 0;
-        } else if (act && next == 0 && s.phase == PH_TREE) {
+        if (act && next == 0 && s.phase == PH_TREE) {
             const double e1 = s.dir * s.eps;
-            if constexpr (CHUNKED) {
-                double *THQ = row(V_THQ), *GQ = row(V_GQ);
-#pragma unroll 1
-                for (int mb = 0; mb < NJ; mb += MB) {
-                    double pp_[MB], gg_[MB], mm_[MB], th_[MB];
-#pragma unroll
-                    for (int mm = 0; mm < MB; ++mm) {
-                        const int j = l32 + 32 * (mb + mm);
-                        pp_[mm] = Pm[j]; gg_[mm] = G[j]; mm_[mm] = MI[j]; th_[mm] = TH[j];
-                    }
-#pragma unroll
-                    for (int mm = 0; mm < MB; ++mm) {
-                        const int j = l32 + 32 * (mb + mm);
-                        const double p = pp_[mm] + 0.5 * e1 * gg_[mm];
-                        if (j < D) {
-                            if (copy_later) { THQ[j] = th_[mm]; GQ[j] = gg_[mm]; }
-                            Pm[j] = p; TH[j] = th_[mm] + e1 * mm_[mm] * p;
-                        }
-                    }
-                }
-            } else {
+            {
                 double th_[NJ];
 #pragma unroll
                 for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; th_[m] = TH[j]; }
@@ -757,155 +688,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         // ---- E: sample update, metric adaptation, draw output, and the start of the next leapfrog when the trajectory does
         //      not simply continue (new transition, next doubling, step-size search, re-initialisation).  One batch of
         //      loads per case, everything else in registers, including the half kick + drift of the next evaluation.
-        if constexpr (CHUNKED) {
-            if (upds || welf || wend || draw >= 0 || next) {
-                const uint32_t iter = (uint32_t)s.iter, trial = (uint32_t)s.eps_trials, att = (uint32_t)s.init_attempt;
-                double *THS = row(V_THS), *GS = row(V_GS);
-                // pass 1: the current sample (accepted proposal or stored sample): bookkeeping, Welford, metric, draw output
-                if (upds || welf || wend || draw >= 0) {
-                    const double *ST = upds ? row(V_THQ) : THS, *SG = upds ? row(V_GQ) : GS;
-                    double *WM = row(V_WMEAN), *W2 = row(V_WM2);
-                    double *dr = (draw >= 0 && valid) ? a.draws + ((size_t)unit * np.n_draws + draw) * D : nullptr;
-#pragma unroll 1
-                    for (int mb = 0; mb < NJ; mb += MB) {
-                        double ts_[MB], gs_[MB], wm_[MB], w2_[MB];
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            ts_[mm] = ST[j]; gs_[mm] = SG[j];
-                            wm_[mm] = 0.0; w2_[mm] = 0.0;
-                            if (welf || wend) { wm_[mm] = WM[j]; w2_[mm] = W2[j]; }
-                        }
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            if (j < D) {
-                                if (upds) { THS[j] = ts_[mm]; GS[j] = gs_[mm]; }
-                                if (welf || wend) {
-                                    double mean = wm_[mm], m2 = w2_[mm];
-                                    if (welf) {            // Welford (stan::math::welford_var_estimator)
-                                        const double delta = ts_[mm] - mean;
-                                        mean += delta / wn;
-                                        m2 += (ts_[mm] - mean) * delta;
-                                    }
-                                    if (wend) {            // var_adaptation::learn_variance
-                                        const double var = wn > 1.0 ? m2 / (wn - 1.0) : 0.0;
-                                        MI[j] = (wn / (wn + 5.0)) * var + 1e-3 * (5.0 / (wn + 5.0));
-                                        mean = 0.0; m2 = 0.0;
-                                    }
-                                    WM[j] = mean; W2[j] = m2;
-                                }
-                                if (dr) dr[j] = ts_[mm];
-                            }
-                        }
-                    }
-                }
-                if (next == 1 || next == 3) {
-                    // fresh momentum (see the register version below for the scheme); the current sample is in THS / GS now
-                    // unless it was not touched by pass 1, in which case it is there anyway
-                    double *zrow = smem + (size_t)c * (tile_doubles / NC);
-                    const bool have_z = next == 1 && s.z_iter == (int)iter;
-                    const double *ZS = have_z ? row(V_ZN) : zrow;
-                    if (!have_z) {
-#pragma unroll 1
-                        for (int mp = 0; mp < (NJ + 1) / 2; ++mp) {
-                            const int i = l32 + 32 * mp;
-                            if (2 * i < D) {
-                                double z0, z1;
-                                rng_normal_pair(rng, (uint32_t)i, next == 1 ? RNG_MOMENTUM : RNG_EPS_MOMENTUM, next == 1 ? 0u : trial, iter, z0, z1);
-                                zrow[2 * i] = z0; zrow[2 * i + 1] = z1;
-                            }
-                        }
-                        lds_wave_sync();
-                    }
-                    double kin0 = 0.0;
-#pragma unroll 1
-                    for (int mb = 0; mb < NJ; mb += MB) {
-                        double z_[MB], mm_[MB];
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            z_[mm] = j < D ? ZS[j] : 0.0; mm_[mm] = MI[j];
-                        }
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            if (j < D) {
-                                const double p = z_[mm] / sqrt(mm_[mm]);
-                                Pm[j] = p;                    // start momentum; kicked in the last pass
-                                kin0 += mm_[mm] * p * p;
-                            }
-                        }
-                    }
-                    lds_wave_sync();
-                    kin0 = half_sum(kin0);
-                    s.H0 = -s.lps + 0.5 * kin0;
-                    if (next == 1) {
-                        s.lsw = 0.0; s.lsw_sub = -INFINITY; s.depth = 0; s.leaf = 0; s.nleaves = 1;
-                        s.n_leap_iter = 0; s.sum_metro = 0.0;
-                        s.dir = rng_uniform(rng, 0, RNG_DIRECTION, 0, 0, (uint32_t)s.iter) > 0.5 ? 1 : -1;
-                    }
-                    const double e1 = next == 1 ? s.dir * s.eps : s.eps;
-                    const double *ST = upds ? row(V_THQ) : THS, *SG = upds ? row(V_GQ) : GS;
-                    double *rTHM = row(V_THM), *rTHP = row(V_THP), *rPM = row(V_PM), *rPP = row(V_PP), *rGM = row(V_GM),
-                           *rGP = row(V_GP), *rRHO = row(V_RHO);
-#pragma unroll 1
-                    for (int mb = 0; mb < NJ; mb += MB) {
-                        double pp_[MB], ts_[MB], gs_[MB], mm_[MB];
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            pp_[mm] = Pm[j]; ts_[mm] = ST[j]; gs_[mm] = SG[j]; mm_[mm] = MI[j];
-                        }
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            if (j < D) {
-                                const double p = pp_[mm];
-                                if (next == 1) {
-                                    rTHM[j] = ts_[mm]; rTHP[j] = ts_[mm];
-                                    rPM[j] = p; rPP[j] = p;
-                                    rGM[j] = gs_[mm]; rGP[j] = gs_[mm];
-                                    rRHO[j] = p;
-                                }
-                                const double pk = p + 0.5 * e1 * gs_[mm];
-                                Pm[j] = pk;
-                                TH[j] = ts_[mm] + e1 * mm_[mm] * pk;
-                            }
-                        }
-                    }
-                } else if (next == 2) {
-                    const int dir = s.dir;
-                    const double e1 = dir * s.eps;
-                    const bool same = dir == dir_now;
-                    const double *ET = same ? TH : row(dir > 0 ? V_THP : V_THM), *EP = same ? Pm : row(dir > 0 ? V_PP : V_PM);
-                    const double *EG = same ? G : row(dir > 0 ? V_GP : V_GM);
-#pragma unroll 1
-                    for (int mb = 0; mb < NJ; mb += MB) {
-                        double et_[MB], ep_[MB], eg_[MB], mm_[MB];
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            et_[mm] = ET[j]; ep_[mm] = EP[j]; eg_[mm] = EG[j]; mm_[mm] = MI[j];
-                        }
-#pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            if (j < D) {
-                                const double pk = ep_[mm] + 0.5 * e1 * eg_[mm];
-                                Pm[j] = pk;
-                                TH[j] = et_[mm] + e1 * mm_[mm] * pk;
-                            }
-                        }
-                    }
-                } else if (next == 4) {
-                    for (int j = l32; j < D; j += 32) {
-                        TH[j] = np.init_radius * (2.0 * rng_uniform(rng, (uint32_t)j, RNG_INIT, 0, att, 0) - 1.0);
-                        Pm[j] = 0.0;
-                    }
-                }
-            }
-        } else {
+        {
             if (upds || welf || wend || draw >= 0 || next) {
                 const uint32_t iter = (uint32_t)s.iter, trial = (uint32_t)s.eps_trials, att = (uint32_t)s.init_attempt;
                 double *THS = row(V_THS), *GS = row(V_GS);
@@ -1053,17 +836,6 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         BDRT_NUTS_PROF(16);
 
         BDRT_WAVE_PROF(22);
-        if (io.prof && MODE == 4) {
-            // classes: 0 plain leaf, 1 leaf merging > 2 levels, 2 subtree closed (doubling), 3 transition end / other
-            int cls = 0;
-            if (act) { if (endt || (next != 0 && next != 2) || ph0 != PH_TREE) cls = 3; else if (last) cls = 2; else if (nm > 2) cls = 1; }
-            const int other = __shfl_xor(cls, 32);
-            cls = cls > other ? cls : other;
-            if (lane == 0) {
-                atomicAdd((unsigned long long *)&io.prof[2 * cls], (unsigned long long)(clock64() - t_post0));
-                atomicAdd((unsigned long long *)&io.prof[2 * cls + 1], 1ull);
-            }
-        }
         if (io.prof && lane == 0 && next) atomicAdd((unsigned long long *)&io.prof[24], 1ull);
         {
             const int ph = s.phase;
@@ -1071,6 +843,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         }
         BDRT_WAVE_PROF(23);
         BDRT_NUTS_PROF(10);
+        }   // register path
     }
 
     // ---- write the chain states back -----------------------------------------------------------------------------
@@ -1515,7 +1288,7 @@ static size_t nuts_lds_bytes(const DevProblem &P, bool s1)
 {
     const int nj = P.D <= 32 * 11 ? 11 : 16;
     const size_t tile = s1 ? s1_lds_doubles(P) + (size_t)NC * 32 * nj : lds_doubles(P);   // s1: + theta rows
-    return (tile + (size_t)NC) * sizeof(double) + NC * sizeof(ChainState) + 2 * NC * sizeof(int) + 16;
+    return (tile + (size_t)3 * NC) * sizeof(double) + NC * sizeof(ChainState) + 3 * NC * sizeof(int) + 16;
 }
 
 }  // namespace bdrt
@@ -1594,8 +1367,8 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     S.s1_hbm = !S.use_s1 && P.dev.fast_s1 && P.dev.D <= 32 * 16;
     S.hw = P.dev.fast_hw && P.dev.D <= 32 * 27;
     if (S.s1_hbm || S.hw)
-        S.lds_bytes = ((S.hw ? hw_lds_doubles(P.dev) : s1_lds_doubles(P.dev)) + (size_t)NC) * sizeof(double) + NC * sizeof(ChainState) +
-                      2 * NC * sizeof(int) + 16;
+        S.lds_bytes = ((S.hw ? hw_lds_doubles(P.dev) : s1_lds_doubles(P.dev)) + (size_t)3 * NC) * sizeof(double) + NC * sizeof(ChainState) +
+                      3 * NC * sizeof(int) + 16;
     else
         S.lds_bytes = nuts_lds_bytes(P.dev, S.use_s1);
     auto fail = [&](const char *msg) -> bdrt_sampler * { set_error("%s", msg); bdrt_sampler_destroy(s); return nullptr; };

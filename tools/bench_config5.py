@@ -42,13 +42,16 @@ print('config 5 (%s, D=%d, %d units): %.2f M evals/s, %.1f us per round' % (inv.
       (n1 - n0) / (t1 - t0) / 1e6, (t1 - t0) / 600 * 1e6))
 if prof:
     cyc = (C.c_longlong * 32)(); check(lib.bdrt_sampler_phase_profile(h, 0, cyc), 'prof')
-    names = ['tile:scalars', 'tile:x', 'tile:gemmA', 'tile:Zacc', 'tile:likelihood', 'tile:x2', 'tile:gemmL', 'tile:prior',
-             'tile:gemmBwd', 'tile:epilogue', 'nuts:wait', 'nuts:C', 'nuts:S1', 'nuts:D', 'nuts:S2', 'nuts:E', 'nuts:S3']
     nwg = (n_units + 15) // 16
-    for k, nm in enumerate(names): print('PHASE %-18s %9.0f cycles/round' % (nm, cyc[k] / nwg / 600))
-    for k, nm in enumerate(['tile', 'C', 'S1', 'D', "A'", 'E', 'wait']): print('WAVE-AVG %-6s %9.0f' % (nm, cyc[17 + k] / nwg / 600 / 8))
-    for k, nm in enumerate(['plain leaf', 'leaf merging > 2 levels', 'subtree closed', 'transition end / other']):
-        if cyc[2 * k + 1]: print('WAVE-CLASS %-24s %5.1f %% of wave-rounds, %8.0f cycles after the evaluation' % (
-            nm, 100.0 * cyc[2 * k + 1] / (nwg * 600 * 8), cyc[2 * k] / cyc[2 * k + 1]))
-    if prof and cyc[9]: print('LEVEL-PAIR PASS: %.0f cycles each (%d passes)' % (cyc[8] / cyc[9], cyc[9]))
+    wr = nwg * 600 * 8                                            # wave-rounds
+    # wide-vector kernels (D > 512): per-wave averages of the round's stages (bdrt_nuts.hip, bdrt_nuts_wide.h)
+    for nm, k in (('evaluation (MFMA tile)', 17), ("chain's own pass (phase P)", 18), ('cooperative phase (phase H)', 20), ('round barrier wait', 23)):
+        print('WAVE-AVG %-28s %8.0f cycles/round' % (nm, cyc[k] / wr))
+    for k, nm in enumerate(['finished by its own pass', 'with a chain finished cooperatively']):
+        if cyc[2 * k + 1]: print('WAVE-CLASS %-36s %5.1f %% of wave-rounds, %8.0f cycles after the evaluation' % (
+            nm, 100.0 * cyc[2 * k + 1] / wr, cyc[2 * k] / cyc[2 * k + 1]))
+    if cyc[15]:
+        print('COOP %.2f chains per workgroup-round; cycles per chain (thread 0): first trip + reduction %.0f, scalar logic %.0f, '
+              'checkpoint / subtree close %.0f, transition end + continue %.0f, sample / new start %.0f' % (
+              cyc[15] / nwg / 600, *[cyc[k] / cyc[15] for k in (9, 11, 12, 13, 14)]))
 lib.bdrt_sampler_destroy(h)
