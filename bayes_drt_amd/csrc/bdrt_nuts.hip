@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 #include "bdrt_host.h"
 #include "bdrt_nuts_device.h"
@@ -227,66 +228,121 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             (void)dir_now;
             constexpr int MB = NJ % 8 == 0 ? 8 : 9;
             static_assert(NJ % MB == 0, "chunk size must divide NJ");
+            constexpr int NS2 = (32 * NJ + 63) / 64;            // 64-element slices of a row
+            constexpr int LMAX = 4;                             // merge levels a chain's own pass can take
+            typedef double dv2 __attribute__((ext_vector_type(2)));
+            auto ld2 = [](const double *q) -> dv2 { return *reinterpret_cast<const dv2 *>(q); };
+            auto st2 = [](double *q, dv2 v) { *reinterpret_cast<dv2 *>(q) = v; };
             if (act) {
                 const bool treeph = ph0 == PH_TREE;
                 int nmf = 0;
                 if (treeph) { while ((leaf_now >> nmf) & 1) ++nmf; }
                 const bool lastf = treeph && leaf_now == s.nleaves - 1;
-                if (treeph && !lastf && nmf <= 2) {
-                    const bool m0 = nmf > 0, m1 = nmf > 1;
-                    // unconditional loads (a conditional load splits the batch: the compiler waits for everything in flight at
-                    // the join): rows that are not needed alias the momentum row
-                    const double *PL0 = m0 ? row(V_CKP) : Pm, *RL1 = m1 ? row(V_CKC + 1) : Pm, *PL1 = m1 ? row(V_CKP + 1) : Pm;
+                if (treeph && !lastf && nmf <= LMAX) {
+                    // waiting siblings of the levels this leaf closes (level 0: a single leaf, rho = its momentum); a level the
+                    // chain does not close aliases the momentum row: loads stay unconditional (a branch around a load makes the
+                    // compiler wait for everything in flight at the join)
+                    const double *RLp[LMAX], *PLp[LMAX];
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+                        RLp[l] = l < nmf ? row(l == 0 ? V_CKP : V_CKC + l) : Pm;
+                        PLp[l] = l < nmf ? row(V_CKP + l) : Pm;
+                    }
                     double *RHD = row(V_CKC + (nmf > 0 ? nmf : 1)), *FRD = row(V_CKP + nmf);
                     double *THN = row(V_TH) + (s.thsel ? 0 : TH2OFF);
-                    double kin = 0.0, nonfin = 0.0, um0a = 0.0, um0b = 0.0, um1a = 0.0, um1b = 0.0;
-#pragma unroll 1
-                    for (int mb = 0; mb < NJ; mb += MB) {
-                        double a_[MB], b_[MB], c_[MB], l0_[MB], r1_[MB], l1_[MB], t_[MB];
+                    double kin = 0.0, nonfin = 0.0;
+                    double uma[LMAX], umb[LMAX];
 #pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            a_[mm] = Pm[j]; b_[mm] = G[j]; c_[mm] = MI[j]; t_[mm] = TH[j];
-                            l0_[mm] = PL0[j]; r1_[mm] = RL1[j]; l1_[mm] = PL1[j];
-                        }
+                    for (int l = 0; l < LMAX; ++l) { uma[l] = 0.0; umb[l] = 0.0; }
+                    // Straight-line variants of the pass, chosen per WAVE by the number of levels NL either of its two chains
+                    // closes; SB = 64-element slices per batch of loads (fewer when more rows are in flight).
+                    // 16-byte accesses: lane l handles the element pairs 2 l + 64 sl (the pass is bound by the number of
+                    // vector-memory instructions the texture addresser gets through, not by bytes: half as many this way).
+                    auto pass = [&](auto nlc, auto sbc) {
+                        constexpr int NL = decltype(nlc)::value, SBM = decltype(sbc)::value;
+                        auto chunk = [&](int sb, auto sbn) {                 // slices sb .. sb + SB of the rows
+                            constexpr int SB = decltype(sbn)::value;
+                            dv2 a_[SB], b_[SB], c_[SB], t_[SB], lr_[NL > 0 ? NL : 1][SB], lp_[NL > 0 ? NL : 1][SB];
 #pragma unroll
-                        for (int mm = 0; mm < MB; ++mm) {
-                            const int j = l32 + 32 * (mb + mm);
-                            if (j < D) {
-                                const double p = a_[mm] + 0.5 * e * b_[mm];
-                                kin += c_[mm] * p * p;
-                                nonfin += isfinite(b_[mm]) ? 0.0 : 1.0;
-                                const double pn = p + 0.5 * e * b_[mm];
-                                Pm[j] = pn;
-                                THN[j] = t_[mm] + e * c_[mm] * pn;
-                                double rho = p, first = p;
-                                if (m0) {
-                                    rho = l0_[mm] + p;
-                                    um0a += c_[mm] * l0_[mm] * rho;
-                                    um0b += c_[mm] * p * rho;
-                                    first = l0_[mm];
+                            for (int ss = 0; ss < SB; ++ss) {
+                                {
+                                    const int j = 2 * l32 + 64 * (sb + ss);
+                                    const int jc = j < DS ? j : 0;               // (the last slice of a row may be half empty)
+                                    a_[ss] = ld2(Pm + jc); b_[ss] = ld2(G + jc); c_[ss] = ld2(MI + jc); t_[ss] = ld2(TH + jc);
+#pragma unroll
+                                    for (int l = 0; l < NL; ++l) {
+                                        lp_[l][ss] = ld2(PLp[l] + jc);
+                                        if (l > 0) lr_[l][ss] = ld2(RLp[l] + jc);
+                                    }
                                 }
-                                if (m1) {
-                                    rho = r1_[mm] + rho;
-                                    um1a += c_[mm] * l1_[mm] * rho;
-                                    um1b += c_[mm] * p * rho;
-                                    first = l1_[mm];
-                                }
-                                if (m0) RHD[j] = rho;
-                                FRD[j] = first;
                             }
-                        }
+#pragma unroll
+                            for (int ss = 0; ss < SB; ++ss) {
+                                {
+                                    const int j = 2 * l32 + 64 * (sb + ss);
+                                    dv2 pn2, tn2, rho2, first2;
+#pragma unroll
+                                    for (int hh = 0; hh < 2; ++hh) {
+                                        const double p = a_[ss][hh] + 0.5 * e * b_[ss][hh];
+                                        const double pn = p + 0.5 * e * b_[ss][hh];
+                                        const bool live = j + hh < D;
+                                        pn2[hh] = pn;
+                                        tn2[hh] = t_[ss][hh] + e * c_[ss][hh] * pn;
+                                        if (live) {
+                                            kin += c_[ss][hh] * p * p;
+                                            nonfin += isfinite(b_[ss][hh]) ? 0.0 : 1.0;
+                                        }
+                                        double rho = p, first = p;
+#pragma unroll
+                                        for (int l = 0; l < NL; ++l) {
+                                            if (l < nmf) {
+                                                const double plv = lp_[l][ss][hh];
+                                                rho = (l == 0 ? plv : lr_[l][ss][hh]) + rho;
+                                                first = plv;
+                                                if (live) {
+                                                    uma[l] += c_[ss][hh] * plv * rho;
+                                                    umb[l] += c_[ss][hh] * p * rho;
+                                                }
+                                            }
+                                        }
+                                        rho2[hh] = rho; first2[hh] = first;
+                                    }
+                                    if (j < DS) {                                // (rows are padded to DS: whole pairs are stored)
+                                        st2(Pm + j, pn2);
+                                        st2(THN + j, tn2);
+                                        if (NL > 0 && nmf > 0) st2(RHD + j, rho2);
+                                        st2(FRD + j, first2);
+                                    }
+                                }
+                            }
+                        };
+                        // (no bounds tests inside: a branch around loads costs the whole batch its overlap)
+#pragma unroll 1
+                        for (int sb = 0; sb + SBM <= NS2; sb += SBM) chunk(sb, std::integral_constant<int, SBM>{});
+                        if constexpr (NS2 % SBM != 0) chunk(NS2 - NS2 % SBM, std::integral_constant<int, NS2 % SBM>{});
+                    };
+                    {
+                        const bool w1 = __builtin_amdgcn_ballot_w64(nmf > 0) != 0, w2 = __builtin_amdgcn_ballot_w64(nmf > 1) != 0,
+                                   w3 = __builtin_amdgcn_ballot_w64(nmf > 2) != 0;
+                        if (w3) pass(std::integral_constant<int, LMAX>{}, std::integral_constant<int, 2>{});
+                        else if (w2) pass(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+                        else if (w1) pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
+                        else pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
                     }
                     kin = 0.5 * half_sum(kin);
                     nonfin = half_sum(nonfin);
-                    um0a = half_sum(um0a); um0b = half_sum(um0b); um1a = half_sum(um1a); um1b = half_sum(um1b);
+                    bool ok = true;
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+                        const double ua = half_sum(uma[l]), ub = half_sum(umb[l]);
+                        if (l < nmf) ok = ok && (ua > 0.0) && (ub > 0.0);
+                    }
                     // verdict (Stan base_nuts::build_tree: divergence test at the leaf, compute_criterion at every merge)
                     const double lp = lpn[c];
                     double h = -lp + kin;
                     if (isnan(h)) h = INFINITY;
                     const double H0 = s.H0;
                     const bool divergent = (h - H0) > np.max_deltaH;
-                    const bool ok = (!m0 || (um0a > 0.0 && um0b > 0.0)) && (!m1 || (um1a > 0.0 && um1b > 0.0));
                     if (!divergent && ok) {
                         if (l32 == 0) my_leaps += 1;
                         s.n_leap_iter = s.n_leap_iter + 1;

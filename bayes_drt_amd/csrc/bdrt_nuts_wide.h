@@ -42,8 +42,7 @@ __device__ inline void wide_block_sum(double (&v)[N], int n, double *scr, int ti
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         if (i < n) {
-            double t = sum32(v[i]);
-            t += __shfl_xor(t, 32);
+            const double t = solo_wave_sum(v[i]);       // DPP + readlane: no ds_bpermute round trips
             if (lane == 0) scr[wave * N + i] = t;
         }
     }
