@@ -421,6 +421,16 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         double kin = 0.0, nonfin = 0.0;
         const int dir_now = s.dir;
         const int leaf_now = s.leaf;
+        // An odd leaf merges with the single leaf waiting at level 0 (known from the index alone): its momentum is requested
+        // here, so that the HBM round trip runs under the scalar logic of stage S1 instead of after it.  (Even leaves alias the
+        // chain's own momentum row: the load stays unconditional.)
+        constexpr bool PRE0 = NJ <= 11;                  // (16 elements per lane leave no registers for it)
+        double pl0_[PRE0 ? NA : 1];
+        if constexpr (PRE0) {
+            const double *PL0 = (act && ph0 == PH_TREE && (leaf_now & 1)) ? row(V_CKP) : Pm;
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) pl0_[m] = PL0[l32 + 32 * m];
+        }
         if (act) {
 #pragma unroll
             for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; g_[m] = G[j]; }
@@ -550,9 +560,14 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 for (int l = 0; l < nm; ++l) {
                     double lr_[NJ], lp_[NJ];
                     if (l == 0) {
-                        const double *PL = row(V_CKP);
+                        if constexpr (PRE0) {
 #pragma unroll
-                        for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; lp_[m] = PL[j]; lr_[m] = lp_[m]; }
+                            for (int m = 0; m < NJ; ++m) { lp_[m] = pl0_[m]; lr_[m] = lp_[m]; }
+                        } else {
+                            const double *PL = row(V_CKP);
+#pragma unroll
+                            for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; lp_[m] = PL[j]; lr_[m] = lp_[m]; }
+                        }
                     } else {
                         const double *RL = row(V_CKC + l), *PL = row(V_CKP + l);
 #pragma unroll
