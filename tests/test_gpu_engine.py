@@ -231,24 +231,25 @@ def test_batched_optimize_equals_single_fits():
         assert np.array_equal(one[0], both[i]) and r1[0]['iterations'] == rb[i]['iterations']
 
 
-def test_batched_map_of_many_spectra_equals_single_fits():
-    """A batch of 96 spectra through the whole MAP pipeline (lock-step L-BFGS + the device-resident Newton polish, one
-    workgroup per fit): every fit converges, and picks of the batch are bit-identical to the same fits run alone."""
+@pytest.mark.parametrize('n_spectra', [96, 512])
+def test_batched_map_of_many_spectra_equals_single_fits(n_spectra):
+    """A batch of spectra (512 = BASELINE config 4's spectrum count) through the whole MAP pipeline (lock-step L-BFGS + the
+    device-resident Newton polish, one workgroup per fit): every fit converges, and picks of the batch are bit-identical to
+    the same fits run alone."""
     import bench
     from bayes_drt_amd.model import Problem
     from bayes_drt_amd.engine import optimize_batch
     blk, Z, f, kw, d = _bench_problem('optimize', 'K81')
-    fs, Zs = bench.synth_spectra(96)
+    fs, Zs = bench.synth_spectra(n_spectra)
     order = np.argsort(fs)[::-1]
     assert np.allclose(fs[order], f)                       # same 81-point grid as the fixture's matrices
     prob = Problem([blk], Zs, f, **kw)
-    th0 = np.random.RandomState(9).uniform(-2, 2, (96, prob.D))
-    allx, rep = optimize_batch(prob, th0, spec=np.arange(96), max_iter=400, lbfgs_before_newton=400)
+    th0 = np.random.RandomState(9).uniform(-2, 2, (n_spectra, prob.D))
+    allx, rep = optimize_batch(prob, th0, spec=np.arange(n_spectra), max_iter=400, lbfgs_before_newton=400)
     assert all(r['return_code'] == 0 and r['grad_inf'] < 1e-8 for r in rep), [r['return_code'] for r in rep]
-    for i in (0, 41, 95):
+    for i in (0, n_spectra // 2 - 7, n_spectra - 1):
         one, r1 = optimize_batch(prob, th0[i][None], spec=[i], max_iter=400, lbfgs_before_newton=400)
         assert np.array_equal(one[0], allx[i]) and r1[0]['newton_iterations'] == rep[i]['newton_iterations']
-
 
 
 @pytest.mark.parametrize('family', ['series_outliers_K161', 'series_parallel_2block', 'series_K192_Nf96', 'series_K161_Nf107'])
