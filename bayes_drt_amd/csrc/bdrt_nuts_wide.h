@@ -3,7 +3,7 @@
 //
 // In these kernels a chain's vectors do not fit in the registers of its half-wave next to the evaluator, so its rows are
 // streamed from HBM in chunks of MB elements per lane: one dependent memory trip per chunk and per stage, ~5.7 k cycles each
-// even on an idle chip (measured: profiles/r02/config5_wave_classes.txt).  A plain tree leaf needs one such pass (nuts_kernel,
+// even on an idle chip (measured: profiles/r02/config5.txt).  A plain tree leaf needs one such pass (nuts_kernel,
 // stage C of the wide path).  Everything else -- a leaf that closes sub-subtrees above level 1, the last leaf of a subtree,
 // the end of a transition, the step-size search -- used to cost the chain's wave 40-130 k cycles more while the other seven
 // waves of the workgroup waited at the round barrier.
