@@ -284,12 +284,15 @@ def main():
         small = dict(kw, Z=np.atleast_2d(Zall)[:8 * world]) if rank == 0 else None
         dist.barrier()
         t_rt = time.perf_counter()
-        res = par.sample_sharded(small, 8 * world, args.chains, 6, 4, seed=1234, control={'max_treedepth': 5},
-                                 gather='summary')
-        torch.cuda.synchronize()
-        dist.barrier()
-        roundtrip = {'ms': (time.perf_counter() - t_rt) * 1e3, 'spectra': 8 * world, 'chains': args.chains,
-                     'warmup': 6, 'draws': 4, 'gather': 'summary', 'finite': bool(np.all(np.isfinite(res['mean'])))}
+        try:
+            res = par.sample_sharded(small, 8 * world, args.chains, 6, 4, seed=1234, control={'max_treedepth': 5},
+                                     gather='summary')
+            torch.cuda.synchronize()
+            dist.barrier()
+            roundtrip = {'ms': (time.perf_counter() - t_rt) * 1e3, 'spectra': 8 * world, 'chains': args.chains,
+                         'warmup': 6, 'draws': 4, 'gather': 'summary', 'finite': bool(np.all(np.isfinite(res['mean'])))}
+        except Exception as exc:                  # reported in the line; the steady-state rate above stands on its own
+            roundtrip = {'error': '%s: %s' % (type(exc).__name__, exc)}
 
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
