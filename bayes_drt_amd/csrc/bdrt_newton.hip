@@ -23,9 +23,11 @@
 namespace bdrt {
 
 constexpr int NW_NT = 512;
+constexpr int NW_TRY = 4;           // step lengths tried per factorisation: s, s/2, s/4, s/8 -- one batched evaluation
 
 struct NewtonState {            // one per fit, in device memory
     double lp, lam, pred, lp_trial, grad_inf;
+    double gs, ss;              // g.s and s.s of the current step: predicted increase of t s is  t g.s + t^2/2 (lam s.s - g.s)
     int iters, rc, done, need_hess, n_evals, max_iter, hbad, pad1;      // hbad: non-finite Hessian entry seen by the build kernel
     double tol;
 };
@@ -397,67 +399,88 @@ __global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const
         double p = 0.0, q = 0.0;
         for (int w = 0; w < NW_NT / 64; ++w) { p += red[w]; q += red[8 + w]; }
         S.pred = 0.5 * (p + lam * q); S.lam = lam;
+        S.gs = p; S.ss = q;
     }
     pf.mark(NP_PRED);
     if (pf.p) { pf.p[NP_WALL] += wall_clock64() - wall0; pf.p[NP_CALLS] += 1; }
 }
 
-// consume the trial evaluation (lp_t, grad_t in gt): accept / reject (bdrt_newton.h NewtonFit::consume, NEED_TRIAL)
-__global__ __launch_bounds__(256) void newton_accept_kernel(NewtonBufs b, const int *active, int n_active, const double *lp_t)
+// consume the trial evaluations (lp_t, gradients gt; rows NW_TRY a + t): the longest of the step lengths s, s/2, s/4, s/8 that
+// passes the sufficient-increase test is accepted (bdrt_newton.h NewtonFit::consume, NEED_TRIAL, is the t = 0 case; the
+// shorter steps along the same Levenberg-Marquardt direction cost one batched evaluation instead of a re-factorisation
+// with more damping -- 40 % of the solves at K = 161 were such re-factorisations)
+__global__ __launch_bounds__(256) void newton_accept_kernel(NewtonBufs b, const int *active, int n_active, const double *lp_t,
+                                                            const double *trial)
 {
     const int a = blockIdx.x, tid = threadIdx.x;
     const int f = active[a], D = b.D;
     NewtonState &S = b.st[f];
     if (S.done) return;
     __shared__ double red[256];
-    __shared__ int s_acc;
+    __shared__ int s_acc, s_t;
+    __shared__ double s_ginf;
     double *x = b.x + (size_t)f * D, *g = b.g + (size_t)f * D;
-    const double *xt = b.xt + (size_t)f * D, *gt = b.gt + (size_t)a * D;
-    const double lpn = lp_t[a];
-    int fin = isfinite(lpn) ? 1 : 0;
-    double gi = 0.0;
-    for (int j = tid; j < D; j += 256) { const double v = gt[j]; if (!isfinite(v)) fin = 0; gi = fmax(gi, fabs(v)); }
-    fin = __syncthreads_and(fin);
-    red[tid] = gi;
+    if (tid == 0) { s_acc = 0; s_t = 0; S.n_evals += NW_TRY; }
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] = fmax(red[tid], red[tid + w]); __syncthreads(); }
-    const double ginf = red[0];
-    if (tid == 0) {
-        const double lp = S.lp, pred = S.pred;
-        s_acc = fin && (lpn - lp >= 1e-4 * pred) && (lpn >= lp - 1e-12 * fabs(lp));
-        // close to the optimum the predicted increase drops below the resolution of lp itself (a few ulp of |lp|): the
-        // sufficient-increase test then compares rounding noise.  There the step is judged by what it is meant to do --
-        // reduce the gradient -- as long as lp does not visibly decrease.
-        const double noise = 64.0 * 2.220446049250313e-16 * fmax(1.0, fabs(lp));
-        if (fin && !s_acc && pred < noise && lpn >= lp - noise && ginf < S.grad_inf) s_acc = 1;
-        S.n_evals += 1;
-        S.lp_trial = lpn;
-    }
-    __syncthreads();
-    if (s_acc) {
-        for (int j = tid; j < D; j += 256) { x[j] = xt[j]; g[j] = gt[j]; }
+    for (int t = 0; t < NW_TRY; ++t) {
+        const double *gt = b.gt + ((size_t)a * NW_TRY + t) * D;
+        const double lpn = lp_t[a * NW_TRY + t];
+        int fin = isfinite(lpn) ? 1 : 0;
+        double gi = 0.0;
+        for (int j = tid; j < D; j += 256) { const double v = gt[j]; if (!isfinite(v)) fin = 0; gi = fmax(gi, fabs(v)); }
+        fin = __syncthreads_and(fin);
+        red[tid] = gi;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] = fmax(red[tid], red[tid + w]); __syncthreads(); }
+        const double ginf = red[0];
         if (tid == 0) {
-            const double pred = S.pred, rho = pred > 0.0 ? (lpn - S.lp) / pred : 0.0;
-            S.lp = lpn;
-            if (rho > 0.75) S.lam = fmax(S.lam / 5.0, 1e-12);
-            else if (rho < 0.25) S.lam *= 2.0;
-            S.iters += 1;
-            S.grad_inf = ginf;
-            if (ginf < S.tol) { S.rc = 0; S.done = 1; }
-            else if (S.iters >= S.max_iter) { S.rc = 1; S.done = 1; }
-            else S.need_hess = 1;
+            const double lp = S.lp, sc = ldexp(1.0, -t);
+            // predicted increase of the scaled step: with (-H + lam I) s = g,  t g.s + t^2/2 s^T H s = t g.s + t^2/2 (lam s.s - g.s)
+            const double pred = t == 0 ? S.pred : sc * S.gs + 0.5 * sc * sc * (S.lam * S.ss - S.gs);
+            int acc = fin && (lpn - lp >= 1e-4 * pred) && (lpn >= lp - 1e-12 * fabs(lp));
+            // close to the optimum the predicted increase drops below the resolution of lp itself (a few ulp of |lp|): the
+            // sufficient-increase test then compares rounding noise.  There the step is judged by what it is meant to do --
+            // reduce the gradient -- as long as lp does not visibly decrease.
+            const double noise = 64.0 * 2.220446049250313e-16 * fmax(1.0, fabs(lp));
+            if (fin && !acc && pred < noise && lpn >= lp - noise && ginf < S.grad_inf) acc = 1;
+            if (t == 0) S.lp_trial = lpn;
+            if (acc) {
+                const double rho = pred > 0.0 ? (lpn - lp) / pred : 0.0;
+                S.lp = lpn;
+                if (t == 0) {
+                    if (rho > 0.75) S.lam = fmax(S.lam / 5.0, 1e-12);
+                    else if (rho < 0.25) S.lam *= 2.0;
+                } else {
+                    S.lam *= ldexp(1.0, t);                       // the full step was too long: more damping next time
+                }
+                S.iters += 1;
+                S.grad_inf = ginf;
+                if (ginf < S.tol) { S.rc = 0; S.done = 1; }
+                else if (S.iters >= S.max_iter) { S.rc = 1; S.done = 1; }
+                else S.need_hess = 1;
+                s_acc = 1; s_t = t; s_ginf = ginf;
+            }
         }
+        __syncthreads();
+        if (s_acc) break;
+    }
+    if (s_acc) {
+        const double *xs = trial + ((size_t)a * NW_TRY + s_t) * D, *gt = b.gt + ((size_t)a * NW_TRY + s_t) * D;
+        for (int j = tid; j < D; j += 256) { x[j] = xs[j]; g[j] = gt[j]; }
     } else if (tid == 0) {
-        S.lam *= 4.0;                                             // same Hessian, more damping
+        S.lam *= 16.0;                                            // none of the lengths: same Hessian, much more damping
     }
 }
 
-// dense batch of the active fits' trial points: row a <- xt of fit active[a]
+// dense batch of the active fits' trial points: rows NW_TRY a + t <- x + 2^-t s of fit active[a]
 __global__ void newton_gather_kernel(NewtonBufs b, const int *active, int n_active, double *dst)
 {
-    const int a = blockIdx.x;
-    const double *src = b.xt + (size_t)active[a] * b.D;
-    for (int k = threadIdx.x; k < b.D; k += blockDim.x) dst[(size_t)a * b.D + k] = src[k];
+    const int a = blockIdx.x, t = blockIdx.y;
+    const int f = active[a];
+    const double *x = b.x + (size_t)f * b.D, *sv = b.s + (size_t)f * b.D, *xt = b.xt + (size_t)f * b.D;
+    const double sc = ldexp(1.0, -t);
+    double *d = dst + ((size_t)a * NW_TRY + t) * b.D;
+    for (int k = threadIdx.x; k < b.D; k += blockDim.x) d[k] = t == 0 ? xt[k] : x[k] + sc * sv[k];
 }
 
 // first evaluation at the start point: lp, g, convergence test
@@ -500,7 +523,7 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
     b.D = D; b.Dp = Dp;
     const size_t nD = (size_t)n_fits * D * sizeof(double);
     NW_HIP(alloc(nD, (void **)&b.x)); NW_HIP(alloc(nD, (void **)&b.g)); NW_HIP(alloc(nD, (void **)&b.s));
-    NW_HIP(alloc(nD, (void **)&b.xt)); NW_HIP(alloc(nD, (void **)&b.gt)); NW_HIP(alloc(nD, (void **)&b.hstep));
+    NW_HIP(alloc(nD, (void **)&b.xt)); NW_HIP(alloc(nD * NW_TRY, (void **)&b.gt)); NW_HIP(alloc(nD, (void **)&b.hstep));
     NW_HIP(alloc((size_t)n_fits * Dp * Dp * sizeof(double), (void **)&b.H));
     NW_HIP(alloc((size_t)n_fits * Dp * Dp * sizeof(double), (void **)&b.M));
     NW_HIP(alloc((size_t)n_fits * 2 * D * D * sizeof(double), (void **)&b.probes));
@@ -516,16 +539,16 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
     int *d_active = nullptr, *d_spec1 = nullptr, *d_specp = nullptr;
     double *d_lpt = nullptr;
     NW_HIP(alloc((size_t)n_fits * sizeof(int), (void **)&d_active));
-    NW_HIP(alloc((size_t)n_fits * sizeof(int), (void **)&d_spec1));
+    NW_HIP(alloc((size_t)n_fits * NW_TRY * sizeof(int), (void **)&d_spec1));
     NW_HIP(alloc((size_t)n_fits * 2 * D * sizeof(int), (void **)&d_specp));
-    NW_HIP(alloc((size_t)n_fits * sizeof(double), (void **)&d_lpt));
+    NW_HIP(alloc((size_t)n_fits * NW_TRY * sizeof(double), (void **)&d_lpt));
     std::vector<NewtonState> hst((size_t)n_fits);
     for (auto &s : hst) { memset(&s, 0, sizeof(s)); s.lam = 1e-3; s.max_iter = max_iter; s.tol = tol; s.rc = 1; s.done = max_iter > 0 ? 0 : 1; }
     NW_HIP(hipMemcpy(b.st, hst.data(), hst.size() * sizeof(NewtonState), hipMemcpyHostToDevice));
     NW_HIP(hipMemcpy(b.x, x0, nD, hipMemcpyHostToDevice));
     hipStream_t st = P.stream;
     // evaluation at the start points
-    std::vector<int> hspec((size_t)n_fits), hact((size_t)n_fits), hspecp, sp1((size_t)n_fits);
+    std::vector<int> hspec((size_t)n_fits), hact((size_t)n_fits), hspecp, sp1((size_t)n_fits * NW_TRY);
     for (int i = 0; i < n_fits; ++i) hspec[i] = spec ? spec[i] : 0;
     NW_HIP(hipMemcpyAsync(d_spec1, hspec.data(), (size_t)n_fits * sizeof(int), hipMemcpyHostToDevice, st));
     int rc;
@@ -555,11 +578,13 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
         hipLaunchKernelGGL(newton_solve_kernel, dim3(n_active), dim3(NW_NT), lds_solve, st, b, (const int *)d_active, n_active);
         // trial points of the active fits, gathered into contiguous rows of gt / lp_t: evaluate xt of fit hact[a] into slot a
         // (xt rows are per fit; the evaluator wants a dense batch: copy the active rows)
-        hipLaunchKernelGGL(newton_gather_kernel, dim3(n_active), dim3(128), 0, st, b, (const int *)d_active, n_active, b.probes);
-        for (int a = 0; a < n_active; ++a) sp1[a] = hspec[hact[a]];      // (host buffers are reused only after the sync above)
-        NW_HIP(hipMemcpyAsync(d_spec1, sp1.data(), (size_t)n_active * sizeof(int), hipMemcpyHostToDevice, st));
-        if ((rc = launch_logp_grad(&P, b.probes, d_spec1, n_active, 0, d_lpt, b.gt, nullptr, nullptr, nullptr, st))) { cleanup(); return rc; }
-        hipLaunchKernelGGL(newton_accept_kernel, dim3(n_active), dim3(256), 0, st, b, (const int *)d_active, n_active, (const double *)d_lpt);
+        hipLaunchKernelGGL(newton_gather_kernel, dim3(n_active, NW_TRY), dim3(128), 0, st, b, (const int *)d_active, n_active, b.probes);
+        for (int a = 0; a < n_active; ++a)
+            for (int t = 0; t < NW_TRY; ++t) sp1[(size_t)a * NW_TRY + t] = hspec[hact[a]];      // (host buffers are reused only after the sync above)
+        NW_HIP(hipMemcpyAsync(d_spec1, sp1.data(), (size_t)n_active * NW_TRY * sizeof(int), hipMemcpyHostToDevice, st));
+        if ((rc = launch_logp_grad(&P, b.probes, d_spec1, n_active * NW_TRY, 0, d_lpt, b.gt, nullptr, nullptr, nullptr, st))) { cleanup(); return rc; }
+        hipLaunchKernelGGL(newton_accept_kernel, dim3(n_active), dim3(256), 0, st, b, (const int *)d_active, n_active, (const double *)d_lpt,
+                           (const double *)b.probes);
         NW_HIP(hipGetLastError());
     }
     NW_HIP(hipMemcpyAsync(hst.data(), b.st, hst.size() * sizeof(NewtonState), hipMemcpyDeviceToHost, st));
