@@ -67,9 +67,11 @@ __device__ __forceinline__ double bcast_lane(double v, int l)        // value of
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-// In-place blocked Cholesky of the lower triangle of the Dp x Dp row-major matrix M (Dp a multiple of 16).
+// In-place blocked Cholesky of the lower triangle of the Dp x Dp row-major matrix M (Dp a multiple of 16).  The forward
+// substitution L y = v of a right-hand side v [Dp] (LDS) rides along: block J of y from the freshly factored diagonal
+// block while it is in registers, the rows below from the panel while it is in LDS -- v holds y on return.
 // lds: 16*17 (diagonal block) + 16 (reciprocal pivots) + Dp*17 (panel) + 1 (flag) doubles.  Returns false when not positive definite.
-__device__ inline bool chol_blocked(double *M, int Dp, double *lds, NewtonProf &pf)
+__device__ inline bool chol_blocked(double *M, int Dp, double *lds, NewtonProf &pf, double *v)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *Dg = lds, *rinv = Dg + 16 * 17, *Pn = rinv + 16;
@@ -107,10 +109,23 @@ __device__ inline bool chol_blocked(double *M, int Dp, double *lds, NewtonProf &
                 }
             }
             if (!okb) { if (lane == 0) *bad = 1; }
-            else if (lane < 16) {
+            else {
+                // y_J = L11^-1 v_J: lane i holds row i of L11; y_k is broadcast as soon as it is known
+                const double rd = 1.0 / row[i];
+                double t = v[j0 + i];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) Dg[i * 17 + k] = row[k];
-                rinv[i] = 1.0 / row[i];
+                for (int k = 0; k < 16; ++k) {
+                    const double c = t * rd;
+                    const double yk = bcast_lane(c, k);
+                    if (i > k) t -= row[k] * yk;
+                    if (i == k) t = yk * row[i];                          // keeps t / L[i][i] = y_i for the store below
+                }
+                if (lane < 16) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) Dg[i * 17 + k] = row[k];
+                    rinv[i] = rd;
+                    v[j0 + i] = t * rd;
+                }
             }
         }
         __syncthreads();
@@ -148,6 +163,10 @@ __device__ inline bool chol_blocked(double *M, int Dp, double *lds, NewtonProf &
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) row[k] = xk[k];
+            double dotv = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dotv += xk[k] * v[j0 + k];
+            v[j0 + 16 + r] -= dotv;
         }
         __syncthreads();
         for (int e = tid; e < m * 16; e += NW_NT) M[(size_t)(j0 + 16 + (e >> 4)) * Dp + j0 + (e & 15)] = Pn[(size_t)(e >> 4) * 17 + (e & 15)];
@@ -201,54 +220,14 @@ __device__ __forceinline__ double sum16(double t)                  // sum over e
     return t;
 }
 
-// v <- (L L^T)^-1 v, L = lower triangle of the row-major Dp x Dp matrix M (Dp a multiple of 16, identity on the padding);
-// v [Dp] in LDS; Dg: 16*17 doubles of LDS scratch.  Blocked substitution: the 16 x 16 diagonal block is solved by one
-// thread from LDS, the rest of the right-hand side is updated by the whole workgroup with coalesced row reads.
+// v <- L^-T v (the forward substitution was done by chol_blocked), L = lower triangle of the row-major Dp x Dp matrix M
+// (Dp a multiple of 16, identity on the padding); v [Dp] in LDS; Dg: 16*17 doubles of LDS scratch.  Blocked substitution:
+// the 16 x 16 diagonal block by one wave with the block's columns in registers, the rest of the right-hand side is updated
+// by the whole workgroup with coalesced row reads.
 __device__ inline void chol_blocked_solve(const double *M, int Dp, double *v, double *Dg)
 {
     const int tid = threadIdx.x;
     const int nblk = Dp / 16;
-    for (int J = 0; J < nblk; ++J) {                                  // forward: L y = v
-        const int j0 = 16 * J;
-        if (tid < 256) Dg[(tid >> 4) * 17 + (tid & 15)] = M[(size_t)(j0 + (tid >> 4)) * Dp + j0 + (tid & 15)];
-        __syncthreads();
-        if (tid < 64) {
-            // lane j holds row j of the block; y_k is broadcast as soon as it is known (16 steps of one multiply-add)
-            const int j = tid & 15;
-            double Lr[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) Lr[k] = Dg[j * 17 + k];
-            const double rd = 1.0 / Lr[j];
-            double t = v[j0 + j];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const double c = t * rd;
-                const double yk = bcast_lane(c, k);
-                if (j > k) t -= Lr[k] * yk;
-                if (j == k) t = yk * Lr[j];                           // keeps t / L[j][j] = y_j for the store below
-            }
-            if (tid < 16) v[j0 + j] = t * rd;
-        }
-        __syncthreads();
-        // rows below: v_i -= L[i][j0 .. j0+16) . y  -- 16 lanes per row
-        const int lane16 = tid & 15;
-        const double yk = v[j0 + lane16];
-        {
-            constexpr int NR = NW_NT / 16;
-            int i = j0 + 16 + (tid >> 4);
-            for (; i + 3 * NR < Dp; i += 4 * NR) {
-                const double *mp = M + (size_t)i * Dp + j0 + lane16;
-                double t0 = mp[0] * yk, t1 = mp[(size_t)NR * Dp] * yk, t2 = mp[(size_t)2 * NR * Dp] * yk, t3 = mp[(size_t)3 * NR * Dp] * yk;
-                t0 = sum16(t0); t1 = sum16(t1); t2 = sum16(t2); t3 = sum16(t3);
-                if (lane16 == 0) { v[i] -= t0; v[i + NR] -= t1; v[i + 2 * NR] -= t2; v[i + 3 * NR] -= t3; }
-            }
-            for (; i < Dp; i += NR) {
-                const double t = sum16(M[(size_t)i * Dp + j0 + lane16] * yk);
-                if (lane16 == 0) v[i] -= t;
-            }
-        }
-        __syncthreads();
-    }
     for (int J = nblk - 1; J >= 0; --J) {                             // backward: L^T x = y
         const int j0 = 16 * J;
         if (tid < 256) Dg[(tid >> 4) * 17 + (tid & 15)] = M[(size_t)(j0 + (tid >> 4)) * Dp + j0 + (tid & 15)];
@@ -337,7 +316,7 @@ __global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const
     NewtonState &S = b.st[f];
     if (S.done) return;
     double *H = b.H + (size_t)f * Dp * Dp, *M = b.M + (size_t)f * Dp * Dp;
-    const double *x = b.x + (size_t)f * D, *g = b.g + (size_t)f * D, *hs = b.hstep + (size_t)f * D;
+    const double *x = b.x + (size_t)f * D, *g = b.g + (size_t)f * D;
     double *s = b.s + (size_t)f * D, *xt = b.xt + (size_t)f * D;
     double *v = sh;                               // [Dp] right-hand side / solution
     double *red = v + Dp;                         // 64 doubles
@@ -366,9 +345,9 @@ __global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const
         }
         rebuilt = false;
         pf.mark(NP_BUILD);
-        if (chol_blocked(M, Dp, cl, pf)) {
-            for (int i = tid; i < Dp; i += NW_NT) v[i] = i < D ? g[i] : 0.0;
-            __syncthreads();
+        for (int i = tid; i < Dp; i += NW_NT) v[i] = i < D ? g[i] : 0.0;
+        __syncthreads();
+        if (chol_blocked(M, Dp, cl, pf, v)) {
             chol_blocked_solve(M, Dp, v, cl);
             pf.mark(NP_SOLVE);
             int fin = 1;
@@ -393,11 +372,11 @@ __global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const
     const int lane = tid & 63, wave = tid >> 6;
     gs = sum32(gs); gs += __shfl_xor(gs, 32);
     ss = sum32(ss); ss += __shfl_xor(ss, 32);
-    if (lane == 0) { red[wave] = gs; red[8 + wave] = ss; }
+    if (lane == 0) { red[wave] = gs; red[NW_NT / 64 + wave] = ss; }
     __syncthreads();
     if (tid == 0) {
         double p = 0.0, q = 0.0;
-        for (int w = 0; w < NW_NT / 64; ++w) { p += red[w]; q += red[8 + w]; }
+        for (int w = 0; w < NW_NT / 64; ++w) { p += red[w]; q += red[NW_NT / 64 + w]; }
         S.pred = 0.5 * (p + lam * q); S.lam = lam;
         S.gs = p; S.ss = q;
     }
