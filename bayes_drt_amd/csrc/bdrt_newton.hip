@@ -55,6 +55,7 @@ __global__ void newton_probe_kernel(NewtonBufs b, const int *active, int n_activ
     const int a = blockIdx.y, row = blockIdx.x;          // row in [0, 2 D)
     if (a >= n_active) return;
     const int f = active[a], D = b.D, j = row >> 1;
+    if (b.st[f].done || !b.st[f].need_hess) return;      // (rejected trial: same Hessian; the probe rows keep whatever they hold)
     const double *x = b.x + (size_t)f * D;
     double *p = b.probes + ((size_t)a * 2 * D + row) * D;
     const double h = 1e-5 * fmax(1.0, fabs(x[j]));
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void newton_build_kernel(NewtonBufs b, const i
     const double lam = S.lam;
     const int r0 = 16 * blockIdx.x;
     if (S.need_hess) {
-        // (a < n_hess by construction: the fits that need a Hessian are listed first and own probe slot a)
+        // (probe slot a = position in the active list)
         const double *pg = b.pgrad + (size_t)a * 2 * D * D, *hs = b.hstep + (size_t)f * D;
         int bad = 0;
         for (int i = r0 + wv; i < r0 + 16; i += 4) {
@@ -535,35 +536,38 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
     hipLaunchKernelGGL(newton_init_kernel, dim3(n_fits), dim3(256), 0, st, b, n_fits, (const double *)d_lpt, (const double *)b.gt);
     const size_t lds_solve = ((size_t)Dp + 64 + 16 * 17 + 16 + (size_t)Dp * 17 + 2) * sizeof(double);
     NW_HIP(hipFuncSetAttribute((const void *)newton_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
+    // The sequence of launches of one Levenberg-Marquardt round does not depend on what the round decides (kernels skip the
+    // fits that are done; a fit that keeps its Hessian after a rejected trial skips the probe writes and ignores the probe
+    // gradients), so several rounds are enqueued back to back and the host reads the status records once per group.
+    const char *rp_env = getenv("BDRT_NEWTON_ROUNDS");
+    const int rounds_per_sync = std::max(1, rp_env ? atoi(rp_env) : 4);
     const long long max_rounds = (long long)max_iter * 40 + 100;
-    for (long long round = 0; round < max_rounds; ++round) {
+    for (long long round = 0; round < max_rounds; round += rounds_per_sync) {
         NW_HIP(hipMemcpyAsync(hst.data(), b.st, hst.size() * sizeof(NewtonState), hipMemcpyDeviceToHost, st));
         NW_HIP(hipStreamSynchronize(st));
-        int n_active = 0, n_hess = 0;
-        // fits that need a fresh Hessian first, so that their probe rows are contiguous [0, n_hess)
-        for (int i = 0; i < n_fits; ++i) if (!hst[i].done && hst[i].need_hess) hact[n_active++] = i;
-        n_hess = n_active;
-        for (int i = 0; i < n_fits; ++i) if (!hst[i].done && !hst[i].need_hess) hact[n_active++] = i;
+        int n_active = 0;
+        for (int i = 0; i < n_fits; ++i) if (!hst[i].done) hact[n_active++] = i;
         if (n_active == 0) break;
         NW_HIP(hipMemcpyAsync(d_active, hact.data(), (size_t)n_active * sizeof(int), hipMemcpyHostToDevice, st));
-        if (n_hess > 0) {
-            hspecp.resize((size_t)n_hess * 2 * D);
-            for (int a = 0; a < n_hess; ++a) std::fill(hspecp.begin() + (size_t)a * 2 * D, hspecp.begin() + (size_t)(a + 1) * 2 * D, hspec[hact[a]]);
-            NW_HIP(hipMemcpyAsync(d_specp, hspecp.data(), hspecp.size() * sizeof(int), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(newton_probe_kernel, dim3(2 * D, n_hess), dim3(128), 0, st, b, (const int *)d_active, n_hess);
-            if ((rc = launch_logp_grad(&P, b.probes, d_specp, n_hess * 2 * D, 0, b.plp, b.pgrad, nullptr, nullptr, nullptr, st))) { cleanup(); return rc; }
+        hspecp.resize((size_t)n_active * 2 * D);
+        for (int a = 0; a < n_active; ++a) {
+            std::fill(hspecp.begin() + (size_t)a * 2 * D, hspecp.begin() + (size_t)(a + 1) * 2 * D, hspec[hact[a]]);
+            for (int t = 0; t < NW_TRY; ++t) sp1[(size_t)a * NW_TRY + t] = hspec[hact[a]];
         }
-        hipLaunchKernelGGL(newton_build_kernel, dim3(Dp / 16, n_active), dim3(256), 0, st, b, (const int *)d_active, n_active);
-        hipLaunchKernelGGL(newton_solve_kernel, dim3(n_active), dim3(NW_NT), lds_solve, st, b, (const int *)d_active, n_active);
-        // trial points of the active fits, gathered into contiguous rows of gt / lp_t: evaluate xt of fit hact[a] into slot a
-        // (xt rows are per fit; the evaluator wants a dense batch: copy the active rows)
-        hipLaunchKernelGGL(newton_gather_kernel, dim3(n_active, NW_TRY), dim3(128), 0, st, b, (const int *)d_active, n_active, b.probes);
-        for (int a = 0; a < n_active; ++a)
-            for (int t = 0; t < NW_TRY; ++t) sp1[(size_t)a * NW_TRY + t] = hspec[hact[a]];      // (host buffers are reused only after the sync above)
+        NW_HIP(hipMemcpyAsync(d_specp, hspecp.data(), hspecp.size() * sizeof(int), hipMemcpyHostToDevice, st));
         NW_HIP(hipMemcpyAsync(d_spec1, sp1.data(), (size_t)n_active * NW_TRY * sizeof(int), hipMemcpyHostToDevice, st));
-        if ((rc = launch_logp_grad(&P, b.probes, d_spec1, n_active * NW_TRY, 0, d_lpt, b.gt, nullptr, nullptr, nullptr, st))) { cleanup(); return rc; }
-        hipLaunchKernelGGL(newton_accept_kernel, dim3(n_active), dim3(256), 0, st, b, (const int *)d_active, n_active, (const double *)d_lpt,
-                           (const double *)b.probes);
+        for (int r = 0; r < rounds_per_sync; ++r) {
+            // probes of the fits that ask for a fresh Hessian (probe slot a = position in the active list) and their gradients
+            hipLaunchKernelGGL(newton_probe_kernel, dim3(2 * D, n_active), dim3(128), 0, st, b, (const int *)d_active, n_active);
+            if ((rc = launch_logp_grad(&P, b.probes, d_specp, n_active * 2 * D, 0, b.plp, b.pgrad, nullptr, nullptr, nullptr, st))) { cleanup(); return rc; }
+            hipLaunchKernelGGL(newton_build_kernel, dim3(Dp / 16, n_active), dim3(256), 0, st, b, (const int *)d_active, n_active);
+            hipLaunchKernelGGL(newton_solve_kernel, dim3(n_active), dim3(NW_NT), lds_solve, st, b, (const int *)d_active, n_active);
+            // trial points (NW_TRY step lengths per fit) as a dense batch for the evaluator, then the verdict
+            hipLaunchKernelGGL(newton_gather_kernel, dim3(n_active, NW_TRY), dim3(128), 0, st, b, (const int *)d_active, n_active, b.probes);
+            if ((rc = launch_logp_grad(&P, b.probes, d_spec1, n_active * NW_TRY, 0, d_lpt, b.gt, nullptr, nullptr, nullptr, st))) { cleanup(); return rc; }
+            hipLaunchKernelGGL(newton_accept_kernel, dim3(n_active), dim3(256), 0, st, b, (const int *)d_active, n_active, (const double *)d_lpt,
+                               (const double *)b.probes);
+        }
         NW_HIP(hipGetLastError());
     }
     NW_HIP(hipMemcpyAsync(hst.data(), b.st, hst.size() * sizeof(NewtonState), hipMemcpyDeviceToHost, st));
