@@ -473,34 +473,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             } else if (ph0 == PH_EPS) {
                 // Stan base_hmc::init_stepsize
                 if (l32 == 0) my_leaps += 1;
-                double h = -lp + kin;
-                if (isnan(h)) h = INFINITY;
-                const double dH = s.H0 - h;
-                const double thr = -0.2231435513142097557662950903;   // log(0.8)
-                bool finished = false;
-                const int trials = s.eps_trials;
-                const int edir = s.eps_dir;
-                double eps = s.eps;
-                if (trials == 0) {
-                    s.eps_dir = dH > thr ? 1 : -1;
-                } else {
-                    if (edir == 1 && !(dH > thr)) finished = true;
-                    else if (edir == -1 && !(dH < thr)) finished = true;
-                    else eps = edir == 1 ? 2.0 * eps : 0.5 * eps;
-                    if (!(eps > 1e-300) || eps > 1e7) finished = true;   // Stan throws here; we stop adapting
-                    s.eps = eps;
-                }
-                s.eps_trials = trials + 1;
-                if (finished) {
-                    // services::sample::hmc_nuts_diag_e_adapt sets mu = log(10*stepsize) from the CONFIGURED step
-                    // size before the first init_stepsize; after a metric update mu = log(10*eps) (adapt_diag_e_nuts)
-                    s.da_mu = s.iter == 0 ? log(10.0 * np.stepsize0) : log(10.0 * eps);
-                    s.da_counter = 0; s.da_sbar = 0.0; s.da_xbar = 0.0;
-                    s.phase = PH_TREE;
-                    next = 1;
-                } else {
-                    next = 3;
-                }
+                next = nuts_stepsize_trial(s, np, lp, kin);
             } else {   // PH_TREE: one new leaf
                 if (l32 == 0) my_leaps += 1;
                 s.n_leap_iter = s.n_leap_iter + 1;
@@ -648,69 +621,8 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             }
         }
         if (endt) {
-            // end of transition (Stan adapt_diag_e_nuts::transition)
-            const int nli = s.n_leap_iter;
-            const double accept = s.sum_metro / (double)(nli > 0 ? nli : 1);
-            const int iter = s.iter;
-            const bool warm = iter < np.warmup;
-            s.n_leap_total = s.n_leap_total + nli;
-            if (!warm) {
-                s.n_post = s.n_post + 1;
-                s.sum_accept = s.sum_accept + accept;
-                if (endt == 2) s.n_div = s.n_div + 1;
-                if (s.depth >= np.max_depth) s.n_maxdepth = s.n_maxdepth + 1;
-                draw = iter - np.warmup;
-                if (a.lp_draws && valid && l32 == 0) a.lp_draws[(size_t)unit * np.n_draws + draw] = s.lps;
-            }
-            bool redo_eps = false;
-            if (warm) {
-                // stepsize_adaptation::learn_stepsize (dual averaging)
-                const int cnt = s.da_counter + 1;
-                s.da_counter = cnt;
-                const double acc1 = accept > 1.0 ? 1.0 : accept;
-                const double eta = 1.0 / (cnt + np.t0);
-                const double sbar = (1.0 - eta) * s.da_sbar + eta * (np.delta - acc1);
-                s.da_sbar = sbar;
-                const double x = s.da_mu - sbar * sqrt((double)cnt) / np.gamma;
-                const double x_eta = pow((double)cnt, -np.kappa);
-                s.da_xbar = (1.0 - x_eta) * s.da_xbar + x_eta * x;
-                s.eps = exp(x);
-                // var_adaptation::learn_variance bookkeeping (windowed_adaptation)
-                const int wc = s.win_counter;
-                const bool w_act = wc >= s.init_buffer && wc < np.warmup - s.term_buffer && wc != np.warmup;
-                const bool w_end = wc == s.next_window && wc != np.warmup;
-                int win_n = s.win_n;
-                if (w_act) { win_n += 1; welf = true; wn = win_n; }
-                if (w_end) {
-                    // compute_next_window
-                    if (s.next_window != np.warmup - s.term_buffer - 1) {
-                        const int ws = s.win_size * 2;
-                        s.win_size = ws;
-                        int nw = wc + ws;
-                        if (nw != np.warmup - s.term_buffer - 1) {
-                            const int boundary = nw + 2 * ws;
-                            if (boundary >= np.warmup - s.term_buffer) nw = np.warmup - s.term_buffer - 1;
-                        }
-                        s.next_window = nw;
-                    }
-                    wend = true; wn = win_n;
-                    win_n = 0;
-                    redo_eps = true;
-                }
-                s.win_n = win_n;
-                s.win_counter = wc + 1;
-            }
-            s.iter = iter + 1;
-            if (warm && iter + 1 == np.warmup) s.eps = exp(s.da_xbar);       // complete_adaptation
-            if (iter + 1 >= np.warmup + np.n_draws) {
-                s.phase = PH_DONE;
-                next = 0;
-            } else if (redo_eps && iter + 1 < np.warmup) {
-                s.phase = PH_EPS; s.eps_dir = 0; s.eps_trials = 0;
-                next = 3;
-            } else {
-                next = 1;
-            }
+            next = nuts_transition_end(s, np, endt, draw, welf, wend, wn);     // (bdrt_nuts_device.h)
+            if (draw >= 0 && a.lp_draws && valid && l32 == 0) a.lp_draws[(size_t)unit * np.n_draws + draw] = s.lps;
         }
         BDRT_NUTS_PROF(14);
         BDRT_WAVE_PROF(20);
@@ -1039,32 +951,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_solo_kernel(const DevProblem *__
             } else if (ph0 == PH_EPS) {
                 // Stan base_hmc::init_stepsize
                 my_leaps += 1;
-                double h = -lp + kin;
-                if (isnan(h)) h = INFINITY;
-                const double dH = s.H0 - h;
-                const double thr = -0.2231435513142097557662950903;   // log(0.8)
-                bool finished = false;
-                const int trials = s.eps_trials;
-                const int edir = s.eps_dir;
-                double eps = s.eps;
-                if (trials == 0) {
-                    s.eps_dir = dH > thr ? 1 : -1;
-                } else {
-                    if (edir == 1 && !(dH > thr)) finished = true;
-                    else if (edir == -1 && !(dH < thr)) finished = true;
-                    else eps = edir == 1 ? 2.0 * eps : 0.5 * eps;
-                    if (!(eps > 1e-300) || eps > 1e7) finished = true;
-                    s.eps = eps;
-                }
-                s.eps_trials = trials + 1;
-                if (finished) {
-                    s.da_mu = s.iter == 0 ? log(10.0 * np.stepsize0) : log(10.0 * eps);
-                    s.da_counter = 0; s.da_sbar = 0.0; s.da_xbar = 0.0;
-                    s.phase = PH_TREE;
-                    next = 1;
-                } else {
-                    next = 3;
-                }
+                next = nuts_stepsize_trial(s, np, lp, kin);
             } else {   // PH_TREE: one new leaf
                 my_leaps += 1;
                 s.n_leap_iter = s.n_leap_iter + 1;
@@ -1153,66 +1040,8 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_solo_kernel(const DevProblem *__
             }
         }
         if (endt) {
-            // end of transition (Stan adapt_diag_e_nuts::transition)
-            const int nli = s.n_leap_iter;
-            const double accept = s.sum_metro / (double)(nli > 0 ? nli : 1);
-            const int iter = s.iter;
-            const bool warm = iter < np.warmup;
-            s.n_leap_total = s.n_leap_total + nli;
-            if (!warm) {
-                s.n_post = s.n_post + 1;
-                s.sum_accept = s.sum_accept + accept;
-                if (endt == 2) s.n_div = s.n_div + 1;
-                if (s.depth >= np.max_depth) s.n_maxdepth = s.n_maxdepth + 1;
-                draw = iter - np.warmup;
-                if (a.lp_draws && tid == 0) a.lp_draws[(size_t)unit * np.n_draws + draw] = s.lps;
-            }
-            bool redo_eps = false;
-            if (warm) {
-                const int cnt = s.da_counter + 1;
-                s.da_counter = cnt;
-                const double acc1 = accept > 1.0 ? 1.0 : accept;
-                const double eta = 1.0 / (cnt + np.t0);
-                const double sbar = (1.0 - eta) * s.da_sbar + eta * (np.delta - acc1);
-                s.da_sbar = sbar;
-                const double x = s.da_mu - sbar * sqrt((double)cnt) / np.gamma;
-                const double x_eta = pow((double)cnt, -np.kappa);
-                s.da_xbar = (1.0 - x_eta) * s.da_xbar + x_eta * x;
-                s.eps = exp(x);
-                const int wc = s.win_counter;
-                const bool w_act = wc >= s.init_buffer && wc < np.warmup - s.term_buffer && wc != np.warmup;
-                const bool w_end = wc == s.next_window && wc != np.warmup;
-                int win_n = s.win_n;
-                if (w_act) { win_n += 1; welf = true; wn = win_n; }
-                if (w_end) {
-                    if (s.next_window != np.warmup - s.term_buffer - 1) {
-                        const int ws = s.win_size * 2;
-                        s.win_size = ws;
-                        int nw = wc + ws;
-                        if (nw != np.warmup - s.term_buffer - 1) {
-                            const int boundary = nw + 2 * ws;
-                            if (boundary >= np.warmup - s.term_buffer) nw = np.warmup - s.term_buffer - 1;
-                        }
-                        s.next_window = nw;
-                    }
-                    wend = true; wn = win_n;
-                    win_n = 0;
-                    redo_eps = true;
-                }
-                s.win_n = win_n;
-                s.win_counter = wc + 1;
-            }
-            s.iter = iter + 1;
-            if (warm && iter + 1 == np.warmup) s.eps = exp(s.da_xbar);       // complete_adaptation
-            if (iter + 1 >= np.warmup + np.n_draws) {
-                s.phase = PH_DONE;
-                next = 0;
-            } else if (redo_eps && iter + 1 < np.warmup) {
-                s.phase = PH_EPS; s.eps_dir = 0; s.eps_trials = 0;
-                next = 3;
-            } else {
-                next = 1;
-            }
+            next = nuts_transition_end(s, np, endt, draw, welf, wend, wn);     // (bdrt_nuts_device.h)
+            if (draw >= 0 && a.lp_draws && tid == 0) a.lp_draws[(size_t)unit * np.n_draws + draw] = s.lps;
         }
 
         BDRT_SOLO_NPROF(7);

@@ -122,6 +122,105 @@ struct NutsParams {
     int has_init;
 };
 
+// ---- scalar logic shared by the three samplers (16-chain kernel, one-chain-per-workgroup kernel, cooperative wide-vector
+//      path): the same statements on a chain state that lives in LDS or in registers ---------------------------------------
+
+// Stan base_hmc::init_stepsize, one trial: lp, kin = log-posterior / kinetic energy after the trial leapfrog.
+// Returns the kind of next start point: 1 new transition (search finished), 3 another trial.
+template <class S>
+__host__ __device__ inline int nuts_stepsize_trial(S &s, const NutsParams &np, double lp, double kin)
+{
+    double h = -lp + kin;
+    if (isnan(h)) h = INFINITY;
+    const double dH = s.H0 - h;
+    const double thr = -0.2231435513142097557662950903;   // log(0.8)
+    bool finished = false;
+    const int trials = s.eps_trials;
+    const int edir = s.eps_dir;
+    double eps = s.eps;
+    if (trials == 0) {
+        s.eps_dir = dH > thr ? 1 : -1;
+    } else {
+        if (edir == 1 && !(dH > thr)) finished = true;
+        else if (edir == -1 && !(dH < thr)) finished = true;
+        else eps = edir == 1 ? 2.0 * eps : 0.5 * eps;
+        if (!(eps > 1e-300) || eps > 1e7) finished = true;   // Stan throws here; we stop adapting
+        s.eps = eps;
+    }
+    s.eps_trials = trials + 1;
+    if (!finished) return 3;
+    // services::sample::hmc_nuts_diag_e_adapt sets mu = log(10*stepsize) from the CONFIGURED step size before the first
+    // init_stepsize; after a metric update mu = log(10*eps) (adapt_diag_e_nuts)
+    s.da_mu = s.iter == 0 ? log(10.0 * np.stepsize0) : log(10.0 * eps);
+    s.da_counter = 0; s.da_sbar = 0.0; s.da_xbar = 0.0;
+    s.phase = PH_TREE;
+    return 1;
+}
+
+// End of a transition (Stan adapt_diag_e_nuts::transition): statistics, dual averaging, metric-window bookkeeping.
+// endt: 1 U-turn / depth limit, 2 divergence.  Outputs: draw (index of the sampling draw to store, -1 in warm-up),
+// welf / wend (Welford update / end of a metric window, with wn samples), and the kind of next start point (return value:
+// 0 chain finished, 1 new transition, 3 step-size search after a metric update).
+template <class S>
+__host__ __device__ inline int nuts_transition_end(S &s, const NutsParams &np, int endt, int &draw, bool &welf, bool &wend, double &wn)
+{
+    const int nli = s.n_leap_iter;
+    const double accept = s.sum_metro / (double)(nli > 0 ? nli : 1);
+    const int iter = s.iter;
+    const bool warm = iter < np.warmup;
+    s.n_leap_total = s.n_leap_total + nli;
+    if (!warm) {
+        s.n_post = s.n_post + 1;
+        s.sum_accept = s.sum_accept + accept;
+        if (endt == 2) s.n_div = s.n_div + 1;
+        if (s.depth >= np.max_depth) s.n_maxdepth = s.n_maxdepth + 1;
+        draw = iter - np.warmup;
+    }
+    bool redo_eps = false;
+    if (warm) {
+        // stepsize_adaptation::learn_stepsize (dual averaging)
+        const int cnt = s.da_counter + 1;
+        s.da_counter = cnt;
+        const double acc1 = accept > 1.0 ? 1.0 : accept;
+        const double eta = 1.0 / (cnt + np.t0);
+        const double sbar = (1.0 - eta) * s.da_sbar + eta * (np.delta - acc1);
+        s.da_sbar = sbar;
+        const double x = s.da_mu - sbar * sqrt((double)cnt) / np.gamma;
+        const double x_eta = pow((double)cnt, -np.kappa);
+        s.da_xbar = (1.0 - x_eta) * s.da_xbar + x_eta * x;
+        s.eps = exp(x);
+        // var_adaptation::learn_variance bookkeeping (windowed_adaptation)
+        const int wc = s.win_counter;
+        const bool w_act = wc >= s.init_buffer && wc < np.warmup - s.term_buffer && wc != np.warmup;
+        const bool w_end = wc == s.next_window && wc != np.warmup;
+        int win_n = s.win_n;
+        if (w_act) { win_n += 1; welf = true; wn = win_n; }
+        if (w_end) {
+            // compute_next_window
+            if (s.next_window != np.warmup - s.term_buffer - 1) {
+                const int ws = s.win_size * 2;
+                s.win_size = ws;
+                int nw = wc + ws;
+                if (nw != np.warmup - s.term_buffer - 1) {
+                    const int boundary = nw + 2 * ws;
+                    if (boundary >= np.warmup - s.term_buffer) nw = np.warmup - s.term_buffer - 1;
+                }
+                s.next_window = nw;
+            }
+            wend = true; wn = win_n;
+            win_n = 0;
+            redo_eps = true;
+        }
+        s.win_n = win_n;
+        s.win_counter = wc + 1;
+    }
+    s.iter = iter + 1;
+    if (warm && iter + 1 == np.warmup) s.eps = exp(s.da_xbar);       // complete_adaptation
+    if (iter + 1 >= np.warmup + np.n_draws) { s.phase = PH_DONE; return 0; }
+    if (redo_eps && iter + 1 < np.warmup) { s.phase = PH_EPS; s.eps_dir = 0; s.eps_trials = 0; return 3; }
+    return 1;
+}
+
 // Stan's windowed_adaptation schedule (stan/mcmc/windowed_adaptation.hpp)
 __host__ __device__ inline void window_init(ChainState &s, int warmup, int init_buffer, int term_buffer, int base_window)
 {
