@@ -476,26 +476,8 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 next = nuts_stepsize_trial(s, np, lp, kin);
             } else {   // PH_TREE: one new leaf
                 if (l32 == 0) my_leaps += 1;
-                s.n_leap_iter = s.n_leap_iter + 1;
-                double h = -lp + kin;
-                if (isnan(h)) h = INFINITY;
-                const double H0 = s.H0;
-                const bool divergent = (h - H0) > np.max_deltaH;
-                const double w = H0 - h;
-                s.sum_metro = s.sum_metro + (w > 0.0 ? 1.0 : exp(w));
-                if (divergent) {
-                    endt = 2;               // transition ends, subtree discarded, divergent
-                } else {
-                    const double lsw_new = log_sum_exp2(s.lsw_sub, w);
-                    // uniform sampling inside the new subtree: keep leaf i with probability w_i / W_i
-                    const double u = rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
-                    if (leaf_now == 0 || u < exp(w - lsw_new)) { copyq = true; s.lpq = lp; }
-                    s.lsw_sub = lsw_new;
-                    tree = true;
-                    while ((leaf_now >> nm) & 1) ++nm;              // trailing ones = sub-subtrees ending here
-                    last = leaf_now == s.nleaves - 1;
-                    if (last) *slow = 1;                            // closing a subtree (and maybe the transition): a long round
-                }
+                nuts_tree_leaf(s, np, rng, lp, kin, leaf_now, copyq, tree, nm, last, endt);      // (bdrt_nuts_device.h)
+                if (last) *slow = 1;                                // closing a subtree (and maybe the transition): a long round
             }
         }
         BDRT_NUTS_PROF(12);

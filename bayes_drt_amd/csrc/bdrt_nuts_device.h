@@ -157,6 +157,34 @@ __host__ __device__ inline int nuts_stepsize_trial(S &s, const NutsParams &np, d
     return 1;
 }
 
+// One new leaf of the subtree under construction (Stan base_nuts::build_tree at depth 0, seen in time order): energy error,
+// divergence test, acceptance statistic, and the uniform sampling inside the subtree (keep leaf i with probability
+// w_i / W_i).  Outputs: endt = 2 on divergence; otherwise tree = true, copyq (this leaf becomes the subtree's proposal),
+// nm (trailing one bits of the leaf index = sub-subtrees that end here), last (the subtree is complete).
+template <class S>
+__host__ __device__ inline void nuts_tree_leaf(S &s, const NutsParams &np, const Philox &rng, double lp, double kin, int leaf_now,
+                                               bool &copyq, bool &tree, int &nm, bool &last, int &endt)
+{
+    s.n_leap_iter = s.n_leap_iter + 1;
+    double h = -lp + kin;
+    if (isnan(h)) h = INFINITY;
+    const double H0 = s.H0;
+    const bool divergent = (h - H0) > np.max_deltaH;
+    const double w = H0 - h;
+    s.sum_metro = s.sum_metro + (w > 0.0 ? 1.0 : exp(w));
+    if (divergent) {
+        endt = 2;               // transition ends, subtree discarded, divergent
+        return;
+    }
+    const double lsw_new = log_sum_exp2(s.lsw_sub, w);
+    const double u = rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
+    if (leaf_now == 0 || u < exp(w - lsw_new)) { copyq = true; s.lpq = lp; }
+    s.lsw_sub = lsw_new;
+    tree = true;
+    while ((leaf_now >> nm) & 1) ++nm;              // trailing ones = sub-subtrees ending here
+    last = leaf_now == s.nleaves - 1;
+}
+
 // End of a transition (Stan adapt_diag_e_nuts::transition): statistics, dual averaging, metric-window bookkeeping.
 // endt: 1 U-turn / depth limit, 2 divergence.  Outputs: draw (index of the sampling draw to store, -1 in warm-up),
 // welf / wend (Welford update / end of a metric window, with wn samples), and the kind of next start point (return value:
