@@ -122,6 +122,61 @@ struct NutsParams {
     int has_init;
 };
 
+// Stan's windowed_adaptation schedule (stan/mcmc/windowed_adaptation.hpp, SURVEY Appendix A)
+__host__ __device__ inline void window_init(ChainState &s, int warmup, int init_buffer, int term_buffer, int base_window)
+{
+    const bool no_metric = warmup < 20;      // Stan: set_window_params returns early, the (unsigned) next window is never reached
+    if (no_metric) {
+        init_buffer = warmup; term_buffer = 0; base_window = 0;
+    } else if (init_buffer + base_window + term_buffer > warmup) {
+        init_buffer = (int)(0.15 * warmup);
+        term_buffer = (int)(0.1 * warmup);
+        base_window = warmup - (init_buffer + term_buffer);
+    }
+    s.init_buffer = init_buffer; s.term_buffer = term_buffer; s.base_window = base_window;
+    s.win_counter = 0;
+    s.win_size = base_window;
+    s.next_window = no_metric ? -1 : init_buffer + base_window - 1;
+    s.win_n = 0;
+}
+template <class S>
+__host__ __device__ inline bool window_active(const S &s, int warmup)
+{
+    return s.win_counter >= s.init_buffer && s.win_counter < warmup - s.term_buffer && s.win_counter != warmup;
+}
+template <class S>
+__host__ __device__ inline bool window_end(const S &s, int warmup)
+{
+    return s.win_counter == s.next_window && s.win_counter != warmup;
+}
+template <class S>
+__host__ __device__ inline void window_next(S &s, int warmup)
+{
+    if (s.next_window == warmup - s.term_buffer - 1) return;
+    s.win_size *= 2;
+    s.next_window = s.win_counter + s.win_size;
+    if (s.next_window == warmup - s.term_buffer - 1) return;
+    const int boundary = s.next_window + 2 * s.win_size;
+    if (boundary >= warmup - s.term_buffer) s.next_window = warmup - s.term_buffer - 1;
+}
+
+// Stan's stepsize_adaptation::learn_stepsize (dual averaging)
+template <class S>
+__host__ __device__ inline void da_restart(S &s) { s.da_counter = 0; s.da_sbar = 0.0; s.da_xbar = 0.0; }
+template <class S>
+__host__ __device__ inline void da_learn(S &s, const NutsParams &np, double accept)
+{
+    s.da_counter += 1;
+    accept = accept > 1.0 ? 1.0 : accept;
+    const double eta = 1.0 / (s.da_counter + np.t0);
+    s.da_sbar = (1.0 - eta) * s.da_sbar + eta * (np.delta - accept);
+    const double x = s.da_mu - s.da_sbar * sqrt((double)s.da_counter) / np.gamma;
+    const double x_eta = pow((double)s.da_counter, -np.kappa);
+    s.da_xbar = (1.0 - x_eta) * s.da_xbar + x_eta * x;
+    s.eps = exp(x);
+}
+
+
 // ---- scalar logic shared by the three samplers (16-chain kernel, one-chain-per-workgroup kernel, cooperative wide-vector
 //      path): the same statements on a chain state that lives in LDS or in registers ---------------------------------------
 
@@ -152,7 +207,7 @@ __host__ __device__ inline int nuts_stepsize_trial(S &s, const NutsParams &np, d
     // services::sample::hmc_nuts_diag_e_adapt sets mu = log(10*stepsize) from the CONFIGURED step size before the first
     // init_stepsize; after a metric update mu = log(10*eps) (adapt_diag_e_nuts)
     s.da_mu = s.iter == 0 ? log(10.0 * np.stepsize0) : log(10.0 * eps);
-    s.da_counter = 0; s.da_sbar = 0.0; s.da_xbar = 0.0;
+    da_restart(s);
     s.phase = PH_TREE;
     return 1;
 }
@@ -206,35 +261,14 @@ __host__ __device__ inline int nuts_transition_end(S &s, const NutsParams &np, i
     }
     bool redo_eps = false;
     if (warm) {
-        // stepsize_adaptation::learn_stepsize (dual averaging)
-        const int cnt = s.da_counter + 1;
-        s.da_counter = cnt;
-        const double acc1 = accept > 1.0 ? 1.0 : accept;
-        const double eta = 1.0 / (cnt + np.t0);
-        const double sbar = (1.0 - eta) * s.da_sbar + eta * (np.delta - acc1);
-        s.da_sbar = sbar;
-        const double x = s.da_mu - sbar * sqrt((double)cnt) / np.gamma;
-        const double x_eta = pow((double)cnt, -np.kappa);
-        s.da_xbar = (1.0 - x_eta) * s.da_xbar + x_eta * x;
-        s.eps = exp(x);
+        da_learn(s, np, accept);                                 // stepsize_adaptation::learn_stepsize (dual averaging)
         // var_adaptation::learn_variance bookkeeping (windowed_adaptation)
         const int wc = s.win_counter;
-        const bool w_act = wc >= s.init_buffer && wc < np.warmup - s.term_buffer && wc != np.warmup;
-        const bool w_end = wc == s.next_window && wc != np.warmup;
+        const bool w_act = window_active(s, np.warmup), w_end = window_end(s, np.warmup);
         int win_n = s.win_n;
         if (w_act) { win_n += 1; welf = true; wn = win_n; }
         if (w_end) {
-            // compute_next_window
-            if (s.next_window != np.warmup - s.term_buffer - 1) {
-                const int ws = s.win_size * 2;
-                s.win_size = ws;
-                int nw = wc + ws;
-                if (nw != np.warmup - s.term_buffer - 1) {
-                    const int boundary = nw + 2 * ws;
-                    if (boundary >= np.warmup - s.term_buffer) nw = np.warmup - s.term_buffer - 1;
-                }
-                s.next_window = nw;
-            }
+            window_next(s, np.warmup);                           // compute_next_window
             wend = true; wn = win_n;
             win_n = 0;
             redo_eps = true;
@@ -247,55 +281,6 @@ __host__ __device__ inline int nuts_transition_end(S &s, const NutsParams &np, i
     if (iter + 1 >= np.warmup + np.n_draws) { s.phase = PH_DONE; return 0; }
     if (redo_eps && iter + 1 < np.warmup) { s.phase = PH_EPS; s.eps_dir = 0; s.eps_trials = 0; return 3; }
     return 1;
-}
-
-// Stan's windowed_adaptation schedule (stan/mcmc/windowed_adaptation.hpp, SURVEY Appendix A)
-__host__ __device__ inline void window_init(ChainState &s, int warmup, int init_buffer, int term_buffer, int base_window)
-{
-    const bool no_metric = warmup < 20;      // Stan: set_window_params returns early, the (unsigned) next window is never reached
-    if (no_metric) {
-        init_buffer = warmup; term_buffer = 0; base_window = 0;
-    } else if (init_buffer + base_window + term_buffer > warmup) {
-        init_buffer = (int)(0.15 * warmup);
-        term_buffer = (int)(0.1 * warmup);
-        base_window = warmup - (init_buffer + term_buffer);
-    }
-    s.init_buffer = init_buffer; s.term_buffer = term_buffer; s.base_window = base_window;
-    s.win_counter = 0;
-    s.win_size = base_window;
-    s.next_window = no_metric ? -1 : init_buffer + base_window - 1;
-    s.win_n = 0;
-}
-__host__ __device__ inline bool window_active(const ChainState &s, int warmup)
-{
-    return s.win_counter >= s.init_buffer && s.win_counter < warmup - s.term_buffer && s.win_counter != warmup;
-}
-__host__ __device__ inline bool window_end(const ChainState &s, int warmup)
-{
-    return s.win_counter == s.next_window && s.win_counter != warmup;
-}
-__host__ __device__ inline void window_next(ChainState &s, int warmup)
-{
-    if (s.next_window == warmup - s.term_buffer - 1) return;
-    s.win_size *= 2;
-    s.next_window = s.win_counter + s.win_size;
-    if (s.next_window == warmup - s.term_buffer - 1) return;
-    const int boundary = s.next_window + 2 * s.win_size;
-    if (boundary >= warmup - s.term_buffer) s.next_window = warmup - s.term_buffer - 1;
-}
-
-// Stan's stepsize_adaptation::learn_stepsize (dual averaging)
-__host__ __device__ inline void da_restart(ChainState &s) { s.da_counter = 0; s.da_sbar = 0.0; s.da_xbar = 0.0; }
-__host__ __device__ inline void da_learn(ChainState &s, const NutsParams &np, double accept)
-{
-    s.da_counter += 1;
-    accept = accept > 1.0 ? 1.0 : accept;
-    const double eta = 1.0 / (s.da_counter + np.t0);
-    s.da_sbar = (1.0 - eta) * s.da_sbar + eta * (np.delta - accept);
-    const double x = s.da_mu - s.da_sbar * sqrt((double)s.da_counter) / np.gamma;
-    const double x_eta = pow((double)s.da_counter, -np.kappa);
-    s.da_xbar = (1.0 - x_eta) * s.da_xbar + x_eta * x;
-    s.eps = exp(x);
 }
 
 }  // namespace bdrt
