@@ -38,7 +38,7 @@ void bdrt_opt_defaults(bdrt_opt_options *o)
 {
     o->max_iter = 50000; o->history = 5; o->init_alpha = 1e-3; o->tol_obj = 1e-12; o->tol_rel_obj = 1e4;
     o->tol_grad = 1e-8; o->tol_rel_grad = 1e7; o->tol_param = 1e-8;
-    o->newton_max_iter = 2000; o->lbfgs_before_newton = 200; o->newton_tol = 1e-8;
+    o->newton_max_iter = 2000; o->lbfgs_before_newton = 0; o->newton_tol = 1e-8;
 }
 
 int bdrt_optimize(bdrt_problem *p, const double *init_theta, const int *spec, int n_fits, const bdrt_opt_options *opts,

@@ -118,7 +118,7 @@ typedef struct {
      * damped Newton iteration with the full Hessian (2D batched gradient evaluations per step) runs until
      * |grad|_inf < newton_tol.  newton_max_iter = 0 gives the plain Stan-style L-BFGS.                   */
     int newton_max_iter;    /* 2000                                                                      */
-    int lbfgs_before_newton;/* 200 (measured: more L-BFGS iterations before the polish only add time)       */
+    int lbfgs_before_newton;/* 0 (measured: L-BFGS iterations before the Newton iteration only add time)    */
     double newton_tol;      /* 1e-8                                                                      */
 } bdrt_opt_options;
 typedef struct {
