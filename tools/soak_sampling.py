@@ -21,8 +21,10 @@ t0 = time.time()
 draws, lp, diag = sample_units(prob, ns * nc, warm, nd, 2026, None, spec=spec, chain_ids=cid)
 t1 = time.time()
 nl = sum(d['n_leapfrog'] for d in diag)
+per = np.sort(np.array([d['n_leapfrog'] for d in diag], dtype=float))
 print('%d spectra x %d chains x (%d + %d): %.1f s wall, %.2f M leapfrogs, %.1f M evals/s end to end' %
       (ns, nc, warm, nd, t1 - t0, nl / 1e6, nl / (t1 - t0) / 1e6))
+print('leapfrogs per chain: min %.3g, median %.3g, 95th percentile %.3g, max %.3g' % (per[0], per[len(per) // 2], per[int(0.95 * len(per))], per[-1]))
 print('finite draws: %s; divergent transitions %d of %d; tree-depth hits %d; step size median %.3g (min %.3g, max %.3g)' %
       (bool(np.all(np.isfinite(draws)) and np.all(np.isfinite(lp))), sum(d['n_divergent'] for d in diag), ns * nc * nd,
        sum(d['n_max_treedepth'] for d in diag), np.median([d['stepsize'] for d in diag]),
