@@ -66,6 +66,8 @@ struct NutsArgs {
     int rounds;
     int ds;                // row stride of the state vectors (D rounded up to 32)
     long long *prof;       // optional [n_wg][32] cycle counters (phase profile)
+    const int *unit_map;   // one-chain-per-workgroup kernel: unit of workgroup b (nullptr: b) -- the tail of a large run (below)
+    int *active_counter;   // 16-chain kernel: chains still running at the end of the launch (all workgroups)
 };
 
 #include "bdrt_nuts_wide.h"
@@ -825,8 +827,10 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     }
     {
         const int ph = s.phase;
-        const int busy = __syncthreads_or(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE);
+        const bool running = ph == PH_INIT || ph == PH_EPS || ph == PH_TREE;
+        const int busy = __syncthreads_or(running);
         if (tid == 0 && !busy) atomicAdd(a.done_counter, 1);
+        if (a.active_counter && l32 == 0 && running && valid) atomicAdd(a.active_counter, 1);
     }
 }
 
@@ -840,10 +844,10 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_solo_kernel(const DevProblem *__
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevProblem &P = *Pp;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int unit = blockIdx.x;
+    const int unit = a.unit_map ? a.unit_map[blockIdx.x] : blockIdx.x;
     const int D = g.D, DS = a.ds, j = tid;
     const bool own = j < D;                                // this thread owns element j of the D-vectors
-    double *Vg = a.vecs + (size_t)unit * SG_COUNT * DS;    // global rows
+    double *Vg = a.vecs + (size_t)blockIdx.x * SG_COUNT * DS;    // global rows
     double *V = smem + g.o_vec;                            // LDS rows
     auto row = [&](int v) -> double * { return V + (size_t)v * g.DSS; };
     double *red = smem + g.o_red;
@@ -1144,6 +1148,30 @@ __global__ __launch_bounds__(SOLO_NT) void solo_eval_kernel(const DevProblem *__
     if (tid == 0 && lp) lp[b] = *lps;
 }
 
+// The tail of a large run.  The 16-chain kernel advances every live chain by one leapfrog per ~33 us whatever the number of
+// live chains; a run lasts as long as its longest chain (BASELINE config 4: 0.33 .. 0.98 M leapfrogs per chain), and in the
+// tail most tile columns are empty.  Once the number of live chains is below what the one-chain-per-workgroup kernel
+// finishes faster (8.3 us per leapfrog, one chain per CU at a time: below ~4 chains per CU), the live chains move there:
+// this kernel copies a chain's rows from the 16-chain layout [wg][V_*][column][ds16] to [slot][SV_* / SG_*][dss].
+// Same counter-based random numbers and the same arithmetic up to summation order, so the chains continue as they were.
+__global__ void nuts_migrate_kernel(const double *v16, int ds16, int cpw, const int *unit_map, double *vsolo, int dss, int D)
+{
+    const int slot = blockIdx.x, u = unit_map[slot];
+    const int wg = u / cpw, col = slot_col(u % cpw);
+    const double *src = v16 + (size_t)wg * V_COUNT * NC * ds16;
+    double *dst = vsolo + (size_t)slot * SG_COUNT * dss;
+    for (int r = 0; r < SG_COUNT; ++r) {
+        int v;                                            // row of the 16-chain layout that holds row r of the solo layout
+        if (r < SV_CKC) { constexpr int head[SV_CKC] = {V_TH, V_P, V_G, V_THM, V_PM, V_GM, V_THP, V_PP, V_GP, V_THS, V_GS, V_THQ, V_GQ, V_RHO, V_MINV}; v = head[r]; }
+        else if (r < SV_CKP) v = V_CKC + (r - SV_CKC);
+        else if (r < SV_COUNT) v = V_CKP + (r - SV_CKP);
+        else v = r == SG_WMEAN ? V_WMEAN : V_WM2;
+        const double *sr = src + ((size_t)v * NC + col) * ds16;
+        for (int j = threadIdx.x; j < dss; j += blockDim.x) dst[(size_t)r * dss + j] = j < D ? sr[j] : 0.0;
+    }
+}
+static_assert(SOLO_MAXD == MAXD, "the two kernels keep the same number of checkpoint levels");
+
 struct Sampler {
     Problem *prob = nullptr;
     NutsParams np;
@@ -1164,6 +1192,13 @@ struct Sampler {
     unsigned long long *d_leaps = nullptr;
     int rounds_default = 256;
     long long *d_prof = nullptr;
+    // tail migration (nuts_migrate_kernel)
+    int *d_active = nullptr;          // live chains after the last launch of the 16-chain kernel
+    int n_cu = 256;
+    bool may_migrate = false, migrated = false;
+    double *vecs16 = nullptr;         // the 16-chain rows, kept until the sampler is destroyed
+    int *d_unit_map = nullptr;
+    int n_solo = 0;                   // workgroups of the one-chain-per-workgroup kernel (= n_units unless migrated)
 };
 
 static size_t nuts_lds_bytes(const DevProblem &P, bool s1)
@@ -1203,6 +1238,9 @@ void bdrt_sampler_destroy(bdrt_sampler *s)
     if (S.d_done) hipFree(S.d_done);
     if (S.d_leaps) hipFree(S.d_leaps);
     if (S.d_prof) hipFree(S.d_prof);
+    if (S.d_active) hipFree(S.d_active);
+    if (S.vecs16) hipFree(S.vecs16);
+    if (S.d_unit_map) hipFree(S.d_unit_map);
     if (S.stream) hipStreamDestroy(S.stream);
     delete s;
 }
@@ -1228,7 +1266,14 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         if (hipGetDeviceProperties(&prop, P.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
     }
     S.solo = solo_capable(P.dev) && n_units <= 4 * n_cu;
-    if (const char *e = getenv("BDRT_SOLO")) S.solo = solo_capable(P.dev) && atoi(e) != 0;      // diagnostics: force / forbid
+    S.n_cu = n_cu;
+    // a run that starts on the 16-chain kernel may hand its last live chains to the one-chain-per-workgroup kernel
+    S.may_migrate = solo_capable(P.dev) && !S.solo;
+    if (const char *e = getenv("BDRT_SOLO")) {                                                  // diagnostics: force / forbid
+        S.solo = solo_capable(P.dev) && atoi(e) != 0;
+        S.may_migrate = false;
+    }
+    if (const char *e = getenv("BDRT_TAIL_MIGRATION")) S.may_migrate = S.may_migrate && atoi(e) != 0;
     if (S.solo) S.geom = solo_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
     // chains per workgroup: fill every CU with one workgroup before putting a second chain on any wave
     {
@@ -1305,12 +1350,16 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         return fail("hipMalloc(lp) failed");
     if (hipMalloc((void **)&S.d_done, sizeof(int)) != hipSuccess) return fail("hipMalloc failed");
     if (hipMalloc((void **)&S.d_leaps, sizeof(unsigned long long)) != hipSuccess) return fail("hipMalloc failed");
+    if (hipMalloc((void **)&S.d_active, sizeof(int)) != hipSuccess) return fail("hipMalloc failed");
     hipMemcpy(S.args.vecs, hv.data(), nvec * sizeof(double), hipMemcpyHostToDevice);
     hipMemcpy(S.args.states, hs.data(), hs.size() * sizeof(ChainState), hipMemcpyHostToDevice);
     hipMemset(S.args.draws, 0, nd * sizeof(double));
     hipMemset(S.d_leaps, 0, sizeof(unsigned long long));
     S.args.leap_counter = S.d_leaps;
     S.args.done_counter = S.d_done;
+    S.args.active_counter = S.d_active;
+    S.args.unit_map = nullptr;
+    S.n_solo = n_units;
     S.args.n_units = n_units;
     if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     static LdsAttrCache attr_cache;
@@ -1357,6 +1406,7 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
     BDRT_HIP(hipSetDevice(S.prob->device));
     S.args.rounds = rounds;
     BDRT_HIP(hipMemsetAsync(S.d_done, 0, sizeof(int), S.stream));
+    BDRT_HIP(hipMemsetAsync(S.d_active, 0, sizeof(int), S.stream));
     hipEvent_t e0, e1;
     BDRT_HIP(hipEventCreate(&e0));
     BDRT_HIP(hipEventCreate(&e1));
@@ -1370,7 +1420,7 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             else hipLaunchKernelGGL((nuts_kernel<NJV, 0>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);   \
         } while (0)
         if (S.solo)
-            hipLaunchKernelGGL(nuts_solo_kernel, dim3(S.n_units), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
+            hipLaunchKernelGGL(nuts_solo_kernel, dim3(S.n_solo), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
         else if (S.use_s1 && S.D <= 32 * 11)
             hipLaunchKernelGGL((nuts_kernel<11, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
         else if (S.use_s1)
@@ -1411,6 +1461,47 @@ int bdrt_sampler_sync(bdrt_sampler *s)
     return harvest_events(s->impl, true);
 }
 
+// Hand the live chains of a 16-chain run to the one-chain-per-workgroup kernel when that finishes them sooner (see
+// nuts_migrate_kernel).  Called between launches with the stream idle.
+static int maybe_migrate_tail(Sampler &S)
+{
+    int active = 0;
+    BDRT_HIP(hipMemcpy(&active, S.d_active, sizeof(int), hipMemcpyDeviceToHost));
+    // the one-chain kernel runs one chain per CU at a time, 4x faster per leapfrog: it wins below ~4 live chains per CU
+    if (active <= 0 || active > (7 * S.n_cu) / 2) return 0;
+    std::vector<ChainState> hs((size_t)S.n_units);
+    BDRT_HIP(hipMemcpy(hs.data(), S.args.states, hs.size() * sizeof(ChainState), hipMemcpyDeviceToHost));
+    std::vector<int> map;
+    for (int u = 0; u < S.n_units; ++u)
+        if (hs[u].phase == PH_INIT || hs[u].phase == PH_EPS || hs[u].phase == PH_TREE) map.push_back(u);
+    if (map.empty()) return 0;
+    const SoloGeom g = solo_geometry(S.prob->dev.nf, S.prob->dev.blk[0].K, S.prob->dev.D);
+    const size_t lds = (size_t)g.total * sizeof(double) + 64;
+    if (lds > S.lds_bytes) return 0;                      // (bdrt_sampler_create raised every kernel's LDS limit to the 16-chain size)
+    double *vsolo = nullptr;
+    int *dmap = nullptr;
+    if (hipMalloc((void **)&vsolo, map.size() * (size_t)SG_COUNT * g.DSS * sizeof(double)) != hipSuccess) return 0;   // (keep going as is)
+    if (hipMalloc((void **)&dmap, map.size() * sizeof(int)) != hipSuccess) { hipFree(vsolo); return 0; }
+    BDRT_HIP(hipMemcpy(dmap, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(nuts_migrate_kernel, dim3((unsigned)map.size()), dim3(256), 0, S.stream, (const double *)S.args.vecs, S.args.ds,
+                       S.args.cpw, (const int *)dmap, vsolo, g.DSS, S.D);
+    BDRT_HIP(hipGetLastError());
+    BDRT_HIP(hipStreamSynchronize(S.stream));
+    S.vecs16 = S.args.vecs;
+    S.args.prof = nullptr;                                // (the phase-profile slots are laid out per 16-chain workgroup)
+    S.args.vecs = vsolo;
+    S.args.ds = g.DSS;
+    S.d_unit_map = dmap;
+    S.args.unit_map = dmap;
+    S.geom = g;
+    S.lds_bytes = lds;
+    S.solo = true;
+    S.n_solo = (int)map.size();
+    S.n_wg = S.n_solo;                                   // (the all-done test counts finished workgroups)
+    S.migrated = true;
+    return 0;
+}
+
 int bdrt_sampler_run(bdrt_sampler *s)
 {
     if (!s) return -1;
@@ -1424,6 +1515,7 @@ int bdrt_sampler_run(bdrt_sampler *s)
         int rc = bdrt_sampler_advance(s, S.rounds_default, &done);
         if (rc) return rc;
         spent += S.rounds_default;
+        if (!done && S.may_migrate && !S.migrated && (rc = maybe_migrate_tail(S))) return rc;
     }
     if (!done) { set_error("bdrt_sampler_run: chains did not finish within the leapfrog bound"); return -3; }
     return 0;
@@ -1451,6 +1543,8 @@ int bdrt_sampler_results(bdrt_sampler *s, double *draws, double *lp, bdrt_chain_
     }
     return 0;
 }
+
+int bdrt_sampler_tail_units(bdrt_sampler *s) { return s && s->impl.migrated ? s->impl.n_solo : 0; }
 
 int64_t bdrt_sampler_total_leapfrogs(bdrt_sampler *s)
 {

@@ -400,6 +400,10 @@ class Sampler:
     def total_leapfrogs(self):
         return int(self._lib.bdrt_sampler_total_leapfrogs(self.handle))
 
+    def tail_units(self):
+        """Chains that `run` handed from the 16-chain kernel to the one-chain-per-workgroup kernel for the tail (0: none)."""
+        return int(self._lib.bdrt_sampler_tail_units(self.handle))
+
     def kernel_time(self, reset=False):
         ms = C.c_double(); nl = C.c_int64()
         check(self._lib.bdrt_sampler_kernel_time(self.handle, C.byref(ms), C.byref(nl), int(reset)), 'bdrt_sampler_kernel_time')

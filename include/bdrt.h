@@ -172,6 +172,10 @@ int bdrt_sampler_sync(bdrt_sampler *s);
 int bdrt_sampler_run(bdrt_sampler *s);
 /* draws [n_units x n_draws x D] unconstrained; diag [n_units]; either may be NULL */
 int bdrt_sampler_results(bdrt_sampler *s, double *draws_unconstrained, double *lp, bdrt_chain_diag *diag);
+/* run to completion.  A run that starts on the 16-chains-per-workgroup kernel (more than four chains per CU) hands its last
+ * live chains to the one-chain-per-workgroup kernel once that finishes them sooner (BDRT_TAIL_MIGRATION=0 forbids it);
+ * bdrt_sampler_tail_units tells how many chains were handed over (0: none). */
+int bdrt_sampler_tail_units(bdrt_sampler *s);
 /* total leapfrogs executed so far, summed over chains (device counter) */
 int64_t bdrt_sampler_total_leapfrogs(bdrt_sampler *s);
 /* HIP-event time (ms) and launch count of the NUTS kernel accumulated since creation / last reset */
