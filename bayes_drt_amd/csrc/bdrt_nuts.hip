@@ -71,6 +71,7 @@ struct NutsArgs {
 };
 
 #include "bdrt_nuts_wide.h"
+#include "bdrt_solo_wide.h"
 
 // Thread mapping of the bookkeeping stages: chain c of the workgroup lives in ONE half-wave (wave c/2, lanes
 // 32*(c%2)..+31); its D-vectors are contiguous rows, lane l handles elements l, l+32, ...  Per-chain dot products are
@@ -1148,6 +1149,20 @@ __global__ __launch_bounds__(SOLO_NT) void solo_eval_kernel(const DevProblem *__
     if (tid == 0 && lp) lp[b] = *lps;
 }
 
+// the general one-chain evaluator (bdrt_solo_wide.h) on its own: one point per workgroup (tests)
+__global__ __launch_bounds__(SOLO_NT) void wide1_eval_kernel(const DevProblem *__restrict__ Pp, Wide1Geom G, const double *theta,
+                                                             const int *spec, int jacobian, double *lp, double *grad)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const DevProblem &P = *Pp;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    wide1_init(P, G, smem, tid);
+    const Wide1Regs er = wide1_setup(P, G, spec ? spec[b] : 0, tid);
+    __syncthreads();
+    wide1_eval(P, G, smem, theta + (size_t)b * P.D, grad + (size_t)b * P.D, lp + b, er, jacobian, tid);
+}
+
+
 // The tail of a large run.  The 16-chain kernel advances every live chain by one leapfrog per ~33 us whatever the number of
 // live chains; a run lasts as long as its longest chain (BASELINE config 4: 0.33 .. 0.98 M leapfrogs per chain), and in the
 // tail most tile columns are empty.  Once the number of live chains is below what the one-chain-per-workgroup kernel
@@ -1655,6 +1670,32 @@ int bdrt_debug_solo_logp_grad(bdrt_problem *p, const double *theta, const int *s
     if (e == hipSuccess && grad) e = hipMemcpy(grad, dg, nb, hipMemcpyDeviceToHost);
     hipFree(dth); hipFree(dg); hipFree(dlp); hipFree(dsp);
     if (e != hipSuccess) { set_error("bdrt_debug_solo_logp_grad: %s", hipGetErrorString(e)); return -10; }
+    return 0;
+}
+
+int bdrt_debug_wide1_logp_grad(bdrt_problem *p, const double *theta, const int *spec, int B, int jacobian, double *lp, double *grad)
+{
+    if (!p || !theta || B < 1) { set_error("bdrt_debug_wide1_logp_grad: bad arguments"); return -1; }
+    Problem &P = p->impl;
+    if (!wide1_capable(P.dev)) { set_error("problem does not take the general one-chain evaluator"); return -2; }
+    BDRT_HIP(hipSetDevice(P.device));
+    const Wide1Geom G = wide1_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D, P.dev.nblocks);
+    const size_t lds = (size_t)G.total * sizeof(double) + 64;
+    BDRT_HIP(hipFuncSetAttribute((const void *)wide1_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    double *dth = nullptr, *dlp = nullptr, *dg = nullptr;
+    int *dsp = nullptr;
+    const size_t nbytes = (size_t)B * P.dev.D * sizeof(double);
+    BDRT_HIP(hipMalloc((void **)&dth, nbytes)); BDRT_HIP(hipMalloc((void **)&dg, nbytes)); BDRT_HIP(hipMalloc((void **)&dlp, B * sizeof(double)));
+    BDRT_HIP(hipMemcpy(dth, theta, nbytes, hipMemcpyHostToDevice));
+    BDRT_HIP(hipMemset(dg, 0, nbytes));
+    if (spec) { BDRT_HIP(hipMalloc((void **)&dsp, B * sizeof(int))); BDRT_HIP(hipMemcpy(dsp, spec, B * sizeof(int), hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(wide1_eval_kernel, dim3(B), dim3(SOLO_NT), lds, 0, (const DevProblem *)P.d_dev, G, dth, dsp, jacobian, dlp, dg);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && lp) e = hipMemcpy(lp, dlp, B * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && grad) e = hipMemcpy(grad, dg, nbytes, hipMemcpyDeviceToHost);
+    hipFree(dth); hipFree(dg); hipFree(dlp); hipFree(dsp);
+    if (e != hipSuccess) { set_error("bdrt_debug_wide1_logp_grad: %s", hipGetErrorString(e)); return -10; }
     return 0;
 }
 

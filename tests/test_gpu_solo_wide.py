@@ -1,0 +1,79 @@
+"""GPU tests (-m gpu) of the general one-chain-per-workgroup path (bdrt_solo_wide.h): several distributions, parallel blocks,
+the outlier error model -- the reference's own call shape (2-4 chains) for BASELINE config 5."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.helpers import load
+
+pytestmark = pytest.mark.gpu
+
+
+def _family(name):
+    from bayes_drt_amd.engine import blocks_from_dat
+    if name == 'series_outliers':
+        from tests.test_gpu_engine import _bench_problem
+        blk, Z, f, kw, d = _bench_problem('sample', 'K161')
+        so = load('dat_sample_outlier_scalars')
+        kw = dict(kw, outlier_mode=1, so_lambda=float(so['sigma_out_lambda']), so_alpha=float(so['sigma_out_alpha']),
+                  so_beta=float(so['sigma_out_beta']))
+        return dict(blocks=[blk], Z=Z, freq=f, **kw)
+    if name == 'series_plain':
+        from tests.test_gpu_engine import _bench_problem
+        blk, Z, f, kw, d = _bench_problem('sample', 'K161')
+        return dict(blocks=[blk], Z=Z, freq=f, **kw)
+    if name in ('kat_2parallel', 'kat_series_parallel_outliers'):
+        # stored Stan fits of the reference: three blocks (series + two parallel) / two blocks with the stacked outlier model
+        from tests.helpers import kat_to_model
+        return kat_to_model({'kat_2parallel': 'DRT-TpDDT-BpDDT_uniform_0.25',
+                             'kat_series_parallel_outliers': 'PDAC_DRT-TpDDT_outliers'}[name])['kw']
+    dd = load('dat_sample_DRT-TpDDT_plain')
+    blocks, kw2, _ = blocks_from_dat('Series-Parallel_pos_StanModel.pkl', {k: dd[k] for k in dd.files})
+    if name == 'series_parallel_outliers':               # BASELINE config 5's model: the plain matrices + the outlier scalars
+        do = load('dat_sample_DRT-TpDDT_outliers')
+        kw2 = dict(kw2, outlier_mode=2, so_lambda=float(do['so_invscale']))
+    return dict(blocks=blocks, Z=dd['Z'], freq=dd['freq'], **kw2)
+
+
+def _wide1_logp_grad(prob, theta, jac):
+    lib = prob._lib
+    fn = lib.bdrt_debug_wide1_logp_grad
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    lp = np.empty(len(theta)); g = np.empty_like(theta)
+    rc = fn(prob.handle, theta.ctypes.data, None, len(theta), int(jac), lp.ctypes.data, g.ctypes.data)
+    if rc == -2:
+        return None, None                                  # the problem does not take this evaluator
+    assert rc == 0, lib.bdrt_last_error().decode()
+    return lp, g
+
+
+@pytest.mark.parametrize('family', ['series_plain', 'series_outliers', 'series_parallel', 'series_parallel_outliers',
+                                    'kat_2parallel', 'kat_series_parallel_outliers'])
+@pytest.mark.parametrize('jac', [True, False])
+def test_one_chain_evaluator_matches_the_batched_evaluator_and_the_oracle(family, jac):
+    from bayes_drt_amd.model import Problem
+    from oracle import oracle as orc
+    args = _family(family)
+    prob = Problem(**args)
+    om = orc.OracleModel(**args)
+    rng = np.random.default_rng(5)
+    theta = rng.uniform(-2, 2, (5, prob.D))
+    lp, g = _wide1_logp_grad(prob, theta, jac)
+    if family == 'kat_series_parallel_outliers':
+        # measured spectrum on its own frequency grid (106 points, K = 101): A is not Toeplitz, the 16-chain kernel keeps it
+        assert lp is None
+        prob.close()
+        return
+    lp16, g16 = prob.logp_grad(theta, jacobian=jac)
+    for i in range(len(theta)):
+        lp_ref, g_ref = om.logp_grad(theta[i], jac)
+        if not np.isfinite(lp_ref):
+            assert lp[i] == lp_ref
+            continue
+        assert abs(lp[i] - lp_ref) <= 1e-10 * max(1.0, abs(lp_ref)), (i, lp[i], lp_ref)
+        assert np.max(np.abs(g[i] - g_ref)) <= 1e-10 * max(1.0, np.max(np.abs(g_ref))), (i, np.argmax(np.abs(g[i] - g_ref)))
+    fin = np.isfinite(lp16)
+    assert np.allclose(lp[fin], lp16[fin], rtol=1e-11, atol=1e-9) and np.allclose(g[fin], g16[fin], rtol=1e-9, atol=1e-9)
+    prob.close()
