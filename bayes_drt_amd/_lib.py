@@ -69,7 +69,7 @@ SYMBOLS = [
     'bdrt_logp_grad', 'bdrt_logp_grad_dev', 'bdrt_transformed',
     'bdrt_opt_defaults', 'bdrt_optimize',
     'bdrt_nuts_defaults', 'bdrt_sampler_create', 'bdrt_sampler_destroy', 'bdrt_sampler_advance', 'bdrt_sampler_sync',
-    'bdrt_sampler_run', 'bdrt_sampler_results', 'bdrt_sampler_tail_units', 'bdrt_sampler_total_leapfrogs', 'bdrt_sampler_kernel_time',
+    'bdrt_sampler_run', 'bdrt_sampler_results', 'bdrt_sampler_tail_units', 'bdrt_sampler_kind', 'bdrt_sampler_total_leapfrogs', 'bdrt_sampler_kernel_time',
     'bdrt_sampler_phase_profile',
     'bdrt_sample',
     'bdrt_gram', 'bdrt_qp_box', 'bdrt_qp_box_batch', 'bdrt_ridge',
@@ -123,6 +123,8 @@ def load_library():
     lib.bdrt_sampler_run.argtypes = [vp]
     lib.bdrt_sampler_results.argtypes = [vp, vp, vp, vp]
     lib.bdrt_sampler_tail_units.argtypes = [vp]
+    lib.bdrt_sampler_kind.argtypes = [vp]
+    lib.bdrt_sampler_kind.restype = C.c_int
     lib.bdrt_sampler_tail_units.restype = C.c_int
     lib.bdrt_sampler_total_leapfrogs.argtypes = [vp]
     lib.bdrt_sampler_total_leapfrogs.restype = C.c_int64

@@ -1149,6 +1149,65 @@ __global__ __launch_bounds__(SOLO_NT) void solo_eval_kernel(const DevProblem *__
     if (tid == 0 && lp) lp[b] = *lps;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// One chain per workgroup, general block model (bdrt_solo_wide.h): the evaluation by 512 threads, everything after it by the
+// cooperative stage of bdrt_nuts_wide.h.  The chain's vectors stay in the 16-chain layout (column 0 of its workgroup's rows),
+// so the host side is the one of nuts_kernel with one chain per workgroup.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int W1_SCRATCH = 1600;                   // doubles of LDS for the cooperative stage (reductions, momentum normals)
+
+__global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, Wide1Geom G)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const DevProblem &P = *Pp;
+    const int tid = threadIdx.x;
+    const int wg = blockIdx.x, unit = wg;              // cpw == 1: unit u lives in column slot_col(0) = 0 of workgroup u
+    const int D = P.D, DS = a.ds;
+    double *scr = smem + G.total;
+    double *lpn = scr + W1_SCRATCH;
+    ChainState *sts = reinterpret_cast<ChainState *>(lpn + 2);
+    double *V = a.vecs + (size_t)wg * V_COUNT * NC * DS;
+    auto row = [&](int v) -> double * { return V + ((size_t)v * NC) * DS; };
+    const int TH2OFF = (V_TH2 - V_TH) * NC * DS;
+    if (tid == 0) sts[0] = a.states[unit];
+    wide1_init(P, G, smem, tid);
+    __syncthreads();
+    const Wide1Regs er = wide1_setup(P, G, sts[0].spec, tid);
+    if (!sts[0].kicked) {
+        // half kick + drift of the first evaluation of a freshly created sampler
+        const int ph = sts[0].phase;
+        const double e = ph == PH_EPS ? sts[0].eps : (ph == PH_TREE ? sts[0].dir * sts[0].eps : 0.0);
+        double *TH = row(V_TH), *Pm = row(V_P), *Gr = row(V_G), *MI = row(V_MINV);
+        if (ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)
+            for (int j = tid; j < D; j += SOLO_NT) {
+                const double p = Pm[j] + 0.5 * e * Gr[j];
+                Pm[j] = p;
+                TH[j] += e * MI[j] * p;
+            }
+        __syncthreads();
+        if (tid == 0) sts[0].kicked = 1;
+        __syncthreads();
+    }
+    WideCtx wx;
+    wx.P = Pp; wx.np = &np; wx.a = &a; wx.V = V; wx.smem = scr; wx.sts = sts; wx.lpn = lpn; wx.hvy = nullptr; wx.hvk = nullptr;
+    wx.prof = nullptr; wx.D = D; wx.DS = DS; wx.TH2OFF = TH2OFF; wx.c0 = unit; wx.nvalid = 1;
+    unsigned long long my_leaps = 0;
+    for (int round = 0; round < a.rounds; ++round) {
+        const int ph = sts[0].phase;
+        if (!(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)) break;
+        const double *TH = row(V_TH) + (sts[0].thsel ? TH2OFF : 0);
+        wide1_eval(P, G, smem, TH, row(V_G), lpn, er, 1, tid);
+        wide_coop_tail<2>(wx, 0, false, my_leaps, tid);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.states[unit] = sts[0];
+        if (my_leaps) atomicAdd(a.leap_counter, my_leaps);
+        const int ph = sts[0].phase;
+        if (!(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)) atomicAdd(a.done_counter, 1);
+    }
+}
+
 // the general one-chain evaluator (bdrt_solo_wide.h) on its own: one point per workgroup (tests)
 __global__ __launch_bounds__(SOLO_NT) void wide1_eval_kernel(const DevProblem *__restrict__ Pp, Wide1Geom G, const double *theta,
                                                              const int *spec, int jacobian, double *lp, double *grad)
@@ -1198,6 +1257,8 @@ struct Sampler {
     bool hw = false;         // general half-wave evaluator (MODE 4: several distributions, parallel blocks)
     bool solo = false;       // one chain per workgroup, state in LDS (bdrt_solo.h): few chains of the headline family
     SoloGeom geom;
+    bool wide1 = false;      // one chain per workgroup, general block model (bdrt_solo_wide.h): few chains of any other Toeplitz family
+    Wide1Geom geom1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double ms_total = 0.0;
@@ -1298,6 +1359,10 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     }
     S.n_wg = (n_units + S.args.cpw - 1) / S.args.cpw;
     S.D = P.dev.D;
+    // few chains of a model the LDS-resident kernel does not cover: still one chain per workgroup, evaluated by 512 threads
+    S.wide1 = !S.solo && S.args.cpw == 1 && wide1_capable(P.dev);
+    if (const char *e = getenv("BDRT_WIDE1")) S.wide1 = S.wide1 && atoi(e) != 0;                // diagnostics: forbid
+    if (S.wide1) S.geom1 = wide1_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D, P.dev.nblocks);
     S.np.warmup = warmup; S.np.n_draws = n_draws; S.np.max_depth = c.max_treedepth;
     S.np.delta = c.adapt_delta; S.np.gamma = c.adapt_gamma; S.np.t0 = c.adapt_t0; S.np.kappa = c.adapt_kappa;
     S.np.init_radius = c.init_radius; S.np.max_deltaH = c.max_deltaH; S.np.stepsize0 = c.stepsize0;
@@ -1313,6 +1378,8 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
                       3 * NC * sizeof(int) + 16;
     else
         S.lds_bytes = nuts_lds_bytes(P.dev, S.use_s1);
+    const size_t lds_wide1 = S.wide1 ? ((size_t)S.geom1.total + W1_SCRATCH + 2) * sizeof(double) + sizeof(ChainState) + 64 : 0;
+    if (S.wide1) S.lds_bytes = std::max(S.lds_bytes, lds_wide1);     // (one attribute value for every kernel; the launch asks for lds_wide1)
     auto fail = [&](const char *msg) -> bdrt_sampler * { set_error("%s", msg); bdrt_sampler_destroy(s); return nullptr; };
     if (S.lds_bytes > 160 * 1024) return fail("bdrt_sampler_create: problem too large for the 160 KiB LDS budget");
     for (int u = 0; u < n_units; ++u)
@@ -1386,6 +1453,8 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
                                (const void *)nuts_kernel<11, 3>, (const void *)nuts_kernel<16, 3>,
                                (const void *)nuts_kernel<11, 4>, (const void *)nuts_kernel<16, 4>, (const void *)nuts_kernel<27, 4>};
         hipError_t e = hipFuncSetAttribute((const void *)nuts_solo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)nuts_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         for (int i = 0; i < 13 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         return e;
@@ -1434,7 +1503,11 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             if (tp) hipLaunchKernelGGL((nuts_kernel<NJV, 1>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args); \
             else hipLaunchKernelGGL((nuts_kernel<NJV, 0>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);   \
         } while (0)
-        if (S.solo)
+        if (S.wide1)
+            hipLaunchKernelGGL(nuts_wide1_kernel, dim3(S.n_wg), dim3(SOLO_NT),
+                               ((size_t)S.geom1.total + W1_SCRATCH + 2) * sizeof(double) + sizeof(ChainState) + 64, S.stream, dp, S.np, S.args,
+                               S.geom1);
+        else if (S.solo)
             hipLaunchKernelGGL(nuts_solo_kernel, dim3(S.n_solo), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
         else if (S.use_s1 && S.D <= 32 * 11)
             hipLaunchKernelGGL((nuts_kernel<11, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
@@ -1560,6 +1633,7 @@ int bdrt_sampler_results(bdrt_sampler *s, double *draws, double *lp, bdrt_chain_
 }
 
 int bdrt_sampler_tail_units(bdrt_sampler *s) { return s && s->impl.migrated ? s->impl.n_solo : 0; }
+int bdrt_sampler_kind(bdrt_sampler *s) { return !s ? -1 : (s->impl.wide1 ? 2 : (s->impl.solo ? 1 : 0)); }
 
 int64_t bdrt_sampler_total_leapfrogs(bdrt_sampler *s)
 {

@@ -400,6 +400,11 @@ class Sampler:
     def total_leapfrogs(self):
         return int(self._lib.bdrt_sampler_total_leapfrogs(self.handle))
 
+    def kind(self):
+        """0: sixteen chains per workgroup, 1: one chain per workgroup with its state in LDS, 2: one chain per workgroup,
+        general block model."""
+        return int(self._lib.bdrt_sampler_kind(self.handle))
+
     def tail_units(self):
         """Chains that `run` handed from the 16-chain kernel to the one-chain-per-workgroup kernel for the tail (0: none)."""
         return int(self._lib.bdrt_sampler_tail_units(self.handle))

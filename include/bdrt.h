@@ -176,6 +176,10 @@ int bdrt_sampler_results(bdrt_sampler *s, double *draws_unconstrained, double *l
  * live chains to the one-chain-per-workgroup kernel once that finishes them sooner (BDRT_TAIL_MIGRATION=0 forbids it);
  * bdrt_sampler_tail_units tells how many chains were handed over (0: none). */
 int bdrt_sampler_tail_units(bdrt_sampler *s);
+/* which kernel advances the chains now: 0 sixteen chains per workgroup (bdrt_nuts.hip), 1 one chain per workgroup with its
+ * state in LDS (bdrt_solo.h: few chains of the single-DRT family), 2 one chain per workgroup, general block model
+ * (bdrt_solo_wide.h: few chains of any other model on log-uniform grids) */
+int bdrt_sampler_kind(bdrt_sampler *s);
 /* total leapfrogs executed so far, summed over chains (device counter) */
 int64_t bdrt_sampler_total_leapfrogs(bdrt_sampler *s);
 /* HIP-event time (ms) and launch count of the NUTS kernel accumulated since creation / last reset */

@@ -252,10 +252,14 @@ def test_batched_map_of_many_spectra_equals_single_fits(n_spectra):
         assert np.array_equal(one[0], allx[i]) and r1[0]['newton_iterations'] == rep[i]['newton_iterations']
 
 
+@pytest.mark.parametrize('kernel', ['one_chain_per_workgroup', 'sixteen_chains'])
 @pytest.mark.parametrize('family', ['series_outliers_K161', 'series_parallel_2block', 'series_K192_Nf96', 'series_K161_Nf107'])
-def test_nuts_matches_oracle_on_the_wide_parameter_vectors(family):
+def test_nuts_matches_oracle_on_the_wide_parameter_vectors(family, kernel, monkeypatch):
     """The sampler kernels for 352 < D <= 512 and D > 512 (outlier error model: D = 493; two blocks of 161: D = 656) against the
-    recursive oracle: identical tree shapes, draws equal to summation-order noise (short runs)."""
+    recursive oracle: identical tree shapes, draws equal to summation-order noise (short runs).  Three chains would take the
+    one-chain-per-workgroup kernels (bdrt_solo.h / bdrt_solo_wide.h); `sixteen_chains` keeps them on the 16-chain kernel."""
+    if kernel == 'sixteen_chains':
+        monkeypatch.setenv('BDRT_WIDE1', '0'); monkeypatch.setenv('BDRT_SOLO', '0')
     from bayes_drt_amd.model import Problem
     from bayes_drt_amd.engine import sample_units
     from oracle import oracle as orc
@@ -293,7 +297,7 @@ def test_nuts_matches_oracle_on_the_wide_parameter_vectors(family):
         assert np.all(err < 1e-6), err
 
 
-@pytest.mark.parametrize('tile,seed', [('half_wave', 13), ('half_wave', 11), ('generic', 13)])
+@pytest.mark.parametrize('tile,seed', [('half_wave', 13), ('half_wave', 11), ('generic', 13), ('one_chain', 13), ('one_chain', 11)])
 def test_wide_path_long_run_matches_oracle(tile, seed, monkeypatch):
     """The wide-vector sampler path (D = 656: the chain's own pass + the cooperative phase of bdrt_nuts_wide.h) through
     everything a real run meets: trees up to depth 7 (leaves that merge more than four levels go to the cooperative phase),
@@ -305,6 +309,7 @@ def test_wide_path_long_run_matches_oracle(tile, seed, monkeypatch):
     from bayes_drt_amd.engine import sample_units, blocks_from_dat
     from oracle import oracle as orc
     if tile == 'generic': monkeypatch.setenv('BDRT_GENERIC_TILE', '1')
+    if tile != 'one_chain': monkeypatch.setenv('BDRT_WIDE1', '0')       # three chains: else the kernel of bdrt_solo_wide.h
     dd = load('dat_sample_DRT-TpDDT_plain')
     blocks, kw2, _ = blocks_from_dat('Series-Parallel_pos_StanModel.pkl', {k: dd[k] for k in dd.files})
     args = dict(blocks=blocks, Z=dd['Z'], freq=dd['freq'], **kw2)

@@ -77,3 +77,31 @@ def test_one_chain_evaluator_matches_the_batched_evaluator_and_the_oracle(family
     fin = np.isfinite(lp16)
     assert np.allclose(lp[fin], lp16[fin], rtol=1e-11, atol=1e-9) and np.allclose(g[fin], g16[fin], rtol=1e-9, atol=1e-9)
     prob.close()
+
+
+@pytest.mark.parametrize('family', ['series_parallel_outliers', 'kat_2parallel', 'series_outliers'])
+def test_few_chains_take_the_one_chain_kernel_and_equal_the_16_chain_kernel(family, monkeypatch):
+    """Four chains of a multi-distribution / outlier model run on the kernel of bdrt_solo_wide.h: bit-identical across launch
+    slicing, and the same chains as on the 16-chain kernel (BDRT_WIDE1=0) up to summation order."""
+    from bayes_drt_amd.engine import Sampler
+    from bayes_drt_amd.model import Problem
+    from bayes_drt_amd._lib import NutsControl
+    prob = Problem(**_family(family))
+    ctrl = NutsControl(); prob._lib.bdrt_nuts_defaults(C.byref(ctrl)); ctrl.max_treedepth = 6
+
+    def run(slice_rounds):
+        with Sampler(prob, 4, 10, 6, 21, ctrl) as smp:
+            kind = smp.kind()
+            smp.run(slice_rounds)
+            return smp.results() + (kind,)
+
+    d_a, lp_a, g_a, kind_a = run(None)
+    d_b, lp_b, g_b, kind_b = run(13)
+    assert kind_a == 2 and kind_b == 2
+    assert np.array_equal(d_a, d_b) and np.array_equal(lp_a, lp_b)
+    monkeypatch.setenv('BDRT_WIDE1', '0')
+    d_c, lp_c, g_c, kind_c = run(None)
+    assert kind_c == 0
+    assert [x['n_leapfrog'] for x in g_a] == [x['n_leapfrog'] for x in g_c]
+    assert np.max(np.abs(d_a - d_c)) <= 1e-6 * np.max(np.abs(d_c))
+    prob.close()
