@@ -392,7 +392,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             {
                 WideCtx wx;
                 wx.P = Pp; wx.np = &np; wx.a = &a; wx.V = V; wx.smem = smem; wx.sts = sts; wx.lpn = lpn; wx.hvy = hvy; wx.hvk = hvk;
-                wx.prof = io.prof; wx.D = D; wx.DS = DS; wx.TH2OFF = TH2OFF; wx.c0 = c0; wx.nvalid = nvalid;
+                wx.prof = io.prof; wx.D = D; wx.DS = DS; wx.TH2OFF = TH2OFF; wx.c0 = c0; wx.nvalid = nvalid; wx.ncol = NC;
                 for (int hc = 0; hc < NC; ++hc) {
                     const int kind = hvy[hc];
                     if (kind) wide_coop_tail<(NJ * 32 + WIDE_NT - 1) / WIDE_NT>(wx, hc, kind == 2, my_leaps, tid);
@@ -1151,8 +1151,7 @@ __global__ __launch_bounds__(SOLO_NT) void solo_eval_kernel(const DevProblem *__
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // One chain per workgroup, general block model (bdrt_solo_wide.h): the evaluation by 512 threads, everything after it by the
-// cooperative stage of bdrt_nuts_wide.h.  The chain's vectors stay in the 16-chain layout (column 0 of its workgroup's rows),
-// so the host side is the one of nuts_kernel with one chain per workgroup.
+// cooperative stage of bdrt_nuts_wide.h.  Global state layout: vecs [n_units][V_COUNT][ds] (the rows of nuts_kernel, one column).
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int W1_SCRATCH = 1600;                   // doubles of LDS for the cooperative stage (reductions, momentum normals)
 
@@ -1161,14 +1160,14 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevProblem &P = *Pp;
     const int tid = threadIdx.x;
-    const int wg = blockIdx.x, unit = wg;              // cpw == 1: unit u lives in column slot_col(0) = 0 of workgroup u
+    const int wg = blockIdx.x, unit = wg;
     const int D = P.D, DS = a.ds;
     double *scr = smem + G.total;
     double *lpn = scr + W1_SCRATCH;
     ChainState *sts = reinterpret_cast<ChainState *>(lpn + 2);
-    double *V = a.vecs + (size_t)wg * V_COUNT * NC * DS;
-    auto row = [&](int v) -> double * { return V + ((size_t)v * NC) * DS; };
-    const int TH2OFF = (V_TH2 - V_TH) * NC * DS;
+    double *V = a.vecs + (size_t)wg * V_COUNT * DS;       // this chain's rows [V_COUNT][ds]
+    auto row = [&](int v) -> double * { return V + (size_t)v * DS; };
+    const int TH2OFF = (V_TH2 - V_TH) * DS;
     if (tid == 0) sts[0] = a.states[unit];
     wide1_init(P, G, smem, tid);
     __syncthreads();
@@ -1190,7 +1189,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
     }
     WideCtx wx;
     wx.P = Pp; wx.np = &np; wx.a = &a; wx.V = V; wx.smem = scr; wx.sts = sts; wx.lpn = lpn; wx.hvy = nullptr; wx.hvk = nullptr;
-    wx.prof = nullptr; wx.D = D; wx.DS = DS; wx.TH2OFF = TH2OFF; wx.c0 = unit; wx.nvalid = 1;
+    wx.prof = nullptr; wx.D = D; wx.DS = DS; wx.TH2OFF = TH2OFF; wx.c0 = unit; wx.nvalid = 1; wx.ncol = 1;
     unsigned long long my_leaps = 0;
     for (int round = 0; round < a.rounds; ++round) {
         const int ph = sts[0].phase;
@@ -1360,9 +1359,13 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     S.n_wg = (n_units + S.args.cpw - 1) / S.args.cpw;
     S.D = P.dev.D;
     // few chains of a model the LDS-resident kernel does not cover: still one chain per workgroup, evaluated by 512 threads
-    S.wide1 = !S.solo && S.args.cpw == 1 && wide1_capable(P.dev);
+    S.wide1 = !S.solo && n_units <= (5 * n_cu) / 2 && wide1_capable(P.dev);     // (measured at D = 818: 10.6 M evals/s from 256 units on; the 16-chain kernel passes that at ~700)
     if (const char *e = getenv("BDRT_WIDE1")) S.wide1 = S.wide1 && atoi(e) != 0;                // diagnostics: forbid
-    if (S.wide1) S.geom1 = wide1_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D, P.dev.nblocks);
+    if (getenv("BDRT_CHAINS_PER_WG")) S.wide1 = false;                                          // (a forced packing means the 16-chain kernel)
+    if (S.wide1) {
+        S.geom1 = wide1_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D, P.dev.nblocks);
+        S.args.cpw = 1; S.n_wg = n_units;
+    }
     S.np.warmup = warmup; S.np.n_draws = n_draws; S.np.max_depth = c.max_treedepth;
     S.np.delta = c.adapt_delta; S.np.gamma = c.adapt_gamma; S.np.t0 = c.adapt_t0; S.np.kappa = c.adapt_kappa;
     S.np.init_radius = c.init_radius; S.np.max_deltaH = c.max_deltaH; S.np.stepsize0 = c.stepsize0;
@@ -1389,7 +1392,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     const int DS = S.solo ? S.geom.DSS : (S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : 32 * 27));
     if (S.D > 32 * 27) { set_error("bdrt_sampler_create: D = %d > 864 not supported", S.D); bdrt_sampler_destroy(s); return nullptr; }
     S.args.ds = DS;
-    const int ncol = S.solo ? 1 : NC, nrow = S.solo ? (int)SG_COUNT : (int)V_COUNT;
+    const int ncol = (S.solo || S.wide1) ? 1 : NC, nrow = S.solo ? (int)SG_COUNT : (int)V_COUNT;
     const int r_minv = S.solo ? (int)SV_MINV : (int)V_MINV, r_th = S.solo ? (int)SV_TH : (int)V_TH;
     if (S.solo) S.lds_bytes = (size_t)S.geom.total * sizeof(double) + 64;
     const size_t nvec = (size_t)S.n_wg * nrow * ncol * DS;
@@ -1406,7 +1409,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         st.dir = 1;
         st.lsw_sub = -INFINITY;
         window_init(st, warmup, c.init_buffer, c.term_buffer, c.base_window);
-        const int wg = u / S.args.cpw, cc = S.solo ? 0 : slot_col(u % S.args.cpw);
+        const int wg = u / S.args.cpw, cc = (S.solo || S.wide1) ? 0 : slot_col(u % S.args.cpw);
         double *V = hv.data() + (size_t)wg * nrow * ncol * DS;
         const Philox rng = {S.np.seed_lo, S.np.seed_hi, (uint32_t)st.chain_id};
         for (int j = 0; j < S.D; ++j) {
@@ -1418,7 +1421,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         if (!init_theta) st.init_attempt = 0;
     }
     // unused columns (cpw < 16, last workgroup): finite placeholders
-    for (int wg = 0; wg < S.n_wg && !S.solo; ++wg)
+    for (int wg = 0; wg < S.n_wg && !S.solo && !S.wide1; ++wg)
         for (int k = 0; k < NC; ++k) {
             if (k < S.args.cpw && wg * S.args.cpw + k < n_units) continue;
             double *V = hv.data() + (size_t)wg * V_COUNT * NC * DS;

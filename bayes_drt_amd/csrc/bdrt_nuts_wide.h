@@ -31,6 +31,7 @@ struct WideCtx {
     const double *hvk;      // [NC][2] LDS: kinetic energy / non-finite gradient count of the kind-2 chains
     long long *prof;        // optional cycle counters (slots 10..16: stages of the cooperative phase, thread 0)
     int D, DS, TH2OFF, c0, nvalid;
+    int ncol;               // columns of the row layout: V[(v * ncol + column) * DS] (16; 1 for the one-chain kernel of bdrt_solo_wide.h)
 };
 
 // sums over the workgroup of N per-thread values (fixed order: lanes by the wave reduction, then waves 0..7); every thread
@@ -72,7 +73,7 @@ __device__ inline void wide_coop_tail(const WideCtx &x, int hc, bool c_done, uns
 #define BDRT_WIDE_PROF(slot) do { if (x.prof && tid == 0) { const long long t_ = clock64(); x.prof[slot] += t_ - tw_; tw_ = t_; } } while (0)
     ChainState s = x.sts[hc];
     const Philox rng = {np.seed_lo, np.seed_hi, (uint32_t)s.chain_id};
-    auto row = [&](int v) -> double * { return x.V + ((size_t)v * NC + hc) * DS; };
+    auto row = [&](int v) -> double * { return x.V + ((size_t)v * x.ncol + hc) * DS; };
     const int kslot = col_slot(hc);
     const bool valid = kslot < x.nvalid;
     const int unit = x.c0 + kslot;
