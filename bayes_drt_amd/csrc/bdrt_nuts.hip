@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevProblem &P = *Pp;
     const int tid = threadIdx.x;
-    const int wg = blockIdx.x, unit = wg;
+    const int wg = blockIdx.x, unit = a.unit_map ? a.unit_map[wg] : wg;
     const int D = P.D, DS = a.ds;
     double *scr = smem + G.total;
     double *lpn = scr + W1_SCRATCH;
@@ -1244,6 +1244,18 @@ __global__ void nuts_migrate_kernel(const double *v16, int ds16, int cpw, const 
     }
 }
 static_assert(SOLO_MAXD == MAXD, "the two kernels keep the same number of checkpoint levels");
+
+// the same hand-over for the models of the general one-chain kernel (bdrt_solo_wide.h): rows keep their meaning, the chain's
+// column of [wg][V_*][16][ds] becomes [slot][V_*][ds]
+__global__ void nuts_migrate_wide1_kernel(const double *v16, int ds, int cpw, const int *unit_map, double *v1)
+{
+    const int slot = blockIdx.x, u = unit_map[slot];
+    const int wg = u / cpw, col = slot_col(u % cpw);
+    const double *src = v16 + (size_t)wg * V_COUNT * NC * ds;
+    double *dst = v1 + (size_t)slot * V_COUNT * ds;
+    for (int v = 0; v < V_COUNT; ++v)
+        for (int j = threadIdx.x; j < ds; j += blockDim.x) dst[(size_t)v * ds + j] = src[((size_t)v * NC + col) * ds + j];
+}
 
 struct Sampler {
     Problem *prob = nullptr;
@@ -1343,12 +1355,13 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     S.solo = solo_capable(P.dev) && n_units <= 4 * n_cu;
     S.n_cu = n_cu;
     // a run that starts on the 16-chain kernel may hand its last live chains to the one-chain-per-workgroup kernel
-    S.may_migrate = solo_capable(P.dev) && !S.solo;
+    S.may_migrate = (solo_capable(P.dev) || wide1_capable(P.dev)) && !S.solo;
     if (const char *e = getenv("BDRT_SOLO")) {                                                  // diagnostics: force / forbid
         S.solo = solo_capable(P.dev) && atoi(e) != 0;
         S.may_migrate = false;
     }
     if (const char *e = getenv("BDRT_TAIL_MIGRATION")) S.may_migrate = S.may_migrate && atoi(e) != 0;
+    if (getenv("BDRT_WIDE1") && atoi(getenv("BDRT_WIDE1")) == 0 && !solo_capable(P.dev)) S.may_migrate = false;
     if (S.solo) S.geom = solo_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
     // chains per workgroup: fill every CU with one workgroup before putting a second chain on any wave
     {
@@ -1365,6 +1378,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     if (S.wide1) {
         S.geom1 = wide1_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D, P.dev.nblocks);
         S.args.cpw = 1; S.n_wg = n_units;
+        S.may_migrate = false;
     }
     S.np.warmup = warmup; S.np.n_draws = n_draws; S.np.max_depth = c.max_treedepth;
     S.np.delta = c.adapt_delta; S.np.gamma = c.adapt_gamma; S.np.t0 = c.adapt_t0; S.np.kappa = c.adapt_kappa;
@@ -1558,14 +1572,42 @@ static int maybe_migrate_tail(Sampler &S)
 {
     int active = 0;
     BDRT_HIP(hipMemcpy(&active, S.d_active, sizeof(int), hipMemcpyDeviceToHost));
-    // the one-chain kernel runs one chain per CU at a time, 4x faster per leapfrog: it wins below ~4 live chains per CU
-    if (active <= 0 || active > (7 * S.n_cu) / 2) return 0;
+    // the one-chain kernels run one chain per CU at a time, ~4x faster per leapfrog: the LDS-resident one wins below ~4 live
+    // chains per CU, the general one below ~2.5
+    const bool to_solo = solo_capable(S.prob->dev);
+    if (active <= 0 || active > (to_solo ? (7 * S.n_cu) / 2 : (5 * S.n_cu) / 2)) return 0;
     std::vector<ChainState> hs((size_t)S.n_units);
     BDRT_HIP(hipMemcpy(hs.data(), S.args.states, hs.size() * sizeof(ChainState), hipMemcpyDeviceToHost));
     std::vector<int> map;
     for (int u = 0; u < S.n_units; ++u)
         if (hs[u].phase == PH_INIT || hs[u].phase == PH_EPS || hs[u].phase == PH_TREE) map.push_back(u);
     if (map.empty()) return 0;
+    if (!to_solo) {
+        // general one-chain kernel: the 16-chain rows, one column
+        const Wide1Geom G = wide1_geometry(S.prob->dev.nf, S.prob->dev.blk[0].K, S.prob->dev.D, S.prob->dev.nblocks);
+        const size_t lds1 = ((size_t)G.total + W1_SCRATCH + 2) * sizeof(double) + sizeof(ChainState) + 64;
+        if (lds1 > S.lds_bytes) return 0;
+        double *v1 = nullptr;
+        int *dmap1 = nullptr;
+        if (hipMalloc((void **)&v1, map.size() * (size_t)V_COUNT * S.args.ds * sizeof(double)) != hipSuccess) return 0;
+        if (hipMalloc((void **)&dmap1, map.size() * sizeof(int)) != hipSuccess) { hipFree(v1); return 0; }
+        BDRT_HIP(hipMemcpy(dmap1, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(nuts_migrate_wide1_kernel, dim3((unsigned)map.size()), dim3(256), 0, S.stream, (const double *)S.args.vecs, S.args.ds,
+                           S.args.cpw, (const int *)dmap1, v1);
+        BDRT_HIP(hipGetLastError());
+        BDRT_HIP(hipStreamSynchronize(S.stream));
+        S.vecs16 = S.args.vecs;
+        S.args.prof = nullptr;
+        S.args.vecs = v1;
+        S.d_unit_map = dmap1;
+        S.args.unit_map = dmap1;
+        S.geom1 = G;
+        S.wide1 = true;
+        S.n_solo = (int)map.size();
+        S.n_wg = S.n_solo;
+        S.migrated = true;
+        return 0;
+    }
     const SoloGeom g = solo_geometry(S.prob->dev.nf, S.prob->dev.blk[0].K, S.prob->dev.D);
     const size_t lds = (size_t)g.total * sizeof(double) + 64;
     if (lds > S.lds_bytes) return 0;                      // (bdrt_sampler_create raised every kernel's LDS limit to the 16-chain size)
