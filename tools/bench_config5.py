@@ -42,6 +42,9 @@ print('config 5 (%s, D=%d, %d units): %.2f M evals/s, %.1f us per round' % (inv.
       (n1 - n0) / (t1 - t0) / 1e6, (t1 - t0) / 600 * 1e6))
 if prof:
     cyc = (C.c_longlong * 32)(); check(lib.bdrt_sampler_phase_profile(h, 0, cyc), 'prof')
+    if lib.bdrt_sampler_kind(h) == 2:                             # one-chain-per-workgroup kernel (bdrt_solo_wide.h)
+        print('ONE-CHAIN KERNEL: evaluation %.0f cycles/round, stages after it %.0f' % (cyc[0] / n_units / 600, cyc[1] / n_units / 600))
+        lib.bdrt_sampler_destroy(h); sys.exit(0)
     nwg = (n_units + 15) // 16
     wr = nwg * 600 * 8                                            # wave-rounds
     # wide-vector kernels (D > 512): per-wave averages of the round's stages (bdrt_nuts.hip, bdrt_nuts_wide.h)
