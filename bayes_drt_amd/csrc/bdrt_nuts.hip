@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
         const double *TH = row(V_TH) + (sts[0].thsel ? TH2OFF : 0);
         long long *prof = a.prof ? a.prof + (size_t)wg * 32 : nullptr;       // slots 0 / 1: evaluation / everything after it (thread 0)
         const long long t0 = (prof && tid == 0) ? clock64() : 0;
-        wide1_eval(P, G, smem, TH, row(V_G), lpn, er, 1, tid);
+        wide1_eval(P, G, smem, TH, row(V_G), lpn, er, 1, tid, prof);
         const long long t1 = (prof && tid == 0) ? clock64() : 0;
         wide_coop_tail<2>(wx, 0, false, my_leaps, tid);
         __syncthreads();

@@ -95,8 +95,11 @@ __device__ __forceinline__ void wide1_init(const DevProblem &P, const Wide1Geom 
 // log-posterior + gradient at theta (global row TH) -> gradient to the global row GR, lp to *lp_out (LDS or global).
 // All 512 threads call; ends with a __syncthreads().
 __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, double *lds, const double *__restrict__ TH,
-                                  double *__restrict__ GR, double *lp_out, const Wide1Regs &er, int jacobian, int tid)
+                                  double *__restrict__ GR, double *lp_out, const Wide1Regs &er, int jacobian, int tid,
+                                  long long *prof = nullptr)
 {
+    long long tprev = (prof && tid == 0) ? clock64() : 0;
+#define BDRT_W1_PROF(slot) do { if (prof && tid == 0) { const long long t_ = clock64(); prof[slot] += t_ - tprev; tprev = t_; } } while (0)
     const SoloGeom &g = G.g;
     const int lane = tid & 63, wave = tid >> 6;
     const int nf = g.nf, K = g.K, nb = G.nb;
@@ -143,6 +146,7 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             us[2 + tid] = uu;
         }
         __syncthreads();
+        BDRT_W1_PROF(2);
         // ---- forward product partials; prior chain x -> L x -> w
         {
             const int part = er.fpart, rg = er.frg;
@@ -196,6 +200,7 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             if (lane == 0) { ered[wave * 32 + 8 + 3 * b] = a; ered[wave * 32 + 9 + 3 * b] = c; ered[wave * 32 + 10 + 3 * b] = d; }
         }
         __syncthreads();
+        BDRT_W1_PROF(3);
         // ---- Y_b = sum of the partials (threads n < nf: both halves); backward convolutions sum_i L_i^T w_i (threads CONV0 + k)
         if (tid < nf) {
             const int n = tid, st = 4 * g.RG;
@@ -217,6 +222,7 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             }
         }
         __syncthreads();
+        BDRT_W1_PROF(4);
     }
 
     // ================================================= x_sum prior, likelihood ===================================================
@@ -302,6 +308,7 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
         scv[24] = term; scv[25] = lpx; scv[26] = rej;
     }
     __syncthreads();
+    BDRT_W1_PROF(5);
     const double xs_term = scv[24];
 
     // ================================================= backward, block by block ==================================================
@@ -325,6 +332,7 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             rop[n] = rr; rop[g.NFP + n] = ri;
         }
         __syncthreads();
+        BDRT_W1_PROF(6);
         {
             const int part = er.bpart, mg = er.bmg;
             if (part < g.NPB) {
@@ -336,6 +344,7 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             }
         }
         __syncthreads();
+        BDRT_W1_PROF(7);
         if (tid < K) {
             double graw = gls[b * g.XL + tid] + xs_term;
             const int st = 4 * g.MG;
@@ -344,6 +353,7 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             GR[B.o_ups + tid] = gupv[b];
         }
         __syncthreads();                                   // (the next block's partials reuse zp)
+        BDRT_W1_PROF(8);
     }
 
     // ---- scalar gradients, lp ----------------------------------------------------------------------------------------------------
@@ -375,4 +385,6 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
         *lp_out = scv[26] != 0.0 ? -INFINITY : s;
     }
     __syncthreads();
+    BDRT_W1_PROF(9);
+#undef BDRT_W1_PROF
 }

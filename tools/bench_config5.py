@@ -44,6 +44,8 @@ if prof:
     cyc = (C.c_longlong * 32)(); check(lib.bdrt_sampler_phase_profile(h, 0, cyc), 'prof')
     if lib.bdrt_sampler_kind(h) == 2:                             # one-chain-per-workgroup kernel (bdrt_solo_wide.h)
         print('ONE-CHAIN KERNEL: evaluation %.0f cycles/round, stages after it %.0f' % (cyc[0] / n_units / 600, cyc[1] / n_units / 600))
+        print('   evaluation phases (all blocks): constrain %.0f, products + prior %.0f, sums + L^T w %.0f, likelihood %.0f, operand %.0f, '
+              'transposed products %.0f, chain rule %.0f, scalars + lp %.0f' % tuple(cyc[k] / n_units / 600 for k in range(2, 10)))
         lib.bdrt_sampler_destroy(h); sys.exit(0)
     nwg = (n_units + 15) // 16
     wr = nwg * 600 * 8                                            # wave-rounds
