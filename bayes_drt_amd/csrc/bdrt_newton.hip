@@ -398,7 +398,6 @@ __global__ __launch_bounds__(256) void newton_accept_kernel(NewtonBufs b, const 
     if (S.done) return;
     __shared__ double red[256];
     __shared__ int s_acc, s_t;
-    __shared__ double s_ginf;
     double *x = b.x + (size_t)f * D, *g = b.g + (size_t)f * D;
     if (tid == 0) { s_acc = 0; s_t = 0; S.n_evals += NW_TRY; }
     __syncthreads();
@@ -438,7 +437,7 @@ __global__ __launch_bounds__(256) void newton_accept_kernel(NewtonBufs b, const 
                 if (ginf < S.tol) { S.rc = 0; S.done = 1; }
                 else if (S.iters >= S.max_iter) { S.rc = 1; S.done = 1; }
                 else S.need_hess = 1;
-                s_acc = 1; s_t = t; s_ginf = ginf;
+                s_acc = 1; s_t = t;
             }
         }
         __syncthreads();
