@@ -392,7 +392,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             {
                 WideCtx wx;
                 wx.P = Pp; wx.np = &np; wx.a = &a; wx.V = V; wx.smem = smem; wx.sts = sts; wx.lpn = lpn; wx.hvy = hvy; wx.hvk = hvk;
-                wx.prof = io.prof; wx.D = D; wx.DS = DS; wx.TH2OFF = TH2OFF; wx.c0 = c0; wx.nvalid = nvalid; wx.ncol = NC;
+                wx.prof = io.prof; wx.D = D; wx.DS = DS; wx.TH2OFF = TH2OFF; wx.c0 = c0; wx.nvalid = nvalid; wx.ncol = NC; wx.hot_base = nullptr; wx.hot_slot = nullptr;
                 for (int hc = 0; hc < NC; ++hc) {
                     const int kind = hvy[hc];
                     if (kind) wide_coop_tail<(NJ * 32 + WIDE_NT - 1) / WIDE_NT>(wx, hc, kind == 2, my_leaps, tid);
@@ -1154,8 +1154,17 @@ __global__ __launch_bounds__(SOLO_NT) void solo_eval_kernel(const DevProblem *__
 // cooperative stage of bdrt_nuts_wide.h.  Global state layout: vecs [n_units][V_COUNT][ds] (the rows of nuts_kernel, one column).
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int W1_SCRATCH = 1600;                   // doubles of LDS for the cooperative stage (reductions, momentum normals)
+// rows of the chain kept in LDS for the launch, most used first (as many as fit: `nhot`): a plain leaf then touches HBM only
+// for the trajectory ends / higher checkpoint levels it rarely needs
+__device__ __constant__ signed char W1_HOT_ORDER[12] = {V_TH, V_P, V_G, V_MINV, V_CKP, V_THQ, V_GQ, V_CKP + 1, V_CKC + 1, V_CKP + 2, V_CKC + 2, V_RHO};
+constexpr int W1_HOT_MAX = 12;
 
-__global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, Wide1Geom G)
+__host__ __device__ inline size_t wide1_lds_bytes(const Wide1Geom &G, int ds, int nhot)
+{
+    return ((size_t)G.total + W1_SCRATCH + 2 + (size_t)nhot * ds) * sizeof(double) + sizeof(ChainState) + 64 + 64;
+}
+
+__global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, Wide1Geom G, int nhot)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevProblem &P = *Pp;
@@ -1164,12 +1173,23 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
     const int D = P.D, DS = a.ds;
     double *scr = smem + G.total;
     double *lpn = scr + W1_SCRATCH;
-    ChainState *sts = reinterpret_cast<ChainState *>(lpn + 2);
+    double *hot = lpn + 2;                                 // [nhot][ds]
+    ChainState *sts = reinterpret_cast<ChainState *>(hot + (size_t)nhot * DS);
+    signed char *hslot = reinterpret_cast<signed char *>(sts + 1);      // [V_COUNT] (64 bytes)
     double *V = a.vecs + (size_t)wg * V_COUNT * DS;       // this chain's rows [V_COUNT][ds]
-    auto row = [&](int v) -> double * { return V + (size_t)v * DS; };
-    const int TH2OFF = (V_TH2 - V_TH) * DS;
+    auto grow = [&](int v) -> double * { return V + (size_t)v * DS; };                                    // the row in HBM
+    auto row = [&](int v) -> double * { const int h = hslot[v]; return h >= 0 ? hot + (size_t)h * DS : grow(v); };
     if (tid == 0) sts[0] = a.states[unit];
+    if (tid < V_COUNT) {
+        int h = -1;
+        for (int k = 0; k < nhot; ++k) if (W1_HOT_ORDER[k] == tid) h = k;
+        hslot[tid] = (signed char)h;
+    }
     wide1_init(P, G, smem, tid);
+    for (int k = 0; k < nhot; ++k) {
+        const double *src = grow(W1_HOT_ORDER[k]);
+        for (int j = tid; j < DS; j += SOLO_NT) hot[(size_t)k * DS + j] = src[j];
+    }
     __syncthreads();
     const Wide1Regs er = wide1_setup(P, G, sts[0].spec, tid);
     if (!sts[0].kicked) {
@@ -1189,19 +1209,25 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
     }
     WideCtx wx;
     wx.P = Pp; wx.np = &np; wx.a = &a; wx.V = V; wx.smem = scr; wx.sts = sts; wx.lpn = lpn; wx.hvy = nullptr; wx.hvk = nullptr;
-    wx.prof = nullptr; wx.D = D; wx.DS = DS; wx.TH2OFF = TH2OFF; wx.c0 = unit; wx.nvalid = 1; wx.ncol = 1;
+    wx.prof = nullptr; wx.D = D; wx.DS = DS; wx.TH2OFF = 0; wx.c0 = unit; wx.nvalid = 1; wx.ncol = 1;
+    wx.hot_base = hot; wx.hot_slot = hslot;
     unsigned long long my_leaps = 0;
     for (int round = 0; round < a.rounds; ++round) {
         const int ph = sts[0].phase;
         if (!(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)) break;
-        const double *TH = row(V_TH) + (sts[0].thsel ? TH2OFF : 0);
         long long *prof = a.prof ? a.prof + (size_t)wg * 32 : nullptr;       // slots 0 / 1: evaluation / everything after it (thread 0)
         const long long t0 = (prof && tid == 0) ? clock64() : 0;
-        wide1_eval(P, G, smem, TH, row(V_G), lpn, er, 1, tid, prof);
+        wide1_eval(P, G, smem, row(V_TH), row(V_G), lpn, er, 1, tid, prof);
         const long long t1 = (prof && tid == 0) ? clock64() : 0;
-        wide_coop_tail<2>(wx, 0, false, my_leaps, tid);
+        wx.prof = prof ? prof + 16 : nullptr;                                // (slots 25, 27..31: the stages of the cooperative tail)
+        wide_coop_tail<2, true>(wx, 0, false, my_leaps, tid);
         __syncthreads();
         if (prof && tid == 0) { prof[0] += t1 - t0; prof[1] += clock64() - t1; }
+    }
+    // the LDS-resident rows go back to the chain's HBM rows
+    for (int k = 0; k < nhot; ++k) {
+        double *dst = grow(W1_HOT_ORDER[k]);
+        for (int j = tid; j < DS; j += SOLO_NT) dst[j] = hot[(size_t)k * DS + j];
     }
     if (tid == 0) {
         a.states[unit] = sts[0];
@@ -1251,14 +1277,19 @@ static_assert(SOLO_MAXD == MAXD, "the two kernels keep the same number of checkp
 
 // the same hand-over for the models of the general one-chain kernel (bdrt_solo_wide.h): rows keep their meaning, the chain's
 // column of [wg][V_*][16][ds] becomes [slot][V_*][ds]
-__global__ void nuts_migrate_wide1_kernel(const double *v16, int ds, int cpw, const int *unit_map, double *v1)
+__global__ void nuts_migrate_wide1_kernel(const double *v16, int ds, int cpw, const int *unit_map, double *v1, ChainState *states)
 {
     const int slot = blockIdx.x, u = unit_map[slot];
     const int wg = u / cpw, col = slot_col(u % cpw);
     const double *src = v16 + (size_t)wg * V_COUNT * NC * ds;
     double *dst = v1 + (size_t)slot * V_COUNT * ds;
-    for (int v = 0; v < V_COUNT; ++v)
-        for (int j = threadIdx.x; j < ds; j += blockDim.x) dst[(size_t)v * ds + j] = src[((size_t)v * NC + col) * ds + j];
+    const int live = states[u].thsel ? V_TH2 : V_TH;       // the one-chain kernel keeps theta in V_TH
+    for (int v = 0; v < V_COUNT; ++v) {
+        const int sv = v == V_TH ? live : v;
+        for (int j = threadIdx.x; j < ds; j += blockDim.x) dst[(size_t)v * ds + j] = src[((size_t)sv * NC + col) * ds + j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) states[u].thsel = 0;
 }
 
 struct Sampler {
@@ -1274,6 +1305,7 @@ struct Sampler {
     SoloGeom geom;
     bool wide1 = false;      // one chain per workgroup, general block model (bdrt_solo_wide.h): few chains of any other Toeplitz family
     Wide1Geom geom1;
+    int nhot1 = 0;           // rows of the chain that kernel keeps in LDS
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double ms_total = 0.0;
@@ -1291,6 +1323,14 @@ struct Sampler {
     int *d_unit_map = nullptr;
     int n_solo = 0;                   // workgroups of the one-chain-per-workgroup kernel (= n_units unless migrated)
 };
+
+// as many LDS-resident rows as fit beside the evaluator (160 KiB minus a margin)
+static int wide1_hot_rows(const Wide1Geom &G, int ds)
+{
+    int n = W1_HOT_MAX;
+    while (n > 0 && wide1_lds_bytes(G, ds, n) > 158 * 1024) --n;
+    return n;
+}
 
 static size_t nuts_lds_bytes(const DevProblem &P, bool s1)
 {
@@ -1376,7 +1416,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     S.n_wg = (n_units + S.args.cpw - 1) / S.args.cpw;
     S.D = P.dev.D;
     // few chains of a model the LDS-resident kernel does not cover: still one chain per workgroup, evaluated by 512 threads
-    S.wide1 = !S.solo && n_units <= (5 * n_cu) / 2 && wide1_capable(P.dev);     // (measured at D = 818: 10.6 M evals/s from 256 units on; the 16-chain kernel passes that at ~700)
+    S.wide1 = !S.solo && n_units <= (11 * n_cu) / 4 && wide1_capable(P.dev);    // (measured at D = 818: 12.7 M evals/s from 256 units on; the 16-chain kernel passes that at ~750)
     if (const char *e = getenv("BDRT_WIDE1")) S.wide1 = S.wide1 && atoi(e) != 0;                // diagnostics: forbid
     if (getenv("BDRT_CHAINS_PER_WG")) S.wide1 = false;                                          // (a forced packing means the 16-chain kernel)
     if (S.wide1) {
@@ -1399,8 +1439,11 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
                       3 * NC * sizeof(int) + 16;
     else
         S.lds_bytes = nuts_lds_bytes(P.dev, S.use_s1);
-    const size_t lds_wide1 = S.wide1 ? ((size_t)S.geom1.total + W1_SCRATCH + 2) * sizeof(double) + sizeof(ChainState) + 64 : 0;
-    if (S.wide1) S.lds_bytes = std::max(S.lds_bytes, lds_wide1);     // (one attribute value for every kernel; the launch asks for lds_wide1)
+    if (S.wide1) {
+        const int ds1 = S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : 32 * 27);
+        S.nhot1 = wide1_hot_rows(S.geom1, ds1);
+        S.lds_bytes = std::max(S.lds_bytes, wide1_lds_bytes(S.geom1, ds1, S.nhot1));     // (one attribute value for every kernel)
+    }
     auto fail = [&](const char *msg) -> bdrt_sampler * { set_error("%s", msg); bdrt_sampler_destroy(s); return nullptr; };
     if (S.lds_bytes > 160 * 1024) return fail("bdrt_sampler_create: problem too large for the 160 KiB LDS budget");
     for (int u = 0; u < n_units; ++u)
@@ -1525,9 +1568,8 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             else hipLaunchKernelGGL((nuts_kernel<NJV, 0>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);   \
         } while (0)
         if (S.wide1)
-            hipLaunchKernelGGL(nuts_wide1_kernel, dim3(S.n_wg), dim3(SOLO_NT),
-                               ((size_t)S.geom1.total + W1_SCRATCH + 2) * sizeof(double) + sizeof(ChainState) + 64, S.stream, dp, S.np, S.args,
-                               S.geom1);
+            hipLaunchKernelGGL(nuts_wide1_kernel, dim3(S.n_wg), dim3(SOLO_NT), wide1_lds_bytes(S.geom1, S.args.ds, S.nhot1), S.stream, dp,
+                               S.np, S.args, S.geom1, S.nhot1);
         else if (S.solo)
             hipLaunchKernelGGL(nuts_solo_kernel, dim3(S.n_solo), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
         else if (S.use_s1 && S.D <= 32 * 11)
@@ -1579,7 +1621,7 @@ static int maybe_migrate_tail(Sampler &S)
     // the one-chain kernels run one chain per CU at a time, ~4x faster per leapfrog: the LDS-resident one wins below ~4 live
     // chains per CU, the general one below ~2.5
     const bool to_solo = solo_capable(S.prob->dev);
-    if (active <= 0 || active > (to_solo ? (7 * S.n_cu) / 2 : (5 * S.n_cu) / 2)) return 0;
+    if (active <= 0 || active > (to_solo ? (7 * S.n_cu) / 2 : (11 * S.n_cu) / 4)) return 0;
     std::vector<ChainState> hs((size_t)S.n_units);
     BDRT_HIP(hipMemcpy(hs.data(), S.args.states, hs.size() * sizeof(ChainState), hipMemcpyDeviceToHost));
     std::vector<int> map;
@@ -1589,15 +1631,16 @@ static int maybe_migrate_tail(Sampler &S)
     if (!to_solo) {
         // general one-chain kernel: the 16-chain rows, one column
         const Wide1Geom G = wide1_geometry(S.prob->dev.nf, S.prob->dev.blk[0].K, S.prob->dev.D, S.prob->dev.nblocks);
-        const size_t lds1 = ((size_t)G.total + W1_SCRATCH + 2) * sizeof(double) + sizeof(ChainState) + 64;
-        if (lds1 > S.lds_bytes) return 0;
+        int nhot = W1_HOT_MAX;                                // as many LDS-resident rows as the LDS limit set at creation allows
+        while (nhot > 0 && wide1_lds_bytes(G, S.args.ds, nhot) > std::min(S.lds_bytes, (size_t)158 * 1024)) --nhot;
+        if (wide1_lds_bytes(G, S.args.ds, nhot) > S.lds_bytes) return 0;
         double *v1 = nullptr;
         int *dmap1 = nullptr;
         if (hipMalloc((void **)&v1, map.size() * (size_t)V_COUNT * S.args.ds * sizeof(double)) != hipSuccess) return 0;
         if (hipMalloc((void **)&dmap1, map.size() * sizeof(int)) != hipSuccess) { hipFree(v1); return 0; }
         BDRT_HIP(hipMemcpy(dmap1, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(nuts_migrate_wide1_kernel, dim3((unsigned)map.size()), dim3(256), 0, S.stream, (const double *)S.args.vecs, S.args.ds,
-                           S.args.cpw, (const int *)dmap1, v1);
+                           S.args.cpw, (const int *)dmap1, v1, S.args.states);
         BDRT_HIP(hipGetLastError());
         BDRT_HIP(hipStreamSynchronize(S.stream));
         S.vecs16 = S.args.vecs;
@@ -1606,6 +1649,7 @@ static int maybe_migrate_tail(Sampler &S)
         S.d_unit_map = dmap1;
         S.args.unit_map = dmap1;
         S.geom1 = G;
+        S.nhot1 = nhot;
         S.wide1 = true;
         S.n_solo = (int)map.size();
         S.n_wg = S.n_solo;

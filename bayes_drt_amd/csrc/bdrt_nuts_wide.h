@@ -32,6 +32,9 @@ struct WideCtx {
     long long *prof;        // optional cycle counters (slots 10..16: stages of the cooperative phase, thread 0)
     int D, DS, TH2OFF, c0, nvalid;
     int ncol;               // columns of the row layout: V[(v * ncol + column) * DS] (16; 1 for the one-chain kernel of bdrt_solo_wide.h)
+    // one-chain kernel (HOT = true): rows of the chain that live in LDS for the launch -- hot_slot[v] >= 0: hot_base + slot * DS
+    double *hot_base;
+    const signed char *hot_slot;
 };
 
 // sums over the workgroup of N per-thread values (fixed order: lanes by the wave reduction, then waves 0..7); every thread
@@ -63,7 +66,7 @@ template <int N>
 __device__ inline void wide_block_sum(double (&v)[N], double *scr, int tid) { wide_block_sum<N>(v, N, scr, tid); }
 
 // Finish the round of chain (column) hc.  All threads of the workgroup must call with the same arguments.
-template <int NJX>          // elements per thread: D <= 512 * NJX
+template <int NJX, bool HOT = false>   // NJX elements per thread: D <= 512 * NJX; HOT: some rows of the chain are in LDS (WideCtx::hot_slot)
 __device__ inline void wide_coop_tail(const WideCtx &x, int hc, bool c_done, unsigned long long &my_leaps, int tid)
 {
     const NutsParams &np = *x.np;
@@ -73,7 +76,10 @@ __device__ inline void wide_coop_tail(const WideCtx &x, int hc, bool c_done, uns
 #define BDRT_WIDE_PROF(slot) do { if (x.prof && tid == 0) { const long long t_ = clock64(); x.prof[slot] += t_ - tw_; tw_ = t_; } } while (0)
     ChainState s = x.sts[hc];
     const Philox rng = {np.seed_lo, np.seed_hi, (uint32_t)s.chain_id};
-    auto row = [&](int v) -> double * { return x.V + ((size_t)v * x.ncol + hc) * DS; };
+    auto row = [&](int v) -> double * {
+        if constexpr (HOT) { const int h = x.hot_slot[v]; if (h >= 0) return x.hot_base + (size_t)h * DS; }
+        return x.V + ((size_t)v * x.ncol + hc) * DS;
+    };
     const int kslot = col_slot(hc);
     const bool valid = kslot < x.nvalid;
     const int unit = x.c0 + kslot;

@@ -108,14 +108,14 @@ def test_few_chains_take_the_one_chain_kernel_and_equal_the_16_chain_kernel(fami
 
 
 def test_tail_of_a_large_run_of_a_general_model_moves_to_the_one_chain_kernel(monkeypatch):
-    """More than 2.5 chains per CU of the config 5 model start on the 16-chain kernel; `bdrt_sampler_run` hands the last live
+    """More than 2.75 chains per CU of the config 5 model start on the 16-chain kernel; `bdrt_sampler_run` hands the last live
     chains to the kernel of bdrt_solo_wide.h.  The run equals the one without the hand-over chain by chain."""
     from bayes_drt_amd.engine import Sampler
     from bayes_drt_amd.model import Problem
     from bayes_drt_amd._lib import NutsControl
     prob = Problem(**_family('series_parallel_outliers'))
     ctrl = NutsControl(); prob._lib.bdrt_nuts_defaults(C.byref(ctrl)); ctrl.max_treedepth = 5
-    n_units = 720
+    n_units = 900
 
     def run():
         with Sampler(prob, n_units, 16, 8, 3, ctrl) as smp:
@@ -124,7 +124,7 @@ def test_tail_of_a_large_run_of_a_general_model_moves_to_the_one_chain_kernel(mo
             return smp.results() + (kind0, smp.kind(), smp.tail_units())
 
     d1, lp1, g1, k0, k1, tail1 = run()
-    assert k0 == 0 and k1 == 2 and 0 < tail1 <= 640, (k0, k1, tail1)
+    assert k0 == 0 and k1 == 2 and 0 < tail1 <= 704, (k0, k1, tail1)
     monkeypatch.setenv('BDRT_TAIL_MIGRATION', '0')
     d0, lp0, g0, k0b, k1b, tail0 = run()
     assert k1b == 0 and tail0 == 0

@@ -46,6 +46,8 @@ if prof:
         print('ONE-CHAIN KERNEL: evaluation %.0f cycles/round, stages after it %.0f' % (cyc[0] / n_units / 600, cyc[1] / n_units / 600))
         print('   evaluation phases (all blocks): constrain %.0f, products + prior %.0f, sums + L^T w %.0f, likelihood %.0f, operand %.0f, '
               'transposed products %.0f, chain rule %.0f, scalars + lp %.0f' % tuple(cyc[k] / n_units / 600 for k in range(2, 10)))
+        print('   stages after it: first trip + reduction %.0f, scalar logic %.0f, checkpoint / subtree close %.0f, transition end + continue %.0f, '
+              'sample / new start %.0f' % tuple(cyc[k] / n_units / 600 for k in (25, 27, 28, 29, 30)))
         lib.bdrt_sampler_destroy(h); sys.exit(0)
     nwg = (n_units + 15) // 16
     wr = nwg * 600 * 8                                            # wave-rounds
