@@ -126,13 +126,11 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
     for (int b = 0; b < W1_MAXB; ++b) { xv[b] = 0.0; gupv[b] = 0.0; }
 
     // ================================================= forward, block by block ===================================================
-#pragma unroll
-    for (int b = 0; b < W1_MAXB; ++b) {
-        if (b >= nb) break;
+    // Phases (one barrier each): [constrain block 0] -> for every block: [products + prior chain] -> [Y_b sums + L^T w of the
+    // block + constrain of the NEXT block]; the last block's sums and L^T w ride on the likelihood phase.
+    double tu = 0.0, uu = 0.0;                             // theta_ups / ups of this thread's k in the block being constrained
+    auto constrain = [&](int b) {
         const DevBlock &B = P.blk[b];
-        const double *gen = lds + G.o_gen + b * 2 * 4 * g.GQ;
-        // ---- constrained parameters of the block
-        double tu = 0.0, uu = 0.0;
         if (tid < K) {
             const double tx = TH[B.o_x + tid];
             tu = TH[B.o_ups + tid];
@@ -145,8 +143,42 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             xs[MAXBW + tid] = x * B.x_scale;               // xp = xp_raw * xp_scale (1 for series blocks)
             us[2 + tid] = uu;
         }
-        __syncthreads();
-        BDRT_W1_PROF(2);
+    };
+    auto conv_lt = [&](int b) {                            // sum_i L_i^T w_i of block b (threads CONV0 + k)
+        const DevBlock &B = P.blk[b];
+        const int kc = tid - SOLO_CONV0;
+        if (kc >= 0 && kc < K) {
+            double gl = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double *wi = wr + i * g.XL;
+#pragma unroll
+                for (int d = 0; d < 2 * MAXBW + 1; ++d) gl = fma(B.T[i][d], wi[kc + 2 * MAXBW - d], gl);   // w_i[kc + MAXBW - d]
+            }
+            gls[b * g.XL + kc] = gl;
+        }
+    };
+    auto sum_partials = [&](int n, double &yr, double &yi) {       // Y_b[n] from the partial sums of the current product
+        const int st = 4 * g.RG;
+        double r_[16], i_[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {                     // all loads first: one LDS round trip, not one per part
+            const int pp = p < g.NP ? p : 0;
+            r_[p] = zp[pp * st + n]; i_[p] = zp[pp * st + 4 * g.RGb + n];
+        }
+        yr = 0.0; yi = 0.0;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) if (p < g.NP) { yr += r_[p]; yi += i_[p]; }
+        for (int p = 16; p < g.NP; ++p) { yr += zp[p * st + n]; yi += zp[p * st + 4 * g.RGb + n]; }
+    };
+    constrain(0);
+    __syncthreads();
+    BDRT_W1_PROF(2);
+#pragma unroll
+    for (int b = 0; b < W1_MAXB; ++b) {
+        if (b >= nb) break;
+        const DevBlock &B = P.blk[b];
+        const double *gen = lds + G.o_gen + b * 2 * 4 * g.GQ;
         // ---- forward product partials; prior chain x -> L x -> w
         {
             const int part = er.fpart, rg = er.frg;
@@ -201,28 +233,18 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
         }
         __syncthreads();
         BDRT_W1_PROF(3);
-        // ---- Y_b = sum of the partials (threads n < nf: both halves); backward convolutions sum_i L_i^T w_i (threads CONV0 + k)
-        if (tid < nf) {
-            const int n = tid, st = 4 * g.RG;
-            double yr = 0.0, yi = 0.0;
-            for (int p = 0; p < g.NP; ++p) { yr += zp[p * st + n]; yi += zp[p * st + 4 * g.RGb + n]; }
-            yb[b * 2 * g.NFP + n] = yr; yb[b * 2 * g.NFP + g.NFP + n] = yi;
-        }
-        {
-            const int kc = tid - SOLO_CONV0;
-            if (kc >= 0 && kc < K) {
-                double gl = 0.0;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const double *wi = wr + i * g.XL;
-#pragma unroll
-                    for (int d = 0; d < 2 * MAXBW + 1; ++d) gl = fma(B.T[i][d], wi[kc + 2 * MAXBW - d], gl);   // w_i[kc + MAXBW - d]
-                }
-                gls[b * g.XL + kc] = gl;
+        if (b + 1 < nb) {
+            // ---- Y_b (threads n < nf: both halves), L^T w of this block, and the next block's constrained parameters
+            if (tid < nf) {
+                double yr, yi;
+                sum_partials(tid, yr, yi);
+                yb[b * 2 * g.NFP + tid] = yr; yb[b * 2 * g.NFP + g.NFP + tid] = yi;
             }
+            conv_lt(b);
+            constrain(b + 1);
+            __syncthreads();
+            BDRT_W1_PROF(4);
         }
-        __syncthreads();
-        BDRT_W1_PROF(4);
     }
 
     // ================================================= x_sum prior, likelihood ===================================================
@@ -230,10 +252,16 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
         const double wx = solo_wave_sum(xsum_p);
         if (lane == 0) ered[wave * 32 + 20] = wx;
     }
+    conv_lt(nb - 1);                                       // (the last block's L^T w: threads CONV0 + k, beside the likelihood threads)
     {
         double sR = 0, sL = 0, sH = 0, sHz2 = 0, sHzr2 = 0, sHzi2 = 0;
         if (tid < nf) {
             const int n = tid;
+            {   // Y of the last block: this thread sums its partials itself
+                double yr, yi;
+                sum_partials(n, yr, yi);
+                yb[(nb - 1) * 2 * g.NFP + n] = yr; yb[(nb - 1) * 2 * g.NFP + g.NFP + n] = yi;
+            }
             double zr = 0.0, zi = 0.0;
 #pragma unroll
             for (int b = 0; b < W1_MAXB; ++b) {
@@ -293,23 +321,20 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
         }
     }
     __syncthreads();
-    // x_sum ~ std_normal(), real<lower=0> x_sum_raw (Series-Parallel model code): one thread; the term enters every d lp / d x
-    if (tid == 0) {
+    BDRT_W1_PROF(5);
+    // x_sum ~ std_normal(), real<lower=0> x_sum_raw (Series-Parallel model code): the term enters every d lp / d x, so every
+    // thread adds up the eight wave partials itself
+    double xs_term = 0.0, lpx = 0.0;
+    bool rej = false;
+    if (P.use_x_sum) {
         double xs_raw = 0.0;
 #pragma unroll
         for (int w = 0; w < SOLO_NW; ++w) xs_raw += ered[w * 32 + 20];
-        double term = 0.0, lpx = 0.0, rej = 0.0;
-        if (P.use_x_sum) {
-            const double xsn = xs_raw * P.x_sum_invscale;
-            lpx = -0.5 * xsn * xsn;
-            rej = xs_raw < 0.0 ? 1.0 : 0.0;
-            term = -xs_raw * P.x_sum_invscale * P.x_sum_invscale;
-        }
-        scv[24] = term; scv[25] = lpx; scv[26] = rej;
+        const double xsn = xs_raw * P.x_sum_invscale;
+        lpx = -0.5 * xsn * xsn;
+        rej = xs_raw < 0.0;
+        xs_term = -xs_raw * P.x_sum_invscale * P.x_sum_invscale;
     }
-    __syncthreads();
-    BDRT_W1_PROF(5);
-    const double xs_term = scv[24];
 
     // ================================================= backward, block by block ==================================================
 #pragma unroll
@@ -379,10 +404,10 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
     }
     __syncthreads();
     if (tid == 0) {
-        double s = scv[25];
+        double s = lpx;
 #pragma unroll
         for (int w = 0; w < SOLO_NW; ++w) s += ered[w * 32 + 21];
-        *lp_out = scv[26] != 0.0 ? -INFINITY : s;
+        *lp_out = rej ? -INFINITY : s;
     }
     __syncthreads();
     BDRT_W1_PROF(9);
