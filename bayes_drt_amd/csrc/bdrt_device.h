@@ -51,6 +51,9 @@ struct DevBlock {
     // A_re and A_im exactly Toeplitz (log-uniform frequency and tau grids, reference matrices.py:197-205): their generators
     // [2][nf + K - 1], tg[b][n - m + K - 1] = A_b[n][m]; nullptr otherwise.  Used by the one-chain-per-workgroup path.
     const double *tg;
+    // otherwise (measured spectra on their own frequency grid): plain copies of A for the one-chain-per-workgroup path,
+    // Ad [2 nf][K] row-major (A^T r reads four consecutive columns) and At [K][2 nf] (A x reads four consecutive rows)
+    const double *Ad, *At;
 };
 
 struct DevProblem {

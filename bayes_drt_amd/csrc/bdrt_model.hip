@@ -165,6 +165,13 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
             }
             B.tg = nullptr;
             if (tz && (rc = upload(P, tgv, &B.tg))) return rc;
+            B.Ad = nullptr; B.At = nullptr;
+            if (!tz) {
+                std::vector<double> ad((size_t)N2 * K), at((size_t)K * N2);
+                for (int r = 0; r < N2; ++r)
+                    for (int m = 0; m < K; ++m) { ad[(size_t)r * K + m] = A[(size_t)r * K + m]; at[(size_t)m * N2 + r] = A[(size_t)r * K + m]; }
+                if ((rc = upload(P, ad, &B.Ad)) || (rc = upload(P, at, &B.At))) return rc;
+            }
         }
         // banded-Toeplitz detection of L0, L1, L2 (log-uniform tau grids): every entry outside the band
         // is below 1e-19 of the largest entry and every diagonal is constant to 1e-12 relative.  The dense MFMA path

@@ -52,7 +52,7 @@ inline bool wide1_capable(const DevProblem &P)
     const int K = P.blk[0].K;
     if (K < 2 * MAXBW + 3 || K > 192) return false;
     for (int b = 0; b < P.nblocks; ++b)
-        if (P.blk[b].K != K || P.blk[b].tg == nullptr || !P.blk[b].toep) return false;
+        if (P.blk[b].K != K || !P.blk[b].toep || (P.blk[b].tg == nullptr && (P.blk[b].Ad == nullptr || P.blk[b].At == nullptr))) return false;
     return (size_t)wide1_geometry(P.nf, K, P.D, P.nblocks).total * sizeof(double) + 4096 <= 160 * 1024;
 }
 
@@ -88,7 +88,38 @@ __device__ __forceinline__ void wide1_init(const DevProblem &P, const Wide1Geom 
         const int e = 4 * q + rho;                                                   // logical index: n - m + S
         const int src = e - g.S + g.K - 1;
         const double *tg = P.blk[blk].tg;                                            // [2][nf + K - 1]: c_h[n - m + K - 1]
-        lds[G.o_gen + i] = (src >= 0 && src < glen) ? tg[(size_t)h * glen + src] : 0.0;
+        lds[G.o_gen + i] = (tg && src >= 0 && src < glen) ? tg[(size_t)h * glen + src] : 0.0;
+    }
+}
+
+// dense counterparts of solo_toeplitz4 for a block whose A is not Toeplitz (read from L2):
+//   forward  acc[i] += sum_t At[(m0 + t) * N2 + r0 + i] * v[t]   (rows r0 .. r0+3 of one half, `rows_left` of them exist; columns < K)
+//   backward acc[i] += sum_t Ad[(r0 + t) * K + m0 + i] * v[t]    (columns m0 .. m0+3 < K; `rows_left` rows of the half exist)
+__device__ __forceinline__ void wide1_dense_fwd(const double *__restrict__ At, int N2, int r0, int rows_left, int m0, int K,
+                                                const double *v, int len, double (&acc)[4])
+{
+    const bool e0 = rows_left > 0, e1 = rows_left > 1, e2 = rows_left > 2, e3 = rows_left > 3;
+#pragma unroll 4
+    for (int t = 0; t < len; ++t) {
+        const int m = m0 + t;
+        if (m >= K) break;
+        const double *a = At + (size_t)m * N2 + r0;
+        const double x = v[t];
+        acc[0] = fma(e0 ? a[0] : 0.0, x, acc[0]); acc[1] = fma(e1 ? a[1] : 0.0, x, acc[1]);
+        acc[2] = fma(e2 ? a[2] : 0.0, x, acc[2]); acc[3] = fma(e3 ? a[3] : 0.0, x, acc[3]);
+    }
+}
+__device__ __forceinline__ void wide1_dense_bwd(const double *__restrict__ Ad, int K, int r0, int rows_left, int m0,
+                                                const double *v, int len, double (&acc)[4])
+{
+    const bool e0 = m0 < K, e1 = m0 + 1 < K, e2 = m0 + 2 < K, e3 = m0 + 3 < K;
+#pragma unroll 4
+    for (int t = 0; t < len; ++t) {
+        if (t >= rows_left) break;
+        const double *a = Ad + (size_t)(r0 + t) * K + m0;
+        const double x = v[t];
+        acc[0] = fma(e0 ? a[0] : 0.0, x, acc[0]); acc[1] = fma(e1 ? a[1] : 0.0, x, acc[1]);
+        acc[2] = fma(e2 ? a[2] : 0.0, x, acc[2]); acc[3] = fma(e3 ? a[3] : 0.0, x, acc[3]);
     }
 }
 
@@ -185,7 +216,8 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             if (part < g.NP) {
                 const int h = rg >= g.RGb, n0 = 4 * (rg - h * g.RGb), m0 = part * g.ML;
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
-                solo_toeplitz4<1>(gen + h * 4 * g.GQ, g.GQ, n0 - m0 + g.S, xs + MAXBW + m0, g.ML, acc);
+                if (B.tg) solo_toeplitz4<1>(gen + h * 4 * g.GQ, g.GQ, n0 - m0 + g.S, xs + MAXBW + m0, g.ML, acc);
+                else wide1_dense_fwd(B.At, 2 * nf, h * nf + n0, nf - n0, m0, K, xs + MAXBW + m0, g.ML, acc);
                 double *o = zp + part * (4 * g.RG) + 4 * rg;
                 o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
             }
@@ -363,7 +395,8 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             if (part < g.NPB) {
                 const int half = g.NPB / 2, h = part >= half, pp = part - h * half, n0 = pp * g.NL, m0 = 4 * mg;
                 double acc[4] = {0.0, 0.0, 0.0, 0.0};
-                solo_toeplitz4<-1>(gen + h * 4 * g.GQ, g.GQ, n0 - m0 + g.S, rop + h * g.NFP + n0, g.NL, acc);
+                if (B.tg) solo_toeplitz4<-1>(gen + h * 4 * g.GQ, g.GQ, n0 - m0 + g.S, rop + h * g.NFP + n0, g.NL, acc);
+                else wide1_dense_bwd(B.Ad, K, h * nf + n0, nf - n0, m0, rop + h * g.NFP + n0, g.NL, acc);
                 double *o = zp + part * (4 * g.MG) + 4 * mg;
                 o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
             }

@@ -23,6 +23,23 @@ def _family(name):
         from tests.test_gpu_engine import _bench_problem
         blk, Z, f, kw, d = _bench_problem('sample', 'K161')
         return dict(blocks=[blk], Z=Z, freq=f, **kw)
+    if name == 'series_irregular_frequencies':
+        # a single DRT whose measurement frequencies are not log-uniform (an instrument's rounded list): A is a general
+        # matrix (construct_A's quadrature path), L stays banded Toeplitz
+        from bayes_drt_amd import matrices as gm
+        rng = np.random.default_rng(11)
+        nf, K = 67, 121
+        f = np.sort(np.logspace(5.5, -1.5, nf) * np.exp(0.08 * rng.standard_normal(nf)))[::-1]
+        bf = np.logspace(7.5, -3.5, K)
+        tau = 1 / (2 * np.pi * bf)
+        eps = 1 / np.mean(np.diff(np.log(tau)))
+        A = np.vstack([gm.construct_A(f, 'real', tau=tau, epsilon=eps), gm.construct_A(f, 'imag', tau=tau, epsilon=eps)])
+        L = [gm.construct_L(bf, tau=tau, epsilon=eps, order=o) for o in (0, 1, 2)]
+        x = np.exp(-0.5 * ((np.log(tau) + 5) / 1.2) ** 2)
+        Z = A @ x + np.concatenate([np.full(nf, 0.4), np.zeros(nf)])
+        Z = Z / np.std(np.hypot(Z[:nf], Z[nf:])) + 0.01 * rng.standard_normal(2 * nf)
+        return dict(blocks=[dict(A=A, L0=L[0], L1=L[1], L2=0.75 * L[2], nonneg=True)], Z=Z, freq=f, sigma_min=0.002,
+                    ups_alpha=1.0, ups_beta=0.1, induc_scale=1.0)
     if name in ('kat_2parallel', 'kat_series_parallel_outliers'):
         # stored Stan fits of the reference: three blocks (series + two parallel) / two blocks with the stacked outlier model
         from tests.helpers import kat_to_model
@@ -50,7 +67,7 @@ def _wide1_logp_grad(prob, theta, jac):
 
 
 @pytest.mark.parametrize('family', ['series_plain', 'series_outliers', 'series_parallel', 'series_parallel_outliers',
-                                    'kat_2parallel', 'kat_series_parallel_outliers'])
+                                    'kat_2parallel', 'kat_series_parallel_outliers', 'series_irregular_frequencies'])
 @pytest.mark.parametrize('jac', [True, False])
 def test_one_chain_evaluator_matches_the_batched_evaluator_and_the_oracle(family, jac):
     from bayes_drt_amd.model import Problem
@@ -61,11 +78,9 @@ def test_one_chain_evaluator_matches_the_batched_evaluator_and_the_oracle(family
     rng = np.random.default_rng(5)
     theta = rng.uniform(-2, 2, (5, prob.D))
     lp, g = _wide1_logp_grad(prob, theta, jac)
-    if family == 'kat_series_parallel_outliers':
-        # measured spectrum on its own frequency grid (106 points, K = 101): A is not Toeplitz, the 16-chain kernel keeps it
-        assert lp is None
-        prob.close()
-        return
+    # ('kat_series_parallel_outliers': a measured spectrum on its own frequency grid, 106 points, K = 101 -- A is not Toeplitz
+    #  and the evaluator reads plain copies of it instead of generators)
+    assert lp is not None
     lp16, g16 = prob.logp_grad(theta, jacobian=jac)
     for i in range(len(theta)):
         lp_ref, g_ref = om.logp_grad(theta[i], jac)
@@ -79,7 +94,8 @@ def test_one_chain_evaluator_matches_the_batched_evaluator_and_the_oracle(family
     prob.close()
 
 
-@pytest.mark.parametrize('family', ['series_parallel_outliers', 'kat_2parallel', 'series_outliers'])
+@pytest.mark.parametrize('family', ['series_parallel_outliers', 'kat_2parallel', 'series_outliers', 'series_irregular_frequencies',
+                                    'kat_series_parallel_outliers'])
 def test_few_chains_take_the_one_chain_kernel_and_equal_the_16_chain_kernel(family, monkeypatch):
     """Four chains of a multi-distribution / outlier model run on the kernel of bdrt_solo_wide.h: bit-identical across launch
     slicing, and the same chains as on the 16-chain kernel (BDRT_WIDE1=0) up to summation order."""
