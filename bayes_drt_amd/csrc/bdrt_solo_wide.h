@@ -78,8 +78,8 @@ __device__ __forceinline__ Wide1Regs wide1_setup(const DevProblem &P, const Wide
 __device__ __forceinline__ void wide1_init(const DevProblem &P, const Wide1Geom &G, double *lds, int tid)
 {
     const SoloGeom &g = G.g;
-    for (int i = tid; i < G.o_gen; i += SOLO_NT) lds[i] = 0.0;                       // x rows, ups, w rows
-    for (int i = tid; i < g.XL; i += SOLO_NT) lds[G.o_us + i] = 1.0;                 // ups pads: finite, never used
+    for (int i = tid; i < G.o_gen; i += SOLO_NT)                                     // x rows, w rows: zero halos; ups pads: finite, never used
+        lds[i] = (i >= G.o_us && i < G.o_us + g.XL) ? 1.0 : 0.0;
     for (int i = tid; i < G.total - G.o_zp; i += SOLO_NT) lds[G.o_zp + i] = 0.0;
     const int glen = g.nf + g.K - 1;
     for (int i = tid; i < G.nb * 2 * 4 * g.GQ; i += SOLO_NT) {
