@@ -19,6 +19,9 @@
 namespace bdrt {
 
 constexpr int NC = 16;        // chains per workgroup = MFMA N
+// LDS the 16-chain sampler kernel keeps beside the evaluator's tile region (chain states, lp, spectrum ids ...): a problem is
+// accepted only if tile + this fits 160 KiB, so that whatever can be evaluated and optimised can also be sampled
+constexpr size_t SAMPLER_LDS_RESERVE = 6144;
 constexpr int NT = 512;       // threads per workgroup
 constexpr int NW = NT / 64;   // waves per workgroup
 constexpr int NG = NT / NC;   // row groups in the element-wise phases

@@ -248,9 +248,9 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
                 D.fast_s1, D.fast_hw, D.XR, D.ZR, 1 + D.npar, D.LR, D.XCR, lds_doubles(D) * sizeof(double));
     if (const char *e = getenv("BDRT_DEBUG_SKIP")) D.dbg = atoi(e);
     P.lds_bytes = std::max(lds_doubles(D), D.fast_hw ? hw_lds_doubles(D) : (size_t)0) * sizeof(double);
-    if (P.lds_bytes > 160 * 1024) {
-        set_error("bdrt_problem_create: problem needs %zu B of LDS per workgroup (> 160 KiB): nf=%d, K too large",
-                  P.lds_bytes, nf);
+    if (P.lds_bytes + SAMPLER_LDS_RESERVE > 160 * 1024) {
+        set_error("bdrt_problem_create: problem needs %zu B of LDS per workgroup (+ %zu B of sampler state > 160 KiB): nf=%d, K too large",
+                  P.lds_bytes, SAMPLER_LDS_RESERVE, nf);
         return -2;
     }
     std::vector<double> w(nf);

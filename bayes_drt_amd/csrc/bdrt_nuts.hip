@@ -1164,6 +1164,8 @@ __host__ __device__ inline size_t wide1_lds_bytes(const Wide1Geom &G, int ds, in
     return ((size_t)G.total + W1_SCRATCH + 2 + (size_t)nhot * ds) * sizeof(double) + sizeof(ChainState) + 64 + 64;
 }
 
+static_assert((W1_SCRATCH + 2) * sizeof(double) + sizeof(ChainState) + 128 <= 16384, "wide1_capable (bdrt_solo_wide.h) leaves 16 KiB beside the evaluator");
+
 __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, Wide1Geom G, int nhot)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1332,6 +1334,8 @@ static int wide1_hot_rows(const Wide1Geom &G, int ds)
     return n;
 }
 
+static_assert((size_t)3 * NC * sizeof(double) + NC * sizeof(ChainState) + 3 * NC * sizeof(int) + 16 <= SAMPLER_LDS_RESERVE,
+              "bdrt_problem_create reserves SAMPLER_LDS_RESERVE bytes for what the sampler keeps beside the tile region");
 static size_t nuts_lds_bytes(const DevProblem &P, bool s1)
 {
     const int nj = P.D <= 32 * 11 ? 11 : 16;

@@ -53,7 +53,8 @@ inline bool wide1_capable(const DevProblem &P)
     if (K < 2 * MAXBW + 3 || K > 192) return false;
     for (int b = 0; b < P.nblocks; ++b)
         if (P.blk[b].K != K || !P.blk[b].toep || (P.blk[b].tg == nullptr && (P.blk[b].Ad == nullptr || P.blk[b].At == nullptr))) return false;
-    return (size_t)wide1_geometry(P.nf, K, P.D, P.nblocks).total * sizeof(double) + 4096 <= 160 * 1024;
+    // + the cooperative stage's scratch, lp and chain state of nuts_wide1_kernel (wide1_lds_bytes with no resident rows)
+    return (size_t)wide1_geometry(P.nf, K, P.D, P.nblocks).total * sizeof(double) + 16384 <= 160 * 1024;
 }
 
 struct Wide1Regs {

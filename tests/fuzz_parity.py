@@ -1,0 +1,234 @@
+"""Randomised parity cases: problems of random shape (frequencies 6 ... 128, basis 12 ... 192, one to three distributions,
+series / parallel, sign constraint, both outlier error models, log-uniform and irregular frequency lists, one or several
+spectra) are evaluated and sampled on the GPU and checked against the oracle.
+
+Test infrastructure (it imports oracle/).  `tests/test_gpu_fuzz.py` runs a fixed list of case numbers under `-m gpu`;
+`python -m tests.fuzz_parity --first 0 --count 300` is the soak that list was drawn from (record: profiles/r02/fuzz_parity.txt).
+
+Per case:
+  0. the matrices built on the device (bdrt_build_A / bdrt_build_L) against the oracle's: 1e-11 of the largest entry;
+  1. log-posterior and gradient at random points, with and without the Jacobian term: |dlp| <= 1e-10 max(1, |lp|),
+     |dg|_inf <= 1e-10 max(1, |g|_inf);
+  2. the one-chain-per-workgroup evaluator of bdrt_solo_wide.h (where the problem takes it): same bounds;
+  3. a short NUTS run (6 warm-up + 4 draws, tree depth <= 5) of 1 ... 40 units: per checked unit the number of leapfrogs and of
+     divergences equal the oracle's, the draws agree to 1e-6 of the largest coordinate (summation-order noise amplified by a
+     few dozen leapfrogs; bit-equality is not defined between a tree-reduced and a sequential sum);
+  4. MAP from a random start (bdrt_optimize, defaults): where convergence is reported (|grad|_inf < 1e-8), the oracle's gradient
+     at the answer is < 1e-6 and its lp equals the reported lp to 1e-9; the lp never ends below the start's.
+"""
+import argparse
+import ctypes as C
+import sys
+import time
+
+import numpy as np
+
+
+def make_case(n):
+    """Case number -> (constructor arguments, description).  Pure function of n."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(1000003 * n + 17)
+    nf = int(rng.choice([6, 9, 16, 23, 31, 40, 57, 64, 71, 81, 96, 107, 128, int(rng.integers(6, 129))]))
+    decades = float(rng.uniform(3.0, 9.0))
+    f_hi = 10 ** float(rng.uniform(3.0, 7.0))
+    f = np.logspace(np.log10(f_hi), np.log10(f_hi) - decades, nf)
+    irregular = rng.random() < 0.2
+    if irregular:
+        f = np.sort(f * np.exp(0.3 * decades / nf * rng.standard_normal(nf)))[::-1].copy()
+    nblocks = int(rng.choice([1, 1, 1, 2, 2, 3]))
+    own_spacing = rng.random() < 0.25                    # basis spacing unrelated to the frequency spacing: A is not Toeplitz
+    blocks = []
+    desc = []
+    mats = []
+    for b in range(nblocks):
+        ext_lo, ext_hi = float(rng.uniform(0.0, 2.0)), float(rng.uniform(0.0, 2.0))
+        if own_spacing or irregular:
+            K = int(rng.integers(12, 193 if nblocks == 1 else 130))
+            bf = np.logspace(np.log10(f[0]) + ext_hi, np.log10(f[-1]) - ext_lo, K)
+        else:
+            step = decades / (nf - 1)
+            n_hi, n_lo = int(round(ext_hi / step)), int(round(ext_lo / step))
+            K = nf + n_hi + n_lo
+            cap = 192 if nblocks == 1 else 129
+            while K > cap:
+                if n_hi >= n_lo and n_hi > 0: n_hi -= 1
+                elif n_lo > 0: n_lo -= 1
+                else: break
+                K = nf + n_hi + n_lo
+            if K > cap:
+                K = cap
+                bf = np.logspace(np.log10(f[0]), np.log10(f[-1]), K)
+            else:
+                bf = 10 ** (np.log10(f[0]) + step * n_hi - step * np.arange(K))
+        tau = 1 / (2 * np.pi * bf)
+        eps = 1 / np.mean(np.diff(np.log(tau))) * float(rng.choice([1.0, 1.0, 0.7]))
+        parallel = b > 0
+        if parallel:
+            akw = dict(kernel='DDT', dist_type='parallel', symmetry='planar', bc=str(rng.choice(['transmissive', 'blocking'])))
+        else:
+            akw = dict(kernel='DRT', dist_type='series')
+        A = np.vstack([orc.construct_A(f, 'real', tau=tau, epsilon=eps, **akw),
+                       orc.construct_A(f, 'imag', tau=tau, epsilon=eps, **akw)])
+        L = [orc.construct_L(tau, eps, o) for o in (0, 1, 2)]
+        mats.append((bf, tau, eps, akw, A, L))
+        nonneg = True if parallel else bool(rng.random() < 0.7)
+        blocks.append(dict(A=A, L0=float(rng.choice([1.0, 0.5])) * L[0], L1=L[1], L2=float(rng.choice([0.75, 0.5, 1.0])) * L[2],
+                           parallel=parallel, nonneg=nonneg, x_scale=float(np.exp(rng.uniform(-1, 1))) if parallel else 1.0))
+        desc.append('%s%s K=%d' % ('P' if parallel else 'S', '+' if nonneg else '', K))
+    # a spectrum: a two-peak series distribution + offset + noise (a physical fit is not needed for parity)
+    A0 = blocks[0]['A']
+    K0 = A0.shape[1]
+    lt = np.linspace(-1, 1, K0)
+    x = np.exp(-0.5 * ((lt - rng.uniform(-0.6, 0.6)) / 0.15) ** 2) + 0.5 * np.exp(-0.5 * ((lt - rng.uniform(-0.6, 0.6)) / 0.3) ** 2)
+    n_spectra = int(rng.choice([1, 1, 1, 3]))
+    Zs = []
+    for s in range(n_spectra):
+        Z = A0 @ (x * (1 + 0.2 * s)) + np.concatenate([np.full(nf, float(rng.uniform(0.1, 1.0))), np.zeros(nf)])
+        Z = Z / np.std(np.hypot(Z[:nf], Z[nf:])) + 0.01 * rng.standard_normal(2 * nf)
+        if rng.random() < 0.3:
+            Z[int(rng.integers(0, 2 * nf))] += 0.3                # an outlier
+        Zs.append(Z)
+    om = int(rng.choice([0, 0, 0, 1])) if nblocks == 1 else int(rng.choice([0, 0, 2]))
+    kw = dict(sigma_min=float(rng.choice([0.002, 0.01])), ups_alpha=float(rng.choice([1.0, 0.05])), ups_beta=float(rng.choice([0.1, 0.8])),
+              induc_scale=float(rng.choice([1.0, 0.3])), outlier_mode=om)
+    if om == 1:
+        kw.update(so_lambda=float(rng.choice([10.0, 5.0])), so_alpha=float(rng.choice([5.0, 2.0])), so_beta=1.0)
+    elif om == 2:
+        kw.update(so_lambda=float(rng.choice([10.0, 4.0])))
+    if nblocks > 1:
+        kw.update(use_x_sum=True, x_sum_invscale=float(rng.choice([0.0, 0.5])))
+    n_units = int(rng.choice([1, 2, 4, 5, 16, 17, 33, 40]))
+    text = 'nf=%d%s %s outl=%d spectra=%d units=%d' % (nf, ' irregular' if irregular else (' own-spacing' if own_spacing else ''),
+                                                       ' | '.join(desc), om, n_spectra, n_units)
+    return dict(blocks=blocks, Z=np.array(Zs), freq=f, kw=kw, n_units=n_units, seed=int(rng.integers(1, 10 ** 6)), mats=mats), text
+
+
+def _wide1(prob, theta, jac):
+    fn = prob._lib.bdrt_debug_wide1_logp_grad
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lp = np.empty(len(theta)); g = np.empty_like(theta)
+    rc = fn(prob.handle, theta.ctypes.data, None, len(theta), int(jac), lp.ctypes.data, g.ctypes.data)
+    if rc == -2:
+        return None, None
+    assert rc == 0, prob._lib.bdrt_last_error().decode()
+    return lp, g
+
+
+def run_case(n, verbose=False):
+    """Returns (status, text): status 'ok', 'skip' (the problem is beyond the LDS budget or the sampler's D <= 864: loud error,
+    by design) or 'FAIL'."""
+    from bayes_drt_amd._lib import BdrtError, NutsControl
+    from bayes_drt_amd.engine import Sampler
+    from bayes_drt_amd.model import Problem
+    from oracle import oracle as orc
+    case, text = make_case(n)
+    try:
+        prob = Problem(case['blocks'], case['Z'], case['freq'], **case['kw'])
+    except BdrtError as e:
+        if 'LDS' in str(e):
+            return 'skip', text + ' :: ' + str(e)[:60]
+        raise
+    n_spectra = len(case['Z'])
+    oms = [orc.OracleModel(case['blocks'], case['Z'][s], case['freq'], **case['kw']) for s in range(n_spectra)]
+    rng = np.random.default_rng(n)
+    fails = []
+    # 0: the device-built matrices (bdrt_build_A / _L) against the oracle's, 1e-11 of the largest entry
+    from bayes_drt_amd import matrices as gm
+    for b, (bf, tau, eps, akw, A, L) in enumerate(case['mats']):
+        Ag = np.vstack([gm.construct_A(case['freq'], p, tau=tau, epsilon=eps, **akw) for p in ('real', 'imag')])
+        if not np.max(np.abs(Ag - A)) <= 1e-11 * np.max(np.abs(A)):
+            fails.append('block %d: A differs by %.3g (scale %.3g)' % (b, np.max(np.abs(Ag - A)), np.max(np.abs(A))))
+        for o in (0, 1, 2):
+            Lg = gm.construct_L(bf, tau=tau, epsilon=eps, order=o)
+            if not np.max(np.abs(Lg - L[o])) <= 1e-11 * np.max(np.abs(L[o])):
+                fails.append('block %d: L%d differs by %.3g' % (b, o, np.max(np.abs(Lg - L[o]))))
+    # 1, 2: evaluators
+    npts = 5
+    theta = np.ascontiguousarray(rng.uniform(-2, 2, (npts, prob.D)))
+    spec = (np.arange(npts) % n_spectra).astype(np.int32)
+    for jac in (True, False):
+        lp, g = prob.logp_grad(theta, jacobian=jac, spec=spec)
+        w_lp, w_g = (None, None) if n_spectra > 1 else _wide1(prob, theta, jac)
+        for i in range(npts):
+            lr, gr = oms[spec[i]].logp_grad(theta[i], jac)
+            for nm, a, b in (('batched', lp, g), ('one-chain', w_lp, w_g)):
+                if a is None:
+                    continue
+                if not np.isfinite(lr):
+                    if not (a[i] == lr or (np.isnan(a[i]) and np.isnan(lr))):
+                        fails.append('%s lp non-finite mismatch %r vs %r' % (nm, a[i], lr))
+                    continue
+                if not abs(a[i] - lr) <= 1e-10 * max(1.0, abs(lr)):
+                    fails.append('%s lp jac=%d pt %d: %.17g vs %.17g' % (nm, jac, i, a[i], lr))
+                e = np.max(np.abs(b[i] - gr))
+                if not e <= 1e-10 * max(1.0, np.max(np.abs(gr))):
+                    fails.append('%s grad jac=%d pt %d: err %.3g at %d (|g| %.3g)' % (nm, jac, i, e, int(np.argmax(np.abs(b[i] - gr))),
+                                                                                     np.max(np.abs(gr))))
+    # 3: sampler
+    ctrl = NutsControl(); prob._lib.bdrt_nuts_defaults(C.byref(ctrl)); ctrl.max_treedepth = 5
+    warm, nd, nu, seed = 6, 4, case['n_units'], case['seed']
+    uspec = (np.arange(nu) % n_spectra).astype(np.int32)
+    try:
+        smp = Sampler(prob, nu, warm, nd, seed, ctrl, spec=uspec)
+    except BdrtError as e:
+        if 'not supported' in str(e) and prob.D > 864:      # three distributions + the outlier model: no reference family
+            prob.close()
+            return 'skip', text + ' D=%d :: %s' % (prob.D, str(e)[-40:])
+        raise
+    with smp:
+        kind = smp.kind()
+        smp.run(None)
+        draws, lps, diag = smp.results()
+    for c in sorted({0, nu // 2, nu - 1}):
+        ref, lpr, dr = orc.nuts_sample(oms[uspec[c]], c, seed, warm, nd, control=orc.nuts_control(max_treedepth=5))
+        if dr['n_leapfrog'] != diag[c]['n_leapfrog'] or dr['n_divergent'] != diag[c]['n_divergent']:
+            fails.append('sampler unit %d: leapfrogs %d vs %d, divergences %d vs %d' % (c, diag[c]['n_leapfrog'], dr['n_leapfrog'],
+                                                                                        diag[c]['n_divergent'], dr['n_divergent']))
+            continue
+        err = np.max(np.abs(draws[c] - ref)) / np.max(np.abs(ref))
+        if not err < 1e-6:
+            fails.append('sampler unit %d: draws differ by %.3g' % (c, err))
+    # 4: MAP (Levenberg-Marquardt Newton on the device): where it reports convergence the oracle's gradient at the answer
+    #    vanishes as well and the oracle's lp equals the reported one; "no convergence" is reported, never hidden
+    from bayes_drt_amd.engine import optimize_batch
+    th0 = np.random.default_rng(n + 7).uniform(-2, 2, (1, prob.D))
+    out, rep = optimize_batch(prob, th0, max_iter=2000)
+    lr, gr = oms[0].logp_grad(out[0], False)
+    conv = rep[0]['return_code'] == 0 and rep[0]['grad_inf'] < 1e-8
+    if conv and not (np.max(np.abs(gr)) < 1e-6 and abs(lr - rep[0]['lp']) <= 1e-9 * max(1.0, abs(lr))):
+        fails.append('MAP: reported |g| %.3g lp %.12g, oracle |g| %.3g lp %.12g' % (rep[0]['grad_inf'], rep[0]['lp'], np.max(np.abs(gr)), lr))
+    if not np.isfinite(lr) or lr < oms[0].logp_grad(th0[0], False)[0]:
+        fails.append('MAP: lp at the answer %.6g below lp at the start' % lr)
+    prob.close()
+    text += ' D=%d kernel=%d map=%s' % (prob.D, kind, 'converged/%d' % rep[0]['newton_iterations'] if conv else
+                                        'rc%d,|g|=%.1e' % (rep[0]['return_code'], rep[0]['grad_inf']))
+    if fails:
+        return 'FAIL', text + '\n    ' + '\n    '.join(fails)
+    return 'ok', text
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--first', type=int, default=0)
+    ap.add_argument('--count', type=int, default=100)
+    ap.add_argument('--seconds', type=float, default=0.0, help='stop after this much wall time (0: run all)')
+    a = ap.parse_args()
+    t0 = time.time()
+    tally = dict(ok=0, skip=0, FAIL=0)
+    kinds = {}
+    for n in range(a.first, a.first + a.count):
+        if a.seconds and time.time() - t0 > a.seconds:
+            break
+        try:
+            st, text = run_case(n)
+        except Exception as e:                              # a crash is a failure of the case, keep going
+            st, text = 'FAIL', 'exception %s: %s' % (type(e).__name__, str(e)[:200])
+        tally[st] += 1
+        print('case %4d %-4s %s' % (n, st, text), flush=True)
+    print('TOTAL %d ok, %d skipped (beyond the LDS budget / D > 864: loud errors), %d FAILED in %.0f s' % (tally['ok'], tally['skip'], tally['FAIL'],
+                                                                                 time.time() - t0))
+    return 1 if tally['FAIL'] else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

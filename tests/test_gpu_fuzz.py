@@ -1,0 +1,42 @@
+"""GPU tests (-m gpu): a fixed slice of the randomised parity cases of tests/fuzz_parity.py (matrices, both evaluators, a short
+NUTS run and the MAP of a random problem against the oracle).  The soak over cases 0 ... 599 is recorded in
+profiles/r02/fuzz_parity.txt; it found the two limits pinned below."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# the first 24 cases + the extremes of the generator: 25 (K = 192, Nf = 128), 7 / 287 (two distributions of 129 at 128 / 107
+# frequencies, with the stacked outlier model: D = 742), 3 (K = 6 ... 8), 16 (6 frequencies, 215 basis functions), 598
+CASES = sorted(set(range(24)) | {25, 287, 457, 598})
+
+
+@pytest.mark.parametrize('n', CASES)
+def test_random_problem_matches_the_oracle(n):
+    from tests.fuzz_parity import run_case
+    status, text = run_case(n)
+    assert status in ('ok', 'skip'), text
+    if status == 'skip':
+        assert n == 14, text                    # three distributions of 129 at 107 frequencies: beyond the LDS budget
+
+
+def test_whatever_is_accepted_as_a_problem_can_be_sampled():
+    """Cases 207 and 283 (three distributions, > 107 frequencies) need 155-160 KiB of LDS for the evaluator alone: they used to
+    be accepted by bdrt_problem_create and then refused by bdrt_sampler_create.  The budget check now includes the sampler's
+    share, so the refusal comes at problem creation."""
+    from bayes_drt_amd._lib import BdrtError
+    from bayes_drt_amd.model import Problem
+    from tests.fuzz_parity import make_case, run_case
+    for n in (207, 283):
+        case, text = make_case(n)
+        with pytest.raises(BdrtError) as e:
+            Problem(case['blocks'], case['Z'], case['freq'], **case['kw'])
+        assert 'LDS' in str(e.value)
+        assert run_case(n)[0] == 'skip'
+
+
+def test_parameter_vectors_beyond_864_are_refused_by_the_sampler_not_mis_sampled():
+    """Three distributions + the stacked outlier model (no such family in the reference) can exceed the sampler's 27 elements per
+    lane; evaluation and MAP work, bdrt_sampler_create says so."""
+    from tests.fuzz_parity import run_case
+    status, text = run_case(403)
+    assert status == 'skip' and 'not supported' in text, text
