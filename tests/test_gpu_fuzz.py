@@ -40,3 +40,12 @@ def test_parameter_vectors_beyond_864_are_refused_by_the_sampler_not_mis_sampled
     from tests.fuzz_parity import run_case
     status, text = run_case(403)
     assert status == 'skip' and 'not supported' in text, text
+
+
+@pytest.mark.parametrize('first', [0, 20, 40, 350])
+def test_random_ridge_fits_device_loop_equals_host_loop(first):
+    """tests/fuzz_ridge.py, 20 cases per test (record of cases 0 ... 999: profiles/r02/fuzz_ridge.txt)."""
+    from tests.fuzz_ridge import run_case
+    for n in range(first, first + 20):
+        status, text = run_case(n)
+        assert status == 'ok', 'case %d %s' % (n, text)
