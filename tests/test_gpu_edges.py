@@ -87,3 +87,43 @@ def test_extreme_parameters_give_non_finite_lp_not_a_crash():
     assert not np.isfinite(lp[0]) and not np.isfinite(lp[2])
     assert np.isfinite(lp[3]) and np.all(np.isfinite(g[3]))
     assert lp.shape == (4,)
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize('units,blocks', [(4, 1), (17, 1), (4, 2), (20, 2)])
+def test_a_spectrum_without_a_finite_log_posterior_is_reported_not_sampled(units, blocks):
+    """Stan: "Initialization failed" after 100 attempts.  A NaN in the spectrum makes every evaluation
+    non-finite: each sampler kernel (one chain per workgroup for the single DRT and for two distributions, sixteen chains per
+    workgroup) must stop its chains and say so -- no hang, no draws."""
+    from bayes_drt_amd._lib import BdrtError
+    from bayes_drt_amd.engine import sample_units
+    from bayes_drt_amd.model import Problem
+    blk, Z, f, kw = _problem(40, 64)
+    Z = Z.copy(); Z[7] = np.nan
+    prob = Problem([blk] + [dict(blk, parallel=True, nonneg=True)] * (blocks - 1), Z, f, **kw)
+    with pytest.raises(BdrtError) as e:
+        sample_units(prob, units, 20, 10, 3)
+    assert '100 attempts' in str(e.value)
+    # the evaluator itself returns the non-finite value, it does not raise
+    lp, g = prob.logp_grad(np.zeros((2, prob.D)))
+    assert not np.any(np.isfinite(lp))
+    prob.close()
+
+
+def test_sampler_argument_checks_and_empty_runs():
+    from bayes_drt_amd._lib import BdrtError
+    from bayes_drt_amd.engine import sample_units
+    from bayes_drt_amd.model import Problem
+    blk, Z, f, kw = _problem(40, 64)
+    prob = Problem([blk], Z, f, **kw)
+    with pytest.raises(BdrtError):
+        sample_units(prob, 0, 10, 10, 1)
+    with pytest.raises(BdrtError):
+        sample_units(prob, 2, -1, 10, 1)
+    with pytest.raises(BdrtError):
+        sample_units(prob, 2, 10, 10, 1, spec=[0, 1])            # spectrum 1 does not exist
+    draws, lp, diag = sample_units(prob, 3, 12, 0, 1)             # warm-up only: no draws, the chains still ran
+    assert draws.shape == (3, 0, prob.D) and all(d['n_leapfrog'] > 0 for d in diag)
+    draws, lp, diag = sample_units(prob, 3, 0, 5, 1)              # no warm-up: unit step size search, then draws
+    assert draws.shape == (3, 5, prob.D) and np.all(np.isfinite(draws))
+    prob.close()
