@@ -268,16 +268,30 @@ class StanModel:
         return theta
 
     # ------------------------------------------------------------------ optimizing / sampling
-    def optimizing(self, data, iter=50000, seed=1234, init='random', algorithm='LBFGS+Newton', **opts):
+    def optimizing(self, data, iter=50000, seed=1234, init='random', algorithm='LBFGS+Newton', extra_inits=(), **opts):
         """MAP without Jacobian (Stan `optimizing`).  Returns OrderedDict name -> ndarray with the parameters and
         transformed parameters `Inverter._extract_parameter` reads.
+
+        extra_inits: further starting points (Stan `init=` values).  All starts run as one lock-step batch of
+        `bdrt_optimize` (the wall time of the slowest one); the answer is the start `init` unless another start ends at a
+        clearly higher log-posterior (`last_report['start']` tells which, `last_report['starts']` lists all of them).
 
         algorithm='LBFGS' is the Stan-style L-BFGS(5) with Stan's termination tests (an early-terminated iterate,
         SURVEY fact 4); the default 'LBFGS+Newton' continues with the GPU full-Hessian Newton polish to a true
         stationary point (bdrt_newton.h)."""
         P = self._prepare(data)
         lib = P._lib
-        theta0 = self._init_theta(init, 1, seed)
+        rows = [self._init_theta(init, 1, seed)]
+        for e in extra_inits:
+            try:
+                if isinstance(e, tuple) and e[0] == 'random':           # ('random', k): another draw of the random start
+                    rows.append(self._init_theta('random', 1, seed + int(e[1])))
+                    continue
+                rows.append(self._init_theta(e, 1, seed))
+            except ValueError:                          # a candidate outside the support is simply not used
+                pass
+        theta0 = np.vstack(rows)
+        n = theta0.shape[0]
         o = OptOptions()
         lib.bdrt_opt_defaults(C.byref(o))
         o.max_iter = int(iter)
@@ -287,11 +301,18 @@ class StanModel:
             raise ValueError("algorithm must be 'LBFGS' or 'LBFGS+Newton'")
         for k, v in opts.items():
             setattr(o, k, v)
-        out = np.empty((1, P.D))
-        rep = (OptReport * 1)()
-        check(lib.bdrt_optimize(P.handle, ptr(theta0), None, 1, C.byref(o), ptr(out), rep), 'bdrt_optimize')
-        self.last_report = _report(rep[0])
-        return self.result_dict(out[0])
+        out = np.empty((n, P.D))
+        rep = (OptReport * n)()
+        check(lib.bdrt_optimize(P.handle, ptr(theta0), None, n, C.byref(o), ptr(out), rep), 'bdrt_optimize')
+        reports = [_report(r) for r in rep]
+        best = 0
+        for i in range(1, n):
+            a, b = reports[i], reports[best]
+            higher = np.isfinite(a['lp']) and (not np.isfinite(b['lp']) or a['lp'] > b['lp'] + 1e-6 * max(1.0, abs(b['lp'])))
+            if higher and (a['return_code'] == 0 or b['return_code'] != 0):
+                best = i
+        self.last_report = dict(reports[best], start=best, starts=reports)
+        return self.result_dict(out[best])
 
     def result_dict(self, theta):
         P = self.problem

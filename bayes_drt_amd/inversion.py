@@ -703,6 +703,24 @@ class Inverter:
             self._init_params = init()
         else:
             init = 'random'
+        # MAP: the hierarchical posterior has poor local maxima (everything explained as noise, or a huge Z_hat with a
+        # proportionally huge error) that a single random start reaches on sparse or outlier-ridden spectra.  A second start
+        # from the under-fitted ridge solution costs no wall time (the starts run as one batch on the GPU); the designated
+        # start's answer (random, or ridge with init_from_ridge=True) is kept unless the other one ends at a clearly higher
+        # log-posterior.  BDRT_MAP_SINGLE_START=1: the designated start only, as in the reference.
+        extra_inits = []
+        if mode == 'optimize' and init_from_ridge and not os.environ.get('BDRT_MAP_SINGLE_START'):
+            extra_inits = ['random']                    # (the ridge start stays the designated one)
+        if (mode == 'optimize' and not init_from_ridge and len(self.distributions) == 1 and model_str is None
+                and not os.environ.get('BDRT_MAP_SINGLE_START')):
+            try:
+                extra_inits = [self._get_init_from_ridge(frequencies, Z, mode, nonneg=nonneg, outliers=outliers,
+                                                        inductance_scale=inductance_scale, ridge_kw=ridge_kw)]
+            except Exception as e:                      # the ridge candidate is optional: the random start remains
+                warnings.warn('ridge starting point not available (%s): MAP from the random start only' % e)
+        elif mode == 'optimize' and not init_from_ridge and not os.environ.get('BDRT_MAP_SINGLE_START'):
+            # several distributions: no ridge solution to start from -- three more draws of the random start instead
+            extra_inits = [('random', k) for k in (1, 2, 3)]
         frequencies, Z_scaled, WZ_re, WZ_im, W_re, W_im, dist_mat = self._prep_matrices(
             frequencies, Z, part, weights=None, dZ=False, scale_Z=scale_Z, penalty='discrete', fit_type='map')
         Z_sorted = self.Z_train
@@ -735,7 +753,7 @@ class Inverter:
             dat['N'] = len(frequencies)        # package Series outlier models declare N = Nf (:1208-1211)
         self._stan_input = dat.copy()
         if mode == 'optimize':
-            self._opt_result = model.optimizing(dat, iter=max_iter, seed=random_seed, init=init)
+            self._opt_result = model.optimizing(dat, iter=max_iter, seed=random_seed, init=init, extra_inits=extra_inits)
             self._opt_report = model.last_report
         else:
             self._sample_result = model.sampling(dat, warmup=warmup, iter=warmup + samples, chains=chains,
@@ -800,7 +818,12 @@ class Inverter:
         series = self.distributions[name]['dist_type'] == 'series'
         Rinf = self.R_inf / zs
         induc = max(self.inductance / zs, 0.0) or 1e-10  # lower=0 parameter: strictly positive start
-        values = {'x': coef / zs if series else coef * zs, 'Rinf': Rinf, 'Rinf_raw': Rinf / 100, 'induc': induc,
+        x0 = coef / zs if series else coef * zs
+        if nonneg or not series:
+            # lower=0 parameter: a coefficient the QP left at (numerically) zero starts a little inside the support instead
+            # of making the initialisation fail (Stan rejects an initial value on the bound)
+            x0 = np.maximum(x0, 1e-8 * max(float(np.max(x0)), 1e-300))
+        values = {'x': x0, 'Rinf': Rinf, 'Rinf_raw': Rinf / 100, 'induc': induc,
                   'induc_raw': induc / inductance_scale}
         if outliers:
             suspects = self.check_outliers(frequencies, Z, threshold=3, use_existing_fit=True)   # lenient threshold

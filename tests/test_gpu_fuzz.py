@@ -1,6 +1,7 @@
 """GPU tests (-m gpu): a fixed slice of the randomised parity cases of tests/fuzz_parity.py (matrices, both evaluators, a short
 NUTS run and the MAP of a random problem against the oracle).  The soak over cases 0 ... 599 is recorded in
 profiles/r02/fuzz_parity.txt; it found the two limits pinned below."""
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -49,3 +50,39 @@ def test_random_ridge_fits_device_loop_equals_host_loop(first):
     for n in range(first, first + 20):
         status, text = run_case(n)
         assert status == 'ok', 'case %d %s' % (n, text)
+
+
+@pytest.mark.parametrize('first', [0, 20, 40, 200, 300, 340, 360])
+def test_random_spectra_through_inverter_fit(first):
+    """tests/fuzz_inverter.py, 20 cases per test (record of cases 0 ... 399: profiles/r02/fuzz_inverter.txt)."""
+    from tests.fuzz_inverter import run_case
+    for n in range(first, first + 20):
+        status, text = run_case(n)
+        assert status == 'ok', 'case %d %s' % (n, text)
+
+
+@pytest.mark.parametrize('n', [5, 178, 213])
+def test_map_keeps_the_better_of_the_random_and_the_ridge_start(n, monkeypatch):
+    """Spectra (41 / 128 / 101 points; unconstrained coefficients or the outlier model) on which the random start alone ends in
+    a poor local maximum of the posterior -- everything explained as noise, or a huge Z_hat with a proportionally huge error:
+    with the ridge start in the same batch the fit is the (much) higher maximum, and it follows the spectrum."""
+    import warnings
+    from bayes_drt_amd.inversion import Inverter
+    from tests.fuzz_inverter import make_case
+    case, _ = make_case(n)
+    res = {}
+    for single in (True, False):
+        if single:
+            monkeypatch.setenv('BDRT_MAP_SINGLE_START', '1')
+        else:
+            monkeypatch.delenv('BDRT_MAP_SINGLE_START')
+        inv = Inverter(basis_freq=case['bf'])
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            inv.fit(case['f'], case['Z'], **case['kw'])
+        rms = np.sqrt(np.mean(np.abs(inv.predict_Z(case['f']) - case['Z']) ** 2))
+        res[single] = (inv._opt_report, rms)
+    (r1, rms1), (r2, rms2) = res[True], res[False]
+    assert 'starts' not in r1 or len(r1['starts']) == 1
+    assert r2['start'] == 1 and len(r2['starts']) == 2 and r2['return_code'] == 0
+    assert r2['lp'] > r1['lp'] + 100 and rms2 < 0.5 * rms1, (r1['lp'], r2['lp'], rms1, rms2)

@@ -22,6 +22,14 @@ for K, bf in ((81, f), (101, None), (161, np.logspace(10, -6, 161))):
     print('K=%d: fit(mode=optimize) %.3f s  (L-BFGS %d it + Newton %d it, %d evals), lp %.4f, |grad|_inf %.1e, rc %d; '
           'gamma vs reference MAP rel-L2 %.4f, vs true %.4f' % (K, t1 - t0, r['iterations'], r['newton_iterations'], r['n_evals'],
                                                                  r['lp'], r['grad_inf'], r['return_code'], rel_l2(g, ref), rel_l2(g, true)))
+    print('      starts (random, ridge) in one batch: kept start %d; lp of the starts %s' % (
+        r['start'], ', '.join('%.4f (rc %d, %d it)' % (x['lp'], x['return_code'], x['newton_iterations']) for x in r['starts'])))
+    os.environ['BDRT_MAP_SINGLE_START'] = '1'
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        t0 = time.time(); inv.fit(f, Z, nonneg=True, mode='optimize'); t1 = time.time()
+    del os.environ['BDRT_MAP_SINGLE_START']
+    print('      the random start alone (BDRT_MAP_SINGLE_START=1): %.3f s' % (t1 - t0))
     # the Stan-style iterate beside it: L-BFGS(5) with Stan's termination tests, iter = 50000, no second-order polish
     from bayes_drt_amd.engine import StanModel
     m = StanModel(inv.stan_model_name)
