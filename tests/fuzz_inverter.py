@@ -1,6 +1,7 @@
 """Randomised end-to-end cases of `Inverter.fit` (the reference's entry point, inversion.py:1072): random two-ZARC spectra
 (16 ... 128 frequencies, noise 0 ... 1 %, optional outliers), random options (nonneg, outliers False / True / 'auto',
-init_from_ridge, sigma_min, inductance_scale, default or extended basis, part), MAP mostly, short NUTS runs sometimes.
+init_from_ridge, sigma_min, inductance_scale, default or extended basis), MAP mostly, short NUTS runs sometimes; one case
+in six adds a finite-length diffusion element and is fitted with a DRT + a parallel transmissive DDT (Series-Parallel models).
 
 No reference output exists for random inputs, so the checks are properties every correct fit has:
   1. no exception; every reported quantity finite; the MAP either converged (|grad|_inf < 1e-8) or says why not;
@@ -36,6 +37,15 @@ def make_case(n):
         al = float(rng.uniform(0.8, 1.0))
         Z = Z + R / (1 + (1j * w * t0) ** al)
         Rp += R
+    # one case in six: a finite-length (transmissive, planar) diffusion element in series with ONE of the arcs, fitted with a
+    # DRT + a parallel DDT (the Series-Parallel models; the element is a single line of the DDT: Y = sqrt(s) coth(sqrt(s)) / R_d)
+    rng2 = np.random.default_rng(15485863 * n + 5)           # (its own stream: the single-DRT cases keep their numbers)
+    multi = bool(rng2.random() < 1 / 6) and nf >= 41
+    if multi:
+        Rd, td = float(rng2.uniform(0.5, 2.0)), float(10 ** rng2.uniform(-lo - 2.5, -lo - 1.0) / (2 * np.pi))
+        sq = np.sqrt(1j * w * td)
+        Z = Z + Rd * np.tanh(sq) / sq
+        Rp += Rd
     noise = float(rng.choice([0.0, 0.0025, 0.01]))
     sig = noise * np.mean(np.abs(Z))
     Z = Z + sig * (rng.standard_normal(nf) + 1j * rng.standard_normal(nf))
@@ -56,11 +66,17 @@ def make_case(n):
               inductance_scale=float(rng.choice([1.0, 0.1])))
     kw['outliers'] = {'False': False, 'True': True, 'auto': 'auto'}[str(kw['outliers'])]
     mode = 'sample' if rng.random() < 0.12 else 'optimize'
+    if multi:
+        kw.update(nonneg=True, init_from_ridge=False)            # (ridge initialisation is defined for one distribution only)
+        if kw['outliers'] == 'auto':
+            kw['outliers'] = False                               # (so is the ridge-based outlier screening)
     if mode == 'sample':
         kw.update(mode='sample', warmup=60, samples=40, chains=2, random_seed=int(rng.integers(1, 10 ** 5)))
     text = 'nf=%d noise=%.4f outl_pts=%s basis=%s %s' % (nf, noise, out_idx, 'default' if bf is None else ('f' if bf is f else 'K=%d' % len(bf)),
                                                         ' '.join('%s=%s' % kv for kv in kw.items()))
-    return dict(f=f, Z=Z, bf=bf, kw=kw, sig=sig, R0=R0, Rp=Rp, out_idx=out_idx, mode=mode), text
+    if multi:
+        text = 'DRT+TP-DDT ' + text
+    return dict(f=f, Z=Z, bf=bf, kw=kw, sig=sig, R0=R0, Rp=Rp, out_idx=out_idx, mode=mode, multi=multi), text
 
 
 def run_case(n):
@@ -68,7 +84,12 @@ def run_case(n):
     case, text = make_case(n)
     f, Z, kw = case['f'], case['Z'], case['kw']
     fails = []
-    inv = Inverter(basis_freq=case['bf'])
+    if case['multi']:
+        inv = Inverter(basis_freq=case['bf'], distributions={
+            'DRT': {'kernel': 'DRT'},
+            'TP-DDT': {'kernel': 'DDT', 'symmetry': 'planar', 'bc': 'transmissive', 'dist_type': 'parallel'}})
+    else:
+        inv = Inverter(basis_freq=case['bf'])
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         inv.fit(f, Z, **kw)
@@ -78,8 +99,9 @@ def run_case(n):
         conv = rep['return_code'] == 0 and rep['grad_inf'] < 1e-8
         info += ' map=%s' % ('converged/%d' % rep['newton_iterations'] if conv else 'rc%d,|g|=%.1e' % (rep['return_code'], rep['grad_inf']))
         if len(rep.get('starts', ())) > 1:
-            other = rep['starts'][1 - rep['start']]
-            info += ' start=%d(lp %+.1f vs the other start)' % (rep['start'], rep['lp'] - other['lp'])
+            others = [x['lp'] for i, x in enumerate(rep['starts']) if i != rep['start'] and x['return_code'] == 0]
+            if others:
+                info += ' start=%d(lp %+.1f vs the best other start)' % (rep['start'], rep['lp'] - max(others))
         if not conv and rep['return_code'] not in (1, 2):
             fails.append('MAP report %r' % (rep,))
     Zp = inv.predict_Z(f)
@@ -96,6 +118,10 @@ def run_case(n):
             fails.append('residual rms %.3g (noise %.3g, mean|Z| %.3g)' % (rms, case['sig'], np.mean(np.abs(Z))))
     tau = np.logspace(np.log10(1 / (2 * np.pi * f[0])) - 0.5, np.log10(1 / (2 * np.pi * f[-1])) + 0.5, 120)
     g = inv.predict_distribution('DRT', eval_tau=tau)
+    if case['multi']:
+        g2 = inv.predict_distribution('TP-DDT', eval_tau=tau)
+        if not (np.all(np.isfinite(g2)) and np.min(g2) >= -1e-9 * np.max(np.abs(g2))):
+            fails.append('DDT distribution not finite / negative')
     if not np.all(np.isfinite(g)):
         fails.append('gamma not finite')
     elif kw['nonneg'] and np.min(g) < -1e-9 * np.max(np.abs(g)):
@@ -103,6 +129,8 @@ def run_case(n):
     tol = (0.25 if len(f) >= 21 and case['mode'] == 'optimize' else 0.6) + 10 * (case['sig'] / np.mean(np.abs(Z)))
     if not (np.isfinite(inv.R_inf) and abs(inv.R_inf - case['R0']) <= tol * (case['R0'] + 0.3 * case['Rp'])):
         fails.append('R_inf %.4g (true %.4g)' % (inv.R_inf, case['R0']))
+    if case['multi']:
+        return ('FAIL', text + ' :: ' + info + '\n    ' + '\n    '.join(fails)) if fails else ('ok', text + ' :: ' + info)
     rp = inv.predict_Rp()
     rp = float(np.atleast_1d(rp)[0]) if np.ndim(rp) else float(rp)
     if not (np.isfinite(rp) and abs(rp - case['Rp']) <= tol * case['Rp'] + 0.3 * case['R0'] * tol):
