@@ -450,7 +450,7 @@ __global__ __launch_bounds__(QP_NT) void ridge_kernel(RidgeArgs a)
         for (int i = tid; i < n; i += QP_NT) {
             c1 += coef[i] * (0.5 * tmp[i] + q[i]);
             double dl = (coef[i] - prev[i]) / prev[i];
-            if (a.zero_delta1 && i == 1) dl = 0.0;
+            if (i == 1 && a.gsel[b] < 31 && ((a.zero_delta1 >> a.gsel[b]) & 1)) dl = 0.0;     // (a property of the fit's data part)
             dl = fabs(dl);
             if (dl != dl) dnan += 1.0; else dsum += dl;
         }

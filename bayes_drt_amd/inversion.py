@@ -402,7 +402,10 @@ class Inverter:
         o = _lib.RidgeOptions()
         o.n, o.K, o.off = n, K, off
         o.penalty = 1 if st0['penalty'] == 'integral' else 0
-        o.max_iter, o.hyper_lambda, o.zero_delta1 = int(max_iter), int(bool(hyper_lambda)), int(st0['zero_delta1'])
+        # (bit g of zero_delta1: data part g -- the real-part fits of a cross-validation exclude the inductance from the
+        #  convergence test, the imaginary-part fits do not)
+        o.max_iter, o.hyper_lambda = int(max_iter), int(bool(hyper_lambda))
+        o.zero_delta1 = sum(int(bool(s_['zero_delta1'])) << g for g, s_ in enumerate(setups))
         o.xtol = float(xtol)
         o.hl_fbeta = float(hl_fbeta) if (hl_fbeta is not None and st0['penalty'] != 'integral') else 0.0
         for i in range(3):

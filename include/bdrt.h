@@ -224,7 +224,9 @@ int bdrt_qp_box_batch(const double *P, const double *q, const double *lo, int n,
  *     integral:  c = factor_o x (100, 10, 1), C_j = sum_{r != j} c_r sqrt(lambda_r) M_rj c_j, d = c^2 diag(M) + 2b,
  *                lambda = (C^2 - sign(C) C sqrt(4 d (2a-2) + C^2) + 2 d (2a-2)) / (2 d^2), floored at 1e-15  (:973-983)
  *     P = G + sum_o reg_ord[o] sqrt(lambda_o) base_o sqrt(lambda_o);  x = argmin 1/2 x'Px + q'x, x >= lo
- *     stop when mean |(x - x_prev) / x_prev| < xtol (entry 1 excluded when zero_delta1)
+ *     stop when mean |(x - x_prev) / x_prev| < xtol (entry 1 -- the inductance -- excluded for the fits on data part g
+ *     when bit g of zero_delta1 is set: the reference zeroes it when the inductance is not fitted or only the real part is,
+ *     :733-734, so in a Re-Im cross-validation the real-part fits exclude it and the imaginary-part fits do not)
  *   hyper_lambda = 0: one QP with lambda = lambda0 (ordinary ridge).
  * Outputs: coef [nb][n], lam [nb][3][n], cost = 1/2 x'Px + q'x, fun = the QP's primal objective, iters (outer iterations),
  * flags (bit 0 converged, bit 2 a QP reached its iteration limit); optional per-iteration history (all four or none):
@@ -234,7 +236,7 @@ typedef struct {
     int penalty;            /* 0 discrete, 1 integral */
     int max_iter;
     int hyper_lambda;
-    int zero_delta1;
+    int zero_delta1;        /* bit g: fits with gsel == g leave entry 1 out of the convergence test (ng <= 31) */
     double xtol;
     double hl_fbeta;        /* <= 0: analytic discrete update */
     double reg_ord[3];

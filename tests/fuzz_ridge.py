@@ -9,6 +9,8 @@ Per case:
      stopped at max_iter without converging), R_inf within 1e-6;
   2. the fitted impedance is finite and follows the spectrum (rms residual < 0.5 mean |Z|: a sanity band, the fit quality at
      10 frequencies and lambda_0 ~ 1 is what it is);
+  4. every eighth case: `ridge_ReImCV` over 8 lambdas -- the batched launch gives bit for bit the CV table of the sequential
+     loop;
   3. ordinary ridge (hyper_lambda=False): the KKT conditions of the QP 1/2 x'Px + q'x, x >= lo at the answer of the batched
      interior-point kernel: multipliers >= -1e-5 max|q|, complementarity gap <= 2e-6 |objective| + 1e-7 (cvxopt's tolerances).
 """
@@ -117,6 +119,26 @@ def run_case(n):
             gap = float(np.sum(np.abs(g * (x[0] - lo))))
             if not gap <= 2e-6 * abs(obj[0]) + 1e-7:
                 fails.append('complementarity gap %.3g (objective %.6g)' % (gap, obj[0]))
+    if n % 8 == 0 and kw['penalty'] != 'cholesky':
+        # 4. Re-Im cross-validation: all 2 x len(lambdas) fits as one launch against the reference-style sequential loop
+        cvkw = {k: v for k, v in kw.items() if k in ('penalty', 'nonneg', 'weights', 'reg_ord', 'hl_beta', 'hl_fbeta')}
+        lams = np.logspace(-6, 1, 8)
+        tabs = []
+        for seq in (False, True):
+            if seq:
+                os.environ['BDRT_SEQUENTIAL_CV'] = '1'
+            try:
+                inv = Inverter(basis_freq=case['bf'])
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    best = inv.ridge_ReImCV(f, Z, lambdas=lams, **cvkw)
+                tabs.append((best, inv.cv_result['recv'].copy(), inv.cv_result['imcv'].copy()))
+            finally:
+                os.environ.pop('BDRT_SEQUENTIAL_CV', None)
+        if tabs[0][0] != tabs[1][0] or not (np.array_equal(tabs[0][1], tabs[1][1]) and np.array_equal(tabs[0][2], tabs[1][2])):
+            fails.append('Re-Im CV: batched table differs from the sequential loop (best %g vs %g, max diff %.3g)' % (
+                tabs[0][0], tabs[1][0], max(np.max(np.abs(tabs[0][1] - tabs[1][1])), np.max(np.abs(tabs[0][2] - tabs[1][2])))))
+        text += ' cv=%.0e' % tabs[0][0]
     text += ' iters=%d' % na
     return ('FAIL', text + '\n    ' + '\n    '.join(fails)) if fails else ('ok', text)
 
