@@ -86,3 +86,11 @@ def test_map_keeps_the_better_of_the_random_and_the_ridge_start(n, monkeypatch):
     assert 'starts' not in r1 or len(r1['starts']) == 1
     assert r2['start'] == 1 and len(r2['starts']) == 2 and r2['return_code'] == 0
     assert r2['lp'] > r1['lp'] + 100 and rms2 < 0.5 * rms1, (r1['lp'], r2['lp'], rms1, rms2)
+
+
+def test_random_percentile_and_summary_cases_against_numpy():
+    """tests/fuzz_post.py, cases 0 ... 59 (record of 400: profiles/r02/fuzz_post.txt)."""
+    from tests.fuzz_post import run_case
+    for n in range(60):
+        status, text = run_case(n)
+        assert status == 'ok', 'case %d %s' % (n, text)
