@@ -6,7 +6,8 @@ Test infrastructure (it imports oracle/).  `tests/test_gpu_fuzz.py` runs a fixed
 `python -m tests.fuzz_parity --first 0 --count 300` is the soak that list was drawn from (record: profiles/r02/fuzz_parity.txt).
 
 Per case:
-  0. the matrices built on the device (bdrt_build_A / bdrt_build_L) against the oracle's: 1e-11 of the largest entry;
+  0. the matrices built on the device (bdrt_build_A / _L / _M) against the oracle's: the case's own A and L (1e-11 of the
+     largest entry), plus one A of a random kernel (DRT, blocking / transmissive planar DDT, series / parallel, charge transfer) and M_0..2;
   1. log-posterior and gradient at random points, with and without the Jacobian term: |dlp| <= 1e-10 max(1, |lp|),
      |dg|_inf <= 1e-10 max(1, |g|_inf);
   2. the one-chain-per-workgroup evaluator of bdrt_solo_wide.h (where the problem takes it): same bounds;
@@ -142,6 +143,37 @@ def run_case(n, verbose=False):
             Lg = gm.construct_L(bf, tau=tau, epsilon=eps, order=o)
             if not np.max(np.abs(Lg - L[o])) <= 1e-11 * np.max(np.abs(L[o])):
                 fails.append('block %d: L%d differs by %.3g' % (b, o, np.max(np.abs(Lg - L[o]))))
+    # 0b: one more matrix set per case with a random kernel (all DDT kinds, series / parallel, charge transfer) and the
+    #     integrated-penalty matrices M_0..2, on the case's own frequency / tau grids
+    rk = np.random.default_rng(7 * n + 3)
+    # (not the blocking-spherical DDT: the reference's formula tanh x / (x - tanh x) loses every digit for omega tau << 1 --
+    #  on these wide random grids the reference-style evaluation gives inf / NaN / noise in both implementations, each in its
+    #  own way; tests/test_gpu_matrices.py checks that kernel against the reference's own matrices where those are finite)
+    kind = [('DRT', None, None), ('DDT', 'blocking', 'planar'), ('DDT', 'transmissive', 'planar'), ('DDT', 'transmissive', 'planar')][int(rk.integers(0, 4))]
+    bf0, tau0, eps0 = case['mats'][0][0], case['mats'][0][1], case['mats'][0][2]
+    akw = dict(kernel=kind[0], dist_type='series' if kind[0] == 'DRT' else str(rk.choice(['series', 'parallel'])))
+    if kind[0] == 'DDT':
+        akw.update(bc=kind[1], symmetry=kind[2])
+        if rk.random() < 0.4:
+            akw.update(ct=True, k_ct=float(10 ** rk.uniform(-2, 3)))
+    try:
+        if len(case['freq']) * len(tau0) > 5000 and n % 4:
+            raise RuntimeError('skipped')                  # (the CPU quadrature of a large general matrix takes seconds)
+        Ao = [orc.construct_A(case['freq'], p, tau=tau0, epsilon=eps0, **akw) for p in ('real', 'imag')]
+        Ag = [gm.construct_A(case['freq'], p, tau=tau0, epsilon=eps0, **akw) for p in ('real', 'imag')]
+        mag = np.sqrt(Ao[0] ** 2 + Ao[1] ** 2)
+        okm = np.isfinite(Ao[0]) & np.isfinite(Ao[1])
+        err = np.maximum(np.abs(Ag[0] - Ao[0]), np.abs(Ag[1] - Ao[1]))
+        tolA = 1e-11
+        if not (np.all(np.isfinite(Ag[0][okm])) and np.all(err[okm] <= tolA * mag[okm] + 1e-300)):
+            fails.append('matrix %s: relative error %.3g' % (akw, float(np.nanmax(err[okm] / mag[okm]))))
+    except Exception as e:
+        if 'not equal' not in str(e) and str(e) != 'skipped':   # (the reference's own Toeplitz consistency check may refuse a grid)
+            fails.append('matrix %s: %s %s' % (akw, type(e).__name__, e))
+    for o in (0, 1, 2):
+        Mo, Mg = orc.construct_M(tau0, eps0, o), gm.construct_M(bf0, order=o, epsilon=eps0)
+        if not np.max(np.abs(Mg - Mo)) <= 1e-11 * np.max(np.abs(Mo)):
+            fails.append('M%d differs by %.3g of the largest entry' % (o, np.max(np.abs(Mg - Mo)) / np.max(np.abs(Mo))))
     # 1, 2: evaluators
     npts = 5
     theta = np.ascontiguousarray(rng.uniform(-2, 2, (npts, prob.D)))
