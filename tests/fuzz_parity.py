@@ -11,9 +11,9 @@ Per case:
   1. log-posterior and gradient at random points, with and without the Jacobian term: |dlp| <= 1e-10 max(1, |lp|),
      |dg|_inf <= 1e-10 max(1, |g|_inf);
   2. the one-chain-per-workgroup evaluator of bdrt_solo_wide.h (where the problem takes it): same bounds;
-  3. a short NUTS run (6 warm-up + 4 draws, tree depth <= 5) of 1 ... 40 units: per checked unit the number of leapfrogs and of
-     divergences equal the oracle's, the draws agree to 1e-6 of the largest coordinate (summation-order noise amplified by a
-     few dozen leapfrogs; bit-equality is not defined between a tree-reduced and a sequential sum);
+  3. a short NUTS run (0 / 6 / 20 / 24 warm-up iterations + 4 draws, tree depth <= 5) of 1 ... 40 units: per checked unit the number of leapfrogs and of
+     divergences equal the oracle's, the draws agree to 1e-6 of the largest coordinate (1e-4 after 20 / 24 warm-up iterations:
+     summation-order noise amplified by the leapfrogs; bit-equality is not defined between a tree-reduced and a sequential sum);
   4. MAP from a random start (bdrt_optimize, defaults): where convergence is reported (|grad|_inf < 1e-8), the oracle's gradient
      at the answer is < 1e-6 and its lp equals the reported lp to 1e-9; the lp never ends below the start's.
 """
@@ -198,7 +198,10 @@ def run_case(n, verbose=False):
                                                                                      np.max(np.abs(gr))))
     # 3: sampler
     ctrl = NutsControl(); prob._lib.bdrt_nuts_defaults(C.byref(ctrl)); ctrl.max_treedepth = 5
-    warm, nd, nu, seed = 6, 4, case['n_units'], case['seed']
+    # (warm-up lengths on both sides of Stan's 20-iteration threshold for windowed adaptation: 20 and 24 include a metric
+    #  update and the step-size search that follows it)
+    warm = int(np.random.default_rng(11 * n + 1).choice([6, 6, 0, 20, 24]))
+    nd, nu, seed = 4, case['n_units'], case['seed']
     uspec = (np.arange(nu) % n_spectra).astype(np.int32)
     try:
         smp = Sampler(prob, nu, warm, nd, seed, ctrl, spec=uspec)
@@ -218,7 +221,7 @@ def run_case(n, verbose=False):
                                                                                         diag[c]['n_divergent'], dr['n_divergent']))
             continue
         err = np.max(np.abs(draws[c] - ref)) / np.max(np.abs(ref))
-        if not err < 1e-6:
+        if not err < (1e-6 if warm <= 6 else 1e-4):         # (28 transitions amplify the summation-order noise further)
             fails.append('sampler unit %d: draws differ by %.3g' % (c, err))
     # 4: MAP (Levenberg-Marquardt Newton on the device): where it reports convergence the oracle's gradient at the answer
     #    vanishes as well and the oracle's lp equals the reported one; "no convergence" is reported, never hidden
@@ -232,7 +235,7 @@ def run_case(n, verbose=False):
     if not np.isfinite(lr) or lr < oms[0].logp_grad(th0[0], False)[0]:
         fails.append('MAP: lp at the answer %.6g below lp at the start' % lr)
     prob.close()
-    text += ' D=%d kernel=%d map=%s' % (prob.D, kind, 'converged/%d' % rep[0]['newton_iterations'] if conv else
+    text += ' D=%d kernel=%d warm=%d map=%s' % (prob.D, kind, warm, 'converged/%d' % rep[0]['newton_iterations'] if conv else
                                         'rc%d,|g|=%.1e' % (rep[0]['return_code'], rep[0]['grad_inf']))
     if fails:
         return 'FAIL', text + '\n    ' + '\n    '.join(fails)
