@@ -11,7 +11,10 @@ No reference output exists for random inputs, so the checks are properties every
   3. a non-negative fit has gamma >= 0 everywhere; R_inf and the polarisation resistance are within 25 % (+ noise) of the
      spectrum's true values (60 % for 16-point spectra and for the short NUTS runs) -- the relaxations lie two decades inside
      the frequency window;
-  4. NUTS: the percentile band brackets its own median, the posterior-mean impedance meets the same residual bound.
+  4. NUTS: the percentile band brackets its own median, the posterior-mean impedance meets the same residual bound;
+  5. every prediction entry point (predict_Z on fitted and new frequencies, predict_distribution, predict_Rp, predict_sigma,
+     coef_percentile, score; with percentiles for NUTS fits) returns finite, ordered numbers, and a fresh Inverter that loads the
+     saved fit predicts bit-identical values.
 
 Test infrastructure: `python -m tests.fuzz_inverter --count 100` (record: profiles/r02/fuzz_inverter.txt)."""
 import argparse
@@ -79,6 +82,56 @@ def make_case(n):
     return dict(f=f, Z=Z, bf=bf, kw=kw, sig=sig, R0=R0, Rp=Rp, out_idx=out_idx, mode=mode, multi=multi), text
 
 
+def _api_sweep(inv, case, tau):
+    """Every prediction entry point of the fitted object, with and without percentiles, then a save / load round trip into a
+    fresh Inverter that must predict the same numbers (reference :3980-4064)."""
+    from bayes_drt_amd.inversion import Inverter
+    f = case['f']
+    fails = []
+    f_new = np.logspace(np.log10(f[0]) - 0.3, np.log10(f[-1]) + 0.3, 37)       # frequencies that were not fitted
+    sample = case['mode'] == 'sample'
+    qs = (None, 2.5, 50, 97.5) if sample else (None,)
+    name = 'DRT'
+    out = {}
+    try:
+        for q in qs:
+            out['Z', q] = inv.predict_Z(f_new, percentile=q)
+            out['Zf', q] = inv.predict_Z(f, percentile=q)
+            out['g', q] = inv.predict_distribution(name, eval_tau=tau, percentile=q)
+            out['Rp', q] = np.atleast_1d(inv.predict_Rp(percentile=q))
+            s_re, s_im = inv.predict_sigma(f, percentile=q)
+            out['sre', q], out['sim', q] = s_re, s_im
+            if sample and q is not None:
+                out['coef', q] = inv.coef_percentile(name, q)
+        out['score'] = np.atleast_1d(inv.score(f, case['Z']))
+    except Exception as e:
+        import traceback
+        return ['prediction API raised %s: %s | %s' % (type(e).__name__, e, traceback.format_exc()[-300:].replace('\n', ' / '))]
+    for k, v in out.items():
+        v = np.asarray(v)
+        if not np.all(np.isfinite(v.real if np.iscomplexobj(v) else v)):
+            fails.append('%s not finite' % (k,))
+    if np.any(out['sre', None] <= 0) or np.any(out['sim', None] <= 0):
+        fails.append('predict_sigma not positive')
+    if sample:
+        for key in ('g', 'sre', 'sim', 'Rp'):
+            if not (np.all(out[key, 2.5] <= out[key, 50] + 1e-12) and np.all(out[key, 50] <= out[key, 97.5] + 1e-12)):
+                fails.append('%s percentiles not ordered' % key)
+    # persistence
+    try:
+        d = inv.save_fit_data(which='core')
+        new = Inverter(basis_freq=case['bf'], distributions=inv.distributions) if case['multi'] else Inverter(basis_freq=case['bf'])
+        new.load_fit_data(d)
+        for q in qs:
+            if not np.array_equal(new.predict_Z(f_new, percentile=q), out['Z', q]):
+                fails.append('after load: predict_Z(percentile=%s) differs' % q)
+            if not np.array_equal(new.predict_distribution(name, eval_tau=tau, percentile=q), out['g', q]):
+                fails.append('after load: predict_distribution(percentile=%s) differs' % q)
+    except Exception as e:
+        fails.append('save / load raised %s: %s' % (type(e).__name__, e))
+    return fails
+
+
 def run_case(n):
     from bayes_drt_amd.inversion import Inverter
     case, text = make_case(n)
@@ -130,6 +183,7 @@ def run_case(n):
     if not (np.isfinite(inv.R_inf) and abs(inv.R_inf - case['R0']) <= tol * (case['R0'] + 0.3 * case['Rp'])):
         fails.append('R_inf %.4g (true %.4g)' % (inv.R_inf, case['R0']))
     if case['multi']:
+        fails += _api_sweep(inv, case, tau)
         return ('FAIL', text + ' :: ' + info + '\n    ' + '\n    '.join(fails)) if fails else ('ok', text + ' :: ' + info)
     rp = inv.predict_Rp()
     rp = float(np.atleast_1d(rp)[0]) if np.ndim(rp) else float(rp)
@@ -139,6 +193,7 @@ def run_case(n):
         lo, med, hi_ = (inv.predict_distribution('DRT', eval_tau=tau, percentile=q) for q in (2.5, 50, 97.5))
         if not (np.all(lo <= med + 1e-12) and np.all(med <= hi_ + 1e-12) and np.all(np.isfinite(hi_))):
             fails.append('percentile band does not bracket its median')
+    fails += _api_sweep(inv, case, tau)
     return ('FAIL', text + ' :: ' + info + '\n    ' + '\n    '.join(fails)) if fails else ('ok', text + ' :: ' + info)
 
 
