@@ -174,11 +174,21 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product has no CPU path')
+    # BDRT_BENCH_ONE_DEVICE=1 (test only): every rank on device 0 with a gloo group -- RCCL refuses two ranks on one device --
+    # so that a 1-GPU box can run the N > 1 code path (partition, barriers, reductions, the sharded round trip).  The line is
+    # marked; its value says nothing about scaling.
+    one_device = bool(os.environ.get('BDRT_BENCH_ONE_DEVICE'))
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # BDRT_BENCH_FORCE_DIST=1: take the RCCL code path with a single rank too (lets a 1-GPU box exercise it)
     use_dist = world > 1 or (bool(os.environ.get('BDRT_BENCH_FORCE_DIST')) and 'RANK' in os.environ)
     if use_dist:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if one_device:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    red_dev = 'cpu' if one_device else 'cuda'
 
     from bayes_drt_amd import _lib, parallel as par
     from bayes_drt_amd._lib import NutsControl, check
@@ -295,9 +305,9 @@ def main():
             roundtrip = {'error': '%s: %s' % (type(exc).__name__, exc)}
 
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        e = torch.tensor([evals], dtype=torch.float64, device='cuda')
+        e = torch.tensor([evals], dtype=torch.float64, device=red_dev)
         dist.all_reduce(e, op=dist.ReduceOp.SUM)
         elapsed, evals = float(t.item()), float(e.item())
 
@@ -336,6 +346,8 @@ def main():
         }
         if roundtrip is not None:
             line['config']['dist_roundtrip'] = roundtrip
+        if one_device:
+            line['config']['test_mode'] = 'all %d ranks on ONE device over gloo (BDRT_BENCH_ONE_DEVICE): not a scaling measurement' % world
         if sweep is not None:
             line['config']['raw_logp_grad_kernel_sweep'] = sweep
         if cpu is not None:

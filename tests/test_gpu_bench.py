@@ -62,3 +62,21 @@ def test_bench_contract_under_torchrun_single_rank():
     assert d['config']['evals_in_timed_region'] == d['config']['units_per_gpu'] * 50 * 4
     rt = d['config']['dist_roundtrip']            # broadcast + short sample_sharded run + summary gather over RCCL
     assert rt['finite'] and rt['ms'] > 0 and rt['gather'] == 'summary'
+
+
+def test_bench_two_ranks_on_the_one_device():
+    """The N = 2 code path of bench.py (unit partition, barriers, max / sum reductions, the sample_sharded round trip) under the
+    driver's launcher, both ranks on the box's single GPU over gloo (BDRT_BENCH_ONE_DEVICE=1; RCCL refuses two ranks on one
+    device).  Checks the bookkeeping, not a rate."""
+    env = dict(os.environ, BDRT_BENCH_ONE_DEVICE='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', '29541', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3',
+           '--warmup', '1', '--rounds', '40', '--no-cpu-baseline', '--spectra', '32']
+    d = _line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['scaling'] == 'weak' and 'test_mode' in d['config']
+    # weak scaling: every rank runs its own 32 spectra x 8 chains; the line counts the evaluations of both
+    assert d['config']['units_per_gpu'] == 32 * 8
+    assert d['config']['evals_in_timed_region'] == 2 * d['config']['units_per_gpu'] * 40 * 3
+    assert d['value'] > 1e5
+    rt = d['config']['dist_roundtrip']
+    assert 'error' not in rt and rt['finite'] and rt['spectra'] == 16
