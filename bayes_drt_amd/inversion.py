@@ -169,6 +169,15 @@ def _check_basis(basis):
         raise ValueError(f'Invalid basis {basis}. Options are gaussian')
 
 
+def _check_basis_freq(basis_freq):
+    # The reference assumes a descending basis (np.logspace(high, low, K)) without saying so: it never sorts basis_freq, and
+    # with an ascending one its integrals over ln(tau) -- predict_Rp, the M matrices' spacing -- change sign.  Same here, so
+    # say it once instead of returning a negative polarisation resistance silently.
+    if basis_freq is not None and np.ndim(basis_freq) == 1 and len(basis_freq) > 1 and np.any(np.diff(np.asarray(basis_freq, dtype=float)) >= 0):
+        warnings.warn('basis_freq is not in strictly descending order: like the reference, this class does not sort the basis, '
+                      'and quantities integrated over ln(tau) (predict_Rp) change sign for an ascending one')
+
+
 class Inverter:
     def __init__(self, basis_freq=None, basis='gaussian', epsilon=None, fit_inductance=True,
                  distributions={'DRT': {'kernel': 'DRT'}}):
@@ -223,7 +232,7 @@ class Inverter:
     distributions = property(get_distributions, set_distributions)
 
     # ------------------------------------------------------------------ properties (reference :4069-4110)
-    get_basis_freq, set_basis_freq = _invalidating_property('_basis_freq')
+    get_basis_freq, set_basis_freq = _invalidating_property('_basis_freq', _check_basis_freq)
     basis_freq = property(get_basis_freq, set_basis_freq)
     get_basis, set_basis = _invalidating_property('_basis', _check_basis)
     basis = property(get_basis, set_basis)

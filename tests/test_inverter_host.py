@@ -226,3 +226,14 @@ def test_stan_data_for_single_part_fits_matches_reference(inv_mod):
     with pytest.raises(ValueError):
         inv._prep_stan_data(fs, Zs, 'real', 'Series', dm, False, 0.002, mode='optimize', inductance_scale=1,
                             outlier_lambda=None, fitY=False, SA=False, SASY=False)
+
+
+def test_ascending_basis_is_flagged(inv_mod):
+    """The reference never sorts basis_freq; an ascending one flips the sign of its ln(tau) integrals.  Same here, with a warning."""
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        inv_mod.Inverter(basis_freq=np.logspace(6, -2, 21))
+        assert not w
+        inv_mod.Inverter(basis_freq=np.logspace(-2, 6, 21))
+        assert len(w) == 1 and 'descending' in str(w[0].message)
