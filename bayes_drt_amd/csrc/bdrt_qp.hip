@@ -185,7 +185,7 @@ __device__ inline int qp_box_solve(const double *__restrict__ P, const double *_
             ok = chol_packed(M, diag, n);
             if (ok) break;
             reg = reg == 0.0 ? 1e-14 * (1.0 + fabs(m00)) : reg * 100.0;
-            if (reg > 1e6) break;
+            if (!(reg <= 1e6)) break;                                  // (also leaves on NaN: non-finite input must not spin here)
         }
         return ok;
     };

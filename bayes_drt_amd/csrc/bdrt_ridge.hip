@@ -144,7 +144,7 @@ int bdrt_qp_box(const double *P, const double *q, const double *lo, int n, doubl
             reg = reg == 0.0 ? 1e-14 * (1.0 + std::fabs(M[0])) : reg * 100.0;
             L = M;
             for (int i = 0; i < n; ++i) L[(size_t)i * n + i] += reg;
-            if (reg > 1e6) return false;
+            if (!(reg <= 1e6)) return false;                // (also on NaN)
         }
         return true;
     };

@@ -169,6 +169,18 @@ def _check_basis(basis):
         raise ValueError(f'Invalid basis {basis}. Options are gaussian')
 
 
+def _validate_spectrum(frequencies, Z):
+    """The reference hands NaN / inf / non-positive frequencies to cvxopt and Stan, which fail or return NaN in their own ways;
+    here such input never reaches a kernel."""
+    frequencies, Z = np.asarray(frequencies, dtype=float), np.asarray(Z)
+    if len(frequencies) != len(Z):
+        raise ValueError("Length of frequencies and Z must be equal")
+    if not (np.all(np.isfinite(frequencies)) and np.all(np.isfinite(Z))):
+        raise ValueError('frequencies and Z must be finite (NaN / inf found)')
+    if np.any(frequencies <= 0):
+        raise ValueError('frequencies must be positive')
+
+
 def _check_basis_freq(basis_freq):
     # The reference assumes a descending basis (np.logspace(high, low, K)) without saying so: it never sorts basis_freq, and
     # with an ascending one its integrals over ln(tau) -- predict_Rp, the M matrices' spacing -- change sign.  Same here, so
@@ -707,6 +719,7 @@ class Inverter:
             raise ValueError(f"Invalid part {part}. Options are 'both', 'real', or 'imag'")
         if mode not in ('optimize', 'sample'):
             raise ValueError("mode must be 'optimize' or 'sample'")
+        _validate_spectrum(frequencies, Z)
         if init_from_ridge:
             if len(self.distributions) > 1:
                 raise ValueError('Ridge initialization can only be performed for single-distribution fits')
@@ -920,6 +933,7 @@ class Inverter:
             raise ValueError("Length of frequencies and Z must be equal")
         Z = np.array(Z) if type(Z) != np.ndarray else Z
         frequencies = np.array(frequencies, dtype=float) if type(frequencies) != np.ndarray else frequencies
+        _validate_spectrum(frequencies, Z)
         if sort_desc:
             order = np.argsort(frequencies)[::-1]
             frequencies, Z = frequencies[order], Z[order]
@@ -1069,6 +1083,9 @@ class Inverter:
             if info['kernel'] == 'DDT' and info['symmetry'] == 'planar':
                 target = 14 if info['bc'] == 'transmissive' else 2.4
                 self._Z_scale = target * np.sqrt(len(Z) / 81) / np.std(np.abs(1 / Z))
+        if not (np.isfinite(self._Z_scale) and self._Z_scale > 0):
+            raise ValueError('the modulus of Z has no spread (std |Z| = %r): the spectrum cannot be scaled; pass scale_Z=False '
+                             'or check the data' % (self._Z_scale,))
         return Z / self._Z_scale
 
     def _rescale_coef(self, coef, dist_type):

@@ -127,3 +127,46 @@ def test_sampler_argument_checks_and_empty_runs():
     draws, lp, diag = sample_units(prob, 3, 0, 5, 1)              # no warm-up: unit step size search, then draws
     assert draws.shape == (3, 5, prob.D) and np.all(np.isfinite(draws))
     prob.close()
+
+
+@pytest.mark.timeout(120)
+def test_non_finite_or_degenerate_spectra_are_refused_not_hung_on():
+    """NaN / inf in Z, non-positive frequencies, a spectrum without spread: `Inverter` refuses them before any kernel runs (they
+    used to spin in the KKT regularisation loop of the QP kernel -- on the device -- because `reg > 1e6` is false for NaN).  The
+    C ABI itself returns an error for a non-finite QP and a non-zero return code for a MAP without a finite log-posterior."""
+    import warnings
+    from bayes_drt_amd._lib import BdrtError
+    from bayes_drt_amd.engine import optimize_batch
+    from bayes_drt_amd.inversion import Inverter, _qp_batch
+    from bayes_drt_amd.model import Problem
+    f = np.logspace(5, -1, 31)
+    w = 2 * np.pi * f
+    Z = 1.0 + 2.0 / (1 + (1j * w * 1e-2) ** 0.9)
+    for bad in (np.nan, np.inf):
+        Zb = Z.copy(); Zb[4] = bad
+        for call in (lambda inv: inv.fit(f, Zb, nonneg=True), lambda inv: inv.ridge_fit(f, Zb),
+                     lambda inv: inv.fit(f, Zb, nonneg=True, mode='sample', warmup=5, samples=2),
+                     lambda inv: inv.ridge_ReImCV(f, Zb, lambdas=np.logspace(-3, 0, 3))):
+            with pytest.raises(ValueError):
+                call(Inverter(basis_freq=f))
+    with pytest.raises(ValueError):
+        Inverter(basis_freq=f).fit(np.r_[f[:-1], 0.0], Z, nonneg=True)
+    with pytest.raises(ValueError):
+        Inverter(basis_freq=f).ridge_fit(f, np.zeros_like(Z))
+    # the C ABI on its own
+    n = 12
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((20, n)); P = A.T @ A; q = rng.standard_normal(n)
+    Pn = P.copy(); Pn[3, 3] = np.nan
+    with pytest.raises(BdrtError):
+        _qp_batch(Pn[None], q[None], np.zeros(n))
+    x, obj = _qp_batch(P[None], q[None], np.zeros(n))                  # (and the kernel still works afterwards)
+    assert np.all(np.isfinite(x))
+    blk, Zs, fs, kw = _problem(40, 64)
+    Zs = Zs.copy(); Zs[3] = np.nan
+    prob = Problem([blk], Zs, fs, **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        out, rep = optimize_batch(prob, np.zeros((1, prob.D)))
+    assert rep[0]['return_code'] != 0
+    prob.close()
