@@ -81,6 +81,19 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
         set_error("bdrt_problem_create: Z/freq missing or n_spectra < 1");
         return -1;
     }
+    // The matrices and the frequency list must be finite: the structure detection below (Toeplitz generators, banded L) reads
+    // a few rows and columns and would silently drop a stray NaN / inf elsewhere.  (Z may hold NaN: the log-posterior is then
+    // not finite and every caller reports that, see bdrt.h.)
+    {
+        auto finite = [](const double *v, size_t n) { for (size_t i = 0; i < n; ++i) if (!std::isfinite(v[i])) return false; return true; };
+        bool ok = finite(dat->freq, (size_t)dat->nf);
+        for (int b = 0; b < dat->nblocks && ok; ++b) {
+            const size_t K = (size_t)dat->K[b];
+            if (dat->K[b] < 1 || !dat->A[b] || !dat->L0[b] || !dat->L1[b] || !dat->L2[b]) { set_error("bdrt_problem_create: block %d incomplete", b); return -1; }
+            ok = finite(dat->A[b], 2 * (size_t)dat->nf * K) && finite(dat->L0[b], K * K) && finite(dat->L1[b], K * K) && finite(dat->L2[b], K * K);
+        }
+        if (!ok) { set_error("bdrt_problem_create: non-finite entry in freq / A / L0 / L1 / L2"); return -1; }
+    }
     bind_process_device();
     BDRT_HIP(hipGetDevice(&P.device));
     DevProblem &D = P.dev;

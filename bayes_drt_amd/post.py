@@ -37,7 +37,7 @@ def project_percentile(samples, Phi, bias, q):
     X = np.ascontiguousarray(X)
     rows, K = X.shape
     qa = np.atleast_1d(np.asarray(q, dtype=np.float64))
-    if np.any(qa < 0) or np.any(qa > 100):
+    if not np.all((qa >= 0) & (qa <= 100)):              # (NaN included, like numpy)
         raise ValueError('Percentiles must be in the range [0, 100]')
     M = 0
     P = b = None
@@ -71,7 +71,7 @@ def summary(draws, q, is_pos=None):
         raise ValueError('summary: draws must be [rows x K]')
     rows, K = X.shape
     qa = np.ascontiguousarray(np.atleast_1d(np.asarray(q, dtype=np.float64)))
-    if np.any(qa < 0) or np.any(qa > 100):
+    if not np.all((qa >= 0) & (qa <= 100)):              # (NaN included, like numpy)
         raise ValueError('Percentiles must be in the range [0, 100]')
     mask = None
     if is_pos is not None:

@@ -163,6 +163,14 @@ def test_non_finite_or_degenerate_spectra_are_refused_not_hung_on():
     x, obj = _qp_batch(P[None], q[None], np.zeros(n))                  # (and the kernel still works afterwards)
     assert np.all(np.isfinite(x))
     blk, Zs, fs, kw = _problem(40, 64)
+    for key in ('A', 'L1'):                                            # matrices must be finite: refused at creation
+        bad = dict(blk); bad[key] = blk[key].copy(); bad[key][3, 5] = np.inf if key == 'L1' else np.nan
+        with pytest.raises(BdrtError) as e:
+            Problem([bad], Zs, fs, **kw)
+        assert 'non-finite' in str(e.value)
+    from bayes_drt_amd import post
+    with pytest.raises(ValueError):
+        post.percentile(np.ones((5, 3)), np.nan)                       # numpy: "Percentiles must be in the range [0, 100]"
     Zs = Zs.copy(); Zs[3] = np.nan
     prob = Problem([blk], Zs, fs, **kw)
     with warnings.catch_warnings():
