@@ -1387,6 +1387,14 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     bdrt_nuts_control c;
     if (ctrl) c = *ctrl; else bdrt_nuts_defaults(&c);
     if (c.max_treedepth < 1 || c.max_treedepth > MAXD) { set_error("max_treedepth must be in [1,%d]", MAXD); return nullptr; }
+    // Stan's argument checks (stan::services: adapt delta in (0,1), gamma / kappa / t0 / stepsize > 0, init radius >= 0); written so
+    // that NaN fails them.  Nonsense here does not crash a kernel, it silently gives nonsense chains.
+    if (!(c.adapt_delta > 0.0 && c.adapt_delta < 1.0)) { set_error("bdrt_sampler_create: adapt_delta must be in (0,1)"); return nullptr; }
+    if (!(c.adapt_gamma > 0.0) || !(c.adapt_kappa > 0.0) || !(c.adapt_t0 > 0.0)) { set_error("bdrt_sampler_create: adapt_gamma, adapt_kappa, adapt_t0 must be positive"); return nullptr; }
+    if (!(c.stepsize0 > 0.0) || !std::isfinite(c.stepsize0)) { set_error("bdrt_sampler_create: stepsize0 must be positive and finite"); return nullptr; }
+    if (!(c.init_radius >= 0.0) || !std::isfinite(c.init_radius)) { set_error("bdrt_sampler_create: init_radius must be >= 0 and finite"); return nullptr; }
+    if (!(c.max_deltaH > 0.0)) { set_error("bdrt_sampler_create: max_deltaH must be positive"); return nullptr; }
+    if (c.init_buffer < 0 || c.term_buffer < 0 || c.base_window < 0) { set_error("bdrt_sampler_create: adaptation window sizes must be >= 0"); return nullptr; }
     Problem &P = p->impl;
     if (hipSetDevice(P.device) != hipSuccess) { set_error("bdrt_sampler_create: hipSetDevice(%d) failed", P.device); return nullptr; }
     bdrt_sampler *s = new bdrt_sampler();

@@ -156,6 +156,8 @@ typedef struct {
     double stepsize;        /* adapted step size                         */
     double mean_accept;     /* mean accept_stat post-warm-up             */
 } bdrt_chain_diag;
+/* bdrt_sampler_create checks the control block the way Stan's services do: adapt_delta in (0,1); adapt_gamma, adapt_kappa,
+ * adapt_t0, stepsize0, max_deltaH > 0; init_radius >= 0; window sizes >= 0; max_treedepth in [1,10]; NaN fails every check. */
 void bdrt_nuts_defaults(bdrt_nuts_control *c);
 
 typedef struct bdrt_sampler bdrt_sampler;

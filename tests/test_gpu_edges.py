@@ -122,6 +122,16 @@ def test_sampler_argument_checks_and_empty_runs():
         sample_units(prob, 2, -1, 10, 1)
     with pytest.raises(BdrtError):
         sample_units(prob, 2, 10, 10, 1, spec=[0, 1])            # spectrum 1 does not exist
+    import ctypes as C
+    from bayes_drt_amd._lib import NutsControl
+    for bad in (dict(adapt_delta=1.0), dict(adapt_delta=0.0), dict(adapt_delta=float('nan')), dict(stepsize0=0.0), dict(stepsize0=float('inf')),
+                dict(stepsize0=-1.0), dict(adapt_gamma=0.0), dict(adapt_t0=-5.0), dict(max_deltaH=float('nan')), dict(init_radius=-1.0),
+                dict(base_window=-1), dict(max_treedepth=0), dict(max_treedepth=11)):
+        c = NutsControl(); prob._lib.bdrt_nuts_defaults(C.byref(c))
+        for k, v in bad.items():
+            setattr(c, k, v)
+        with pytest.raises(BdrtError):                                # Stan's own argument checks; NaN fails them too
+            sample_units(prob, 2, 10, 5, 1, c)
     draws, lp, diag = sample_units(prob, 3, 12, 0, 1)             # warm-up only: no draws, the chains still ran
     assert draws.shape == (3, 0, prob.D) and all(d['n_leapfrog'] > 0 for d in diag)
     draws, lp, diag = sample_units(prob, 3, 0, 5, 1)              # no warm-up: unit step size search, then draws
