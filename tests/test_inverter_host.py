@@ -237,3 +237,17 @@ def test_ascending_basis_is_flagged(inv_mod):
         assert not w
         inv_mod.Inverter(basis_freq=np.logspace(-2, 6, 21))
         assert len(w) == 1 and 'descending' in str(w[0].message)
+
+
+def test_non_finite_spectra_are_refused_before_any_kernel(inv_mod):
+    """(runs without a GPU: the check comes first)"""
+    f = np.logspace(5, -1, 31)
+    Z = 1.0 + 2.0 / (1 + (2j * np.pi * f * 1e-2) ** 0.9)
+    for bad in (np.nan, np.inf):
+        Zb = Z.copy(); Zb[4] = bad
+        with pytest.raises(ValueError, match='finite'):
+            inv_mod.Inverter(basis_freq=f).fit(f, Zb, nonneg=True)
+    with pytest.raises(ValueError, match='positive'):
+        inv_mod.Inverter(basis_freq=f).fit(np.r_[f[:-1], -1.0], Z)
+    with pytest.raises(ValueError, match='equal'):
+        inv_mod.Inverter(basis_freq=f).fit(f[:-1], Z)
