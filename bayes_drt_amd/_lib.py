@@ -82,6 +82,31 @@ def library_path():
     return os.path.join(_HERE, 'libbdrt.so')
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch's ROCm wheels bundle their own libamdhip64 / libhsa-runtime64; libbdrt.so is linked
+    against the system ROCm.  Loaded in the order "libbdrt first, torch later" the process ends up with BOTH runtimes and the
+    second one finds no GPU ("No HIP GPUs are available" from torch).  In the order "torch first" libbdrt's dependency resolves
+    to the runtime torch brought (same SONAME) -- the configuration bench.py, the tests and parallel.py run in.  So when
+    PyTorch is installed, its runtime is loaded before libbdrt.so whatever the caller imports first (without importing torch).
+    BDRT_HIP_RUNTIME=system skips this (a process that will never import torch)."""
+    import importlib.util
+    import sys
+    if 'torch' in sys.modules or os.environ.get('BDRT_HIP_RUNTIME') == 'system':
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass                                   # fall back to the system runtime libbdrt.so was linked against
+
+
 def load_library():
     """Load libbdrt.so.  Raises BdrtError when it has not been built (no silent fallback)."""
     global _LIB
@@ -91,6 +116,7 @@ def load_library():
     if not os.path.exists(path):
         raise BdrtError('libbdrt.so not found at %s: build it with `python -c "import __graft_entry__ as g; '
                         'g.build()"` or `make -C bayes_drt_amd/csrc`' % path)
+    _preload_hip_runtime()
     lib = C.CDLL(path)
     vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.c_void_p
     lib.bdrt_last_error.restype = C.c_char_p

@@ -188,3 +188,47 @@ def test_non_finite_or_degenerate_spectra_are_refused_not_hung_on():
         out, rep = optimize_batch(prob, np.zeros((1, prob.D)))
     assert rep[0]['return_code'] != 0
     prob.close()
+
+
+def test_device_memory_does_not_grow_over_many_problems_samplers_and_fits():
+    """Create / use / destroy cycles (problems, MAP, samplers of the three kernel kinds, Inverter ridge + MAP + NUTS fits): the
+    free device memory after 40 more cycles equals the free memory after the first ones."""
+    import gc
+    import warnings
+    import torch
+    from bayes_drt_amd.engine import optimize_batch, sample_units
+    from bayes_drt_amd.inversion import Inverter
+    from bayes_drt_amd.model import Problem
+
+    def free_mib():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0] / 2 ** 20
+
+    blk, Z, f, kw = _problem(81, 161)
+    fz = np.logspace(5, -1, 41)
+    Zz = 1.0 + 2.0 / (1 + (2j * np.pi * fz * 1e-2) ** 0.9)
+
+    def cycle(i):
+        prob = Problem([blk], Z, f, **kw)
+        prob.logp_grad(np.zeros((5, prob.D)))
+        optimize_batch(prob, np.zeros((1, prob.D)), newton_max_iter=3)
+        sample_units(prob, [3, 20, 300][i % 3], 5, 3, i)
+        prob.close()
+        inv = Inverter(basis_freq=fz)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            inv.ridge_fit(fz, Zz)
+            inv.fit(fz, Zz, nonneg=True)
+            if i % 10 == 0:
+                inv.fit(fz, Zz, nonneg=True, mode='sample', warmup=10, samples=5)
+        inv.predict_Z(fz)
+
+    for i in range(6):
+        cycle(i)
+    gc.collect()
+    before = free_mib()
+    for i in range(40):
+        cycle(i)
+    gc.collect()
+    after = free_mib()
+    assert before - after < 8.0, (before, after)
