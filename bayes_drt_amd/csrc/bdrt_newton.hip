@@ -514,6 +514,7 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
     if (prof_env && prof_env[0] == '1') {
         NW_HIP(alloc(NP_COUNT * sizeof(long long), (void **)&b.prof));
         NW_HIP(hipMemset(b.prof, 0, NP_COUNT * sizeof(long long)));
+        NW_HIP(hipStreamSynchronize(nullptr));          // the fill is asynchronous; the kernels run on the problem's own stream
     }
     int *d_active = nullptr, *d_spec1 = nullptr, *d_specp = nullptr;
     double *d_lpt = nullptr;

@@ -1513,6 +1513,10 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     hipMemcpy(S.args.states, hs.data(), hs.size() * sizeof(ChainState), hipMemcpyHostToDevice);
     hipMemset(S.args.draws, 0, nd * sizeof(double));
     hipMemset(S.d_leaps, 0, sizeof(unsigned long long));
+    // hipMemset returns before the fill has happened, and the sampler's kernels run on a NON-BLOCKING stream that does not order
+    // itself behind the null stream: without this wait a launch that follows quickly (several host threads sampling at once)
+    // can have its first draws / its leapfrog counter zeroed under it.
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return fail("bdrt_sampler_create: initial fills failed");
     S.args.leap_counter = S.d_leaps;
     S.args.done_counter = S.d_done;
     S.args.active_counter = S.d_active;
@@ -1780,7 +1784,10 @@ int bdrt_sampler_phase_profile(bdrt_sampler *s, int enable, long long *cycles32)
     if (enable && !S.d_prof) {
         BDRT_HIP(hipMalloc((void **)&S.d_prof, (size_t)S.n_wg * 32 * sizeof(long long)));
     }
-    if (S.d_prof) BDRT_HIP(hipMemset(S.d_prof, 0, (size_t)S.n_wg * 32 * sizeof(long long)));
+    if (S.d_prof) {
+        BDRT_HIP(hipMemset(S.d_prof, 0, (size_t)S.n_wg * 32 * sizeof(long long)));
+        BDRT_HIP(hipStreamSynchronize(nullptr));        // (same ordering rule as in bdrt_sampler_create)
+    }
     if (!enable && S.d_prof) { hipFree(S.d_prof); S.d_prof = nullptr; }
     S.args.prof = S.d_prof;
     return 0;
