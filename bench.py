@@ -50,6 +50,16 @@ PYSTAN_DERIVED = {'value': 2250.0, 'unit': 'evals/s', 'processes': 4,
                             'K=81), scaled to K=161; not measured on this box'}
 
 
+# what the CPU figure is: the parity checker, compiled -O3 -march=native, not a tuned CPU implementation (scalar dense
+# mat-vecs, buffers allocated per evaluation, no use of the Toeplitz / band structure the GPU path exploits).  The GPU/CPU
+# ratio is context, not a quality measure -- roofline.frac is.
+CPU_PORT_NOTE = ('untuned checker: oracle/bdrt_oracle.c is the plain-C parity oracle (scalar dense mat-vecs, per-evaluation '
+                 'malloc, no Toeplitz/band shortcuts), one chain per physical core')
+# MFMA instructions the structured path issues per evaluation of a 16-chain tile: forward A (11 row tiles x 42 k-steps) +
+# backward A^T (11 x 42) = 924 v_mfma_f64_16x16x4_f64 of 2048 flop each (SQ_INSTS_MFMA in profiles/ agrees)
+MFMA_FLOP_PER_EVAL = 924 * 2048 / 16.0
+
+
 def synth_spectra(n, seed=20260101):
     """n two-ZARC spectra, parameters per SURVEY 8(d) config 4; noise models cycled uniform/Orazem/Macdonald 0.25 %."""
     rs = np.random.RandomState(seed)
@@ -112,12 +122,28 @@ def _cpu_leg(nproc, seconds):
     return total
 
 
+def physical_cores():
+    """Physical cores this process may run on (hyper-thread siblings counted once)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    cores = set()
+    for cpu in allowed:
+        try:
+            with open('/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list' % cpu) as fh:
+                cores.add(fh.read().strip())
+        except OSError:
+            cores.add(str(cpu))
+    return max(1, len(cores))
+
+
 def cpu_baseline(seconds=8.0):
     """Oracle log_prob+grad evaluations/s inside the oracle's NUTS driver on the host cores: one core, then one chain
     per core (pystan's own layout: one process per chain)."""
     from oracle import oracle as orc
     orc.build(force=True, native=True)           # -O3 -march=native for THIS host (the checker build is untouched)
-    ncores = min(os.cpu_count() or 1, 16)
+    ncores = physical_cores()
     single = _cpu_leg(1, seconds)
     allc = _cpu_leg(ncores, seconds)
     model = ''
@@ -126,11 +152,47 @@ def cpu_baseline(seconds=8.0):
             model = next((ln.split(':', 1)[1].strip() for ln in fh if ln.startswith('model name')), '')
     except OSError:
         pass
-    return dict(value=allc, unit='evals/s', cores=ncores, kind='port', single_core=single, cpu_model=model,
-                pystan_derived=PYSTAN_DERIVED,
+    return dict(value=allc, unit='evals/s', cores=ncores, kind='port', tuning=CPU_PORT_NOTE, single_core=single,
+                cpu_model=model, logical_cpus=os.cpu_count(), pystan_derived=PYSTAN_DERIVED,
                 sample='leapfrogs of real NUTS warm-up transitions (oracle/nuts_oracle.c driving oracle/bdrt_oracle.c, '
                        'Series_pos 81x161, jacobian on), gcc -O3 -march=native: 1 process x %.0f s (single_core), then %d '
                        'processes x %.0f s, one chain per core (value)' % (seconds, ncores, seconds))
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`bench.py --gpus N` started without a launcher: run the N ranks as a child `python -m torch.distributed.run` (the
+    command the driver itself uses), relay its output and return its exit code.  Refuses (non-zero) when the box has fewer
+    than N devices, unless BDRT_BENCH_ONE_DEVICE (test mode) is set."""
+    if not os.environ.get('BDRT_BENCH_ONE_DEVICE'):
+        try:
+            import torch
+            have = torch.cuda.device_count()
+        except Exception:
+            have = 0
+        if have < n:
+            sys.stderr.write('bench.py: --gpus %d asked for, %d device(s) visible; not launching\n' % (n, have))
+            return 2
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, BDRT_BENCH_SELF_LAUNCHED='1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    child = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    for ln in child.stdout.splitlines():
+        if ln not in lines:
+            sys.stderr.write(ln + '\n')
+    if child.returncode != 0 or len(lines) != 1:
+        sys.stderr.write('bench.py: launcher exited %d with %d result line(s)\n' % (child.returncode, len(lines)))
+        return child.returncode or 3
+    print(lines[0])
+    return 0
 
 
 def build_problem_kwargs(n_spectra, lib=None):
@@ -159,11 +221,20 @@ def main():
     ap.add_argument('--phase-profile', action='store_true', help='print the in-kernel cycle breakdown (perturbs timing)')
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # started bare: become the launcher.  Nothing in this process has touched the GPU yet (device_count() does not
+        # initialise HIP on this image), and the ranks are a CHILD process, never an exec.
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus must equal WORLD_SIZE')
+    if world != args.gpus:
+        # one process per GPU (pystan: one process per chain, inversion.py:1218-1221): a line that says n_gpus = N is
+        # printed by N ranks or not at all
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d; refusing to report n_gpus from a different number of '
+                         'ranks' % (args.gpus, world))
 
     # CPU baseline first (rank 0, N=1 only), before this process touches the GPU: workers are plain subprocesses
     cpu = None
@@ -288,6 +359,26 @@ def main():
             us = e0.elapsed_time(e1) / 10 * 1e3
             sweep.append({'B': B, 'us_per_launch': us, 'evals_per_s': B / us * 1e6})
 
+    # ---- BASELINE config 3 (the reference's own call shape: 4 chains of one spectrum): latency-bound, reported beside the
+    # throughput figure as SURVEY 8(d) asks.  One-chain-per-workgroup kernel (bdrt_solo.h); outside the timed region.
+    few = None
+    if rank == 0 and args.gpus == 1:
+        p1 = Problem(blocks, np.atleast_2d(Zall)[:1], freq, **local_kw)
+        s4 = Sampler(p1, 4, 1000000, 1, 1234, ctrl)
+        s4.advance(2000); s4.sync()
+        m0 = s4.total_leapfrogs(); s4.kernel_time(reset=True)
+        tf = time.perf_counter()
+        for _ in range(10):
+            s4.advance(1000)
+        s4.sync()
+        tf = time.perf_counter() - tf
+        m1 = s4.total_leapfrogs(); kms, kl = s4.kernel_time()
+        few = {'workload': 'config3: 1 spectrum x 4 NUTS chains, Series_pos 81x161', 'chains': 4,
+               'evals_per_s': (m1 - m0) / tf, 'us_per_leapfrog_round': kms * 1e3 / max(kl, 1) / 1000,
+               'sampler_kind': s4.kind(), 'bound': 'latency-bound: 4 of 256 CUs busy, one dependent evaluation per round'}
+        s4.close()
+        p1.close()
+
     # ---- N > 1: one complete sample_sharded call (broadcast + short run + summary gather), timed apart from the rate ----
     roundtrip = None
     if use_dist:
@@ -304,7 +395,19 @@ def main():
         except Exception as exc:                  # reported in the line; the steady-state rate above stands on its own
             roundtrip = {'error': '%s: %s' % (type(exc).__name__, exc)}
 
+    ranks_seen, devices_seen, backend = 1, [local_rank], 'none (single process)'
     if use_dist:
+        # who actually took part: every rank contributes 1 and its device index
+        one = torch.ones(1, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(one.item()))
+        mine = torch.tensor([float(torch.cuda.current_device())], dtype=torch.float64, device=red_dev)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        devices_seen = [int(g.item()) for g in got]
+        backend = dist.get_backend()
+        if ranks_seen != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit('bench.py: %d ranks answered, --gpus %d' % (ranks_seen, args.gpus))
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         e = torch.tensor([evals], dtype=torch.float64, device=red_dev)
@@ -319,12 +422,15 @@ def main():
         achieved = evals_per_launch * FLOP_PER_EVAL / (avg_ms * 1e-3) / 1e12
         # HBM bytes per launch of the sampler kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
         # collected separately, gfx950 correction applied: tools/profile_bench.sh), scaled to this run's launch length
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and n_units == N_SPECTRA * CHAINS_PER_SPECTRUM:
             try:
-                per_round = json.load(open(pmc)).get('hbm_bytes_per_round_corrected')
+                pj = json.load(open(pmc))
+                per_round = pj.get('hbm_bytes_per_round_corrected')
                 traffic = per_round * args.rounds if per_round else None
+                traffic_src = ('profiles/pmc_traffic.json (%s), bytes per round x %d rounds; not collected in this run -- PMC '
+                               'passes need rocprofv3 around the process' % (pj.get('source', 'rocprofv3 --pmc passes'), args.rounds))
             except Exception:
                 traffic = None
         line = {
@@ -336,12 +442,25 @@ def main():
                                    'spectra over %d GPU(s), whole spectra per rank), Series_pos 81x161 (D=331), real NUTS '
                                    'transitions; step = one launch of %d leapfrog rounds'
                                    % (args.spectra, args.chains, n_units, n_global, world, args.rounds),
+                       'ranks_seen': ranks_seen,
+                       'rccl': {'backend': backend + (' (= RCCL on ROCm)' if backend == 'nccl' else ''),
+                                'device_ids': devices_seen, 'data_path_collectives': 0,
+                                'launched_by': 'bench.py itself (child torch.distributed.run)'
+                                if os.environ.get('BDRT_BENCH_SELF_LAUNCHED') else
+                                ('torch.distributed.run' if 'RANK' in os.environ else 'plain python, one process')},
                        'units_per_gpu': n_units, 'rounds_per_launch': args.rounds,
                        'evals_in_timed_region': evals, 'timed_region_s': elapsed, 'setup_ms': setup_ms},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F64_MFMA_TFLOPS, 'traffic': traffic,
                          'kernel': 'nuts_kernel', 'avg_launch_ms': avg_ms, 'launches': launches,
                          'flop_per_eval_algorithmic': FLOP_PER_EVAL,
+                         # the same launch priced on what the structured path executes (band convolutions instead of dense
+                         # L products) and on the MFMA pipe alone (A and A^T tiles)
+                         'flop_per_eval_executed': FLOP_PER_EVAL_EXECUTED,
+                         'frac_executed': achieved * FLOP_PER_EVAL_EXECUTED / FLOP_PER_EVAL / PEAK_F64_MFMA_TFLOPS,
+                         'mfma_flop_per_eval': MFMA_FLOP_PER_EVAL,
+                         'mfma_pipe_frac': achieved * MFMA_FLOP_PER_EVAL / FLOP_PER_EVAL / PEAK_F64_MFMA_TFLOPS,
+                         'traffic_source': traffic_src,
                          'executed_tflops_structured_path': achieved * FLOP_PER_EVAL_EXECUTED / FLOP_PER_EVAL},
         }
         if roundtrip is not None:
@@ -350,6 +469,8 @@ def main():
             line['config']['test_mode'] = 'all %d ranks on ONE device over gloo (BDRT_BENCH_ONE_DEVICE): not a scaling measurement' % world
         if sweep is not None:
             line['config']['raw_logp_grad_kernel_sweep'] = sweep
+        if few is not None:
+            line['config']['few_chains'] = few
         if cpu is not None:
             line['cpu_baseline'] = cpu
         print(json.dumps(line))

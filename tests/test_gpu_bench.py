@@ -44,7 +44,13 @@ def test_driver_command_line_times_the_steady_state():
     assert 'hbm_frac_B1_accounting' not in r
     # the kernel's HIP-event time cannot exceed the wall time of the region that contains it
     assert r['avg_launch_ms'] * r['launches'] <= c['timed_region_s'] * 1e3 * 1.001
+    assert c['ranks_seen'] == 1 and c['rccl']['device_ids'] == [0]
+    assert 0 < r['mfma_pipe_frac'] < r['frac_executed'] < r['frac'] < 1
+    fc = c['few_chains']                      # BASELINE config 3 beside the throughput figure, labelled latency-bound
+    assert fc['chains'] == 4 and fc['sampler_kind'] == 1 and fc['evals_per_s'] > 2e5 and 'latency' in fc['bound']
+    assert 2.0 < fc['us_per_leapfrog_round'] < 20.0
     b = d['cpu_baseline']
+    assert 'untuned' in b['tuning'] and b['cores'] <= b['logical_cpus']
     assert b['kind'] == 'port' and b['cores'] >= 1 and 0 < b['single_core'] <= b['value']
     assert b['pystan_derived']['value'] > 0 and 'derived' in b['pystan_derived']['source']
 
@@ -80,3 +86,20 @@ def test_bench_two_ranks_on_the_one_device():
     assert d['value'] > 1e5
     rt = d['config']['dist_roundtrip']
     assert 'error' not in rt and rt['finite'] and rt['spectra'] == 16
+
+
+def test_bare_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts `torch.distributed.run` as a child before any
+    GPU call and relays the single line; the line is produced by two ranks (ranks_seen) or not at all."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['BDRT_BENCH_ONE_DEVICE'] = '1'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--rounds', '30',
+           '--no-cpu-baseline', '--spectra', '16']
+    d = _line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    assert d['n_gpus'] == 2 and d['config']['ranks_seen'] == 2 and d['config']['rccl']['device_ids'] == [0, 0]
+    assert 'bench.py itself' in d['config']['rccl']['launched_by']
+    assert d['config']['evals_in_timed_region'] == 2 * 16 * 8 * 30 * 2
+    # without the test switch a 1-GPU box must refuse: fewer devices than ranks
+    env.pop('BDRT_BENCH_ONE_DEVICE')
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith('{')]
