@@ -1509,10 +1509,13 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     if (hipMalloc((void **)&S.d_done, sizeof(int)) != hipSuccess) return fail("hipMalloc failed");
     if (hipMalloc((void **)&S.d_leaps, sizeof(unsigned long long)) != hipSuccess) return fail("hipMalloc failed");
     if (hipMalloc((void **)&S.d_active, sizeof(int)) != hipSuccess) return fail("hipMalloc failed");
-    hipMemcpy(S.args.vecs, hv.data(), nvec * sizeof(double), hipMemcpyHostToDevice);
-    hipMemcpy(S.args.states, hs.data(), hs.size() * sizeof(ChainState), hipMemcpyHostToDevice);
-    hipMemset(S.args.draws, 0, nd * sizeof(double));
-    hipMemset(S.d_leaps, 0, sizeof(unsigned long long));
+    if (hipMemcpy(S.args.vecs, hv.data(), nvec * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return fail("bdrt_sampler_create: upload of the chain vectors failed");
+    if (hipMemcpy(S.args.states, hs.data(), hs.size() * sizeof(ChainState), hipMemcpyHostToDevice) != hipSuccess)
+        return fail("bdrt_sampler_create: upload of the chain states failed");
+    if (hipMemset(S.args.draws, 0, nd * sizeof(double)) != hipSuccess) return fail("bdrt_sampler_create: clearing the draws failed");
+    if (hipMemset(S.d_leaps, 0, sizeof(unsigned long long)) != hipSuccess)
+        return fail("bdrt_sampler_create: clearing the leapfrog counter failed");
     // hipMemset returns before the fill has happened, and the sampler's kernels run on a NON-BLOCKING stream that does not order
     // itself behind the null stream: without this wait a launch that follows quickly (several host threads sampling at once)
     // can have its first draws / its leapfrog counter zeroed under it.

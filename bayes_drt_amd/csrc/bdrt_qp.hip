@@ -531,7 +531,8 @@ int bdrt_qp_box_batch(const double *P, const double *q, const double *lo, int n,
     int worst = 0;
     for (int b = 0; b < nb; ++b) {
         if (iterations) iterations[b] = its[b];
-        if (its[b] < 0 && worst == 0) worst = its[b];
+        if (its[b] == -3) worst = -3;                              // a non-PD problem outranks an iteration limit elsewhere
+        else if (its[b] < 0 && worst == 0) worst = its[b];
     }
     if (worst == -3) { set_error("bdrt_qp_box_batch: KKT matrix not positive definite"); return -3; }
     if (worst == -4) { set_error("bdrt_qp_box_batch: iteration limit"); return -4; }

@@ -383,16 +383,18 @@ class Inverter:
                   # the reference zeroes the relative change of entry 1 (the inductance) in its convergence test whenever
                   # the inductance is not fitted -- for any distribution type (:733-734)
                   zero_delta1=bool(self.fit_inductance == False or part == 'real'))
+        st['WT_re'], st['WT_im'] = WT_re, WT_im
         st['G'], st['g'] = self._ridge_gram(st, W_re, W_im, WT_re, WT_im)
         return st
 
     @staticmethod
-    def _ridge_gram(st, W_re, W_im, T_re, T_im):
+    def _ridge_gram(st, W_re, W_im, T_re, T_im, part=None):
         """G = sum over the fitted parts of (W A)^T (W A), g = sum of (W A)^T (W T): on the GPU (bdrt_gram)."""
         rows, tg = [], []
-        if st['part'] in ('both', 'real'):
+        part = part or st['part']
+        if part in ('both', 'real'):
             rows.append(W_re @ st['A_re']); tg.append(T_re)
-        if st['part'] in ('both', 'imag'):
+        if part in ('both', 'imag'):
             rows.append(W_im @ st['A_im']); tg.append(T_im)
         WA = np.ascontiguousarray(np.vstack(rows)); WT = np.ascontiguousarray(np.concatenate(tg))
         lib = _lib.require_gpu()
@@ -400,6 +402,23 @@ class Inverter:
         G = np.empty((n, n)); g = np.empty(n)
         _lib.check(lib.bdrt_gram(ptr(WA), ptr(WT), WA.shape[0], n, None, None, ptr(G), ptr(g)), 'bdrt_gram')
         return G, -g                                   # bdrt_gram returns q = -(WA^T WT)
+
+    @classmethod
+    def _unfitted_part_cost(cls, st, coef, W_re=None, W_im=None, T_re=None, T_im=None):
+        """The reference's reported `cost` (fit dict, `_iter_history`) is 0.5 x^T P x + q^T x with P and q built from BOTH data
+        parts whatever `part` is fitted (:711-713, :848-850), whereas the QP itself sees the fitted part only.  This is the
+        unfitted part's share, added to the QP's own cost."""
+        if st['part'] == 'both':
+            return 0.0
+        other = 'imag' if st['part'] == 'real' else 'real'
+        if W_re is None:
+            key = ('cost_other', other)
+            if key not in st:
+                st[key] = cls._ridge_gram(st, st['W_re'], st['W_im'], st['WT_re'], st['WT_im'], part=other)
+            Go, go = st[key]
+        else:
+            Go, go = cls._ridge_gram(st, W_re, W_im, T_re, T_im, part=other)
+        return 0.5 * coef @ Go @ coef - go @ coef
 
     @staticmethod
     def _hyper_prior_terms(penalty, hl_beta, lambda_0):
@@ -455,10 +474,13 @@ class Inverter:
         for j in range(nb):
             if flags[j] & 4:
                 warnings.warn('bdrt_ridge: a QP reached its iteration limit; the last iterate is used')
+            sj = setups[sel[j]]
             hist = [{'lambda_vectors': [hl[j, t, i].copy() for i in range(3)], 'coef': hc[j, t].copy(), 'fun': hf[j, t],
-                     'cost': hk[j, t], 'result': _QPResult({'x': hc[j, t].copy(), 'primal objective': hf[j, t]}),
+                     'cost': hk[j, t] + self._unfitted_part_cost(sj, hc[j, t]),
+                     'result': _QPResult({'x': hc[j, t].copy(), 'primal objective': hf[j, t]}),
                      'dZ_re': np.ones(n)} for t in range(int(iters[j]))]
-            out.append(dict(coef=coef[j].copy(), lambda_vectors=[lamv[j, i].copy() for i in range(3)], cost=cost[j],
+            out.append(dict(coef=coef[j].copy(), lambda_vectors=[lamv[j, i].copy() for i in range(3)],
+                            cost=cost[j] + self._unfitted_part_cost(sj, coef[j]),
                             result=_QPResult({'x': coef[j].copy(), 'primal objective': float(fun[j])}), history=hist,
                             converged=bool(flags[j] & 1), iterations=int(iters[j])))
         return out
@@ -489,7 +511,9 @@ class Inverter:
         def converged(coef, prev):
             with np.errstate(divide='ignore', invalid='ignore'):
                 delta = (coef - prev) / prev
-            if st['zero_delta1']:
+            # the hyper-weights loop of the reference leaves the inductance out of the test only when it is not fitted
+            # (:822: the `or part == 'real'` of the hyper-lambda loop, :733, is commented out there)
+            if (self.fit_inductance == False) if hyper_weights else st['zero_delta1']:
                 delta[1] = 0
             return np.mean(np.abs(delta)) < xtol
 
@@ -574,6 +598,11 @@ class Inverter:
                 result, P, q = solve(G, g, penalty_matrix(lam_vectors, dZ_re))
                 coef = np.array(result['x'])
                 cost = 0.5 * coef @ P @ coef + q @ coef
+                if phase is not None and it > 0:
+                    cost += self._unfitted_part_cost(st, coef, st['W_re'], st['W_im'], st['W_re'] @ target_adj.real,
+                                                     st['W_im'] @ target_adj.imag)
+                else:
+                    cost += self._unfitted_part_cost(st, coef)
                 history.append({'lambda_vectors': [l.copy() for l in lam_vectors], 'coef': coef.copy(),
                                 'fun': result['primal objective'], 'cost': cost, 'result': result, 'dZ_re': dZ_re.copy(),
                                 'hyper_bs': [h.copy() for h in hyper_bs], 'hyper_lambda0s': [h.copy() for h in lam0s],
@@ -603,7 +632,8 @@ class Inverter:
                 G, g = self._ridge_gram(st, Wr, Wi, Wr @ target_s.real, Wi @ target_s.imag)
                 result, P, q = solve(G, g, L2_mat)
                 coef = np.array(result['x'])
-                cost = 0.5 * coef @ P @ coef + q @ coef
+                cost = 0.5 * coef @ P @ coef + q @ coef + self._unfitted_part_cost(st, coef, Wr, Wi, Wr @ target_s.real,
+                                                                                    Wi @ target_s.imag)
                 history.append({'weights': w.copy(), 'coef': coef.copy(), 'fun': result['primal objective'], 'cost': cost,
                                 'result': result, 'dZ_re': dZ_re.copy()})
                 it += 1
@@ -613,7 +643,8 @@ class Inverter:
             return dict(coef=coef, weights=w.copy(), cost=cost, result=result, history=history, converged=ok, iterations=it)
         result, P, q = solve(G, g, penalty_matrix(lam_vectors, dZ_re))
         coef = np.array(result['x'])
-        return dict(coef=coef, cost=0.5 * coef @ P @ coef + q @ coef, result=result, history=None, converged=True, iterations=1)
+        return dict(coef=coef, cost=0.5 * coef @ P @ coef + q @ coef + self._unfitted_part_cost(st, coef), result=result,
+                    history=None, converged=True, iterations=1)
 
     # ------------------------------------------------------------------ ridge: results -> attributes (reference :741-898)
     def _ridge_finish(self, st, res, hyper_lambda, hyper_weights, max_iter):
@@ -662,7 +693,13 @@ class Inverter:
         lambdas = np.asarray(lambdas, dtype=float)
         recv, imcv = np.zeros_like(lambdas), np.zeros_like(lambdas)
         kw = dict(kw)
-        host_variant = kw.get('dZ', False) or kw.get('hl_solution', 'analytic') != 'analytic'
+        # what the one-launch path covers; any other ridge_fit keyword (hyper_weights, hyper_a, hyper_b, correct_phase_offset,
+        # preset, ... -- the reference forwards **kw unchanged, :902-925) takes the sequential loop, and so does a mistyped
+        # keyword: ridge_fit reports it
+        defaults = dict(penalty='discrete', reg_ord=2, L1_penalty=0, scale_Z=True, nonneg=True, weights=None,
+                        hyper_lambda=True, hl_beta=2.5, hl_fbeta=None, xtol=1e-3, max_iter=20, x0=None, dZ=False)
+        host_variant = (kw.get('dZ', False) or kw.get('hl_solution', 'analytic') != 'analytic'
+                        or bool(set(kw) - set(defaults) - {'hl_solution', 'dZ_power'}))
         if os.environ.get('BDRT_SEQUENTIAL_CV') or os.environ.get('BDRT_HOST_LAMBDA_LOOP') or host_variant:
             for i, lam in enumerate(lambdas):
                 self.ridge_fit(frequencies, Z, part='real', lambda_0=lam, **kw)
@@ -671,11 +708,6 @@ class Inverter:
                 Zr = np.real(self.predict_Z(frequencies))
                 recv[i], imcv[i] = np.sum((Z.real - Zr) ** 2), np.sum((Z.imag - Zi) ** 2)
         else:
-            defaults = dict(penalty='discrete', reg_ord=2, L1_penalty=0, scale_Z=True, nonneg=True, weights=None,
-                            hyper_lambda=True, hl_beta=2.5, hl_fbeta=None, xtol=1e-3, max_iter=20, x0=None, dZ=False)
-            unknown = set(kw) - set(defaults) - {'hl_solution', 'dZ_power'}
-            if unknown:
-                raise TypeError('ridge_ReImCV: unexpected arguments %s' % sorted(unknown))
             o = dict(defaults, **{k: v for k, v in kw.items() if k in defaults})
             self.distribution_fits = {}
             setups = {}
@@ -706,62 +738,40 @@ class Inverter:
         return best
 
     # ================================================================== Bayesian fit (reference :1072-1289)
+    _RIDGE_SIDE_EFFECTS = ('distribution_fits', 'R_inf', 'inductance', 'fit_type', '_iter_history', 'cv_result', 'error_fit')
+
     def fit(self, frequencies, Z, part='both', scale_Z=True, nonneg=False, outliers=False, check_outliers=True,
             init_from_ridge=False, ridge_kw={}, sigma_min=0.002, inductance_scale=1, outlier_lambda=None,
             mode='optimize', random_seed=1234, max_iter=50000, warmup=200, samples=200, chains=2, add_stan_data={},
-            model_str=None, fitY=False, SA=False, SASY=False):
+            model_str=None, fitY=False, SA=False, SASY=False, n_starts=None, algorithm=None):
         """Fit the distribution(s) with the calibrated hierarchical Bayesian model: mode='optimize' (MAP) or
-        'sample' (NUTS).  Arguments as in the reference (:1072-1152)."""
-        if fitY or SA or SASY:
-            raise NotImplementedError('fitY / SA / SASY are experimental flags of the reference ("for testing only") and '
-                                      'are not part of this build')
-        if part not in ('both', 'real', 'imag'):
-            raise ValueError(f"Invalid part {part}. Options are 'both', 'real', or 'imag'")
-        if mode not in ('optimize', 'sample'):
-            raise ValueError("mode must be 'optimize' or 'sample'")
+        'sample' (NUTS).  Arguments as in the reference (:1072-1152), plus two that only concern mode='optimize':
+
+        n_starts : None (default) -- the designated start (random, or the ridge solution with init_from_ridge=True) plus the
+            other of the two for a single distribution, or plus three more random draws for several distributions; all
+            starts are ONE lock-step batch on the GPU and the designated start's answer is kept unless another converged
+            start ends at a clearly higher log-posterior (`_opt_report['start']`, `['starts']`).  This DIFFERS from the
+            reference, which optimises from its single start only (:1216) and on multi-modal posteriors returns whatever
+            mode that start leads to.  n_starts=1 is the reference's behaviour (also BDRT_MAP_SINGLE_START=1);
+            n_starts=k > 1: the designated start, the other kind of start if there is one, then further random draws.
+        algorithm : None / 'LBFGS+Newton' (default) -- the device-resident Newton iteration to a stationary point;
+            'LBFGS' -- Stan's L-BFGS(5) with Stan's line search and termination tests alone, i.e. the kind of iterate the
+            reference's `optimizing` call returns."""
+        self._fit_argument_checks(part, mode, fitY, SA, SASY, n_starts, algorithm)
         _validate_spectrum(frequencies, Z)
+        init = 'random'
         if init_from_ridge:
             if len(self.distributions) > 1:
                 raise ValueError('Ridge initialization can only be performed for single-distribution fits')
             init = self._get_init_from_ridge(frequencies, Z, mode, nonneg=nonneg, outliers=outliers,
                                              inductance_scale=inductance_scale, ridge_kw=ridge_kw)
             self._init_params = init()
-        else:
-            init = 'random'
-        # MAP: the hierarchical posterior has poor local maxima (everything explained as noise, or a huge Z_hat with a
-        # proportionally huge error) that a single random start reaches on sparse or outlier-ridden spectra.  A second start
-        # from the under-fitted ridge solution costs no wall time (the starts run as one batch on the GPU); the designated
-        # start's answer (random, or ridge with init_from_ridge=True) is kept unless the other one ends at a clearly higher
-        # log-posterior.  BDRT_MAP_SINGLE_START=1: the designated start only, as in the reference.
         extra_inits = []
-        if mode == 'optimize' and init_from_ridge and not os.environ.get('BDRT_MAP_SINGLE_START'):
-            extra_inits = ['random']                    # (the ridge start stays the designated one)
-        if (mode == 'optimize' and not init_from_ridge and len(self.distributions) == 1 and model_str is None
-                and not os.environ.get('BDRT_MAP_SINGLE_START')):
-            try:
-                extra_inits = [self._get_init_from_ridge(frequencies, Z, mode, nonneg=nonneg, outliers=outliers,
-                                                        inductance_scale=inductance_scale, ridge_kw=ridge_kw)]
-            except Exception as e:                      # the ridge candidate is optional: the random start remains
-                warnings.warn('ridge starting point not available (%s): MAP from the random start only' % e)
-        elif mode == 'optimize' and not init_from_ridge and not os.environ.get('BDRT_MAP_SINGLE_START'):
-            # several distributions: no ridge solution to start from -- three more draws of the random start instead
-            extra_inits = [('random', k) for k in (1, 2, 3)]
-        frequencies, Z_scaled, WZ_re, WZ_im, W_re, W_im, dist_mat = self._prep_matrices(
-            frequencies, Z, part, weights=None, dZ=False, scale_Z=scale_Z, penalty='discrete', fit_type='map')
-        Z_sorted = self.Z_train
-        if outliers == 'auto':
-            idx = self.check_outliers(frequencies, Z_sorted, threshold=4, use_existing_fit=bool(init_from_ridge), **ridge_kw)
-            if len(idx) > 0:
-                outliers = True
-                warnings.warn('Identified likely outliers at indices {}, f={} Hz. An outlier-robust error model will be '
-                              'used. To disable this behavior, pass outliers=False.'.format(idx, frequencies[idx]))
-                # check_outliers may have re-run ridge_fit: restore the 'discrete' matrices for the Bayesian fit
-                frequencies, Z_scaled, WZ_re, WZ_im, W_re, W_im, dist_mat = self._prep_matrices(
-                    frequencies, Z_sorted, part, weights=None, dZ=False, scale_Z=scale_Z, penalty='discrete', fit_type='map')
-            else:
-                outliers = False
-                frequencies, Z_scaled, WZ_re, WZ_im, W_re, W_im, dist_mat = self._prep_matrices(
-                    frequencies, Z_sorted, part, weights=None, dZ=False, scale_Z=scale_Z, penalty='discrete', fit_type='map')
+        if mode == 'optimize':
+            extra_inits = self._map_extra_starts(n_starts, init_from_ridge, model_str, frequencies, Z, nonneg, outliers,
+                                                 inductance_scale, ridge_kw)
+        frequencies, Z_scaled, dist_mat, outliers = self._bayes_matrices(frequencies, Z, part, scale_Z, outliers,
+                                                                         init_from_ridge, ridge_kw)
         if model_str is None:
             model, model_str = self._get_stan_model(nonneg, outliers, False, None, fitY, SA)
         else:
@@ -778,40 +788,106 @@ class Inverter:
             dat['N'] = len(frequencies)        # package Series outlier models declare N = Nf (:1208-1211)
         self._stan_input = dat.copy()
         if mode == 'optimize':
-            self._opt_result = model.optimizing(dat, iter=max_iter, seed=random_seed, init=init, extra_inits=extra_inits)
+            self._opt_result = model.optimizing(dat, iter=max_iter, seed=random_seed, init=init, extra_inits=extra_inits,
+                                                algorithm=algorithm or 'LBFGS+Newton')
             self._opt_report = model.last_report
         else:
             self._sample_result = model.sampling(dat, warmup=warmup, iter=warmup + samples, chains=chains,
                                                  seed=random_seed, init=init,
                                                  control={'adapt_delta': 0.9, 'adapt_t0': 10})
-        self.distribution_fits = {}
-        self.error_fit = {}
-        if model_type in ['Series', 'Parallel']:
-            name = [k for k, v in self.distributions.items() if v['dist_type'] == model_type.lower()][0]
-            self.distribution_fits[name] = {'coef': self._extract_parameter('x', self.distributions[name]['dist_type'], mode)}
-        elif model_type == 'Series-Parallel':
-            for name, info in self.distributions.items():
-                key = 'xs' if info['dist_type'] == 'series' else 'xp'
-                self.distribution_fits[name] = {'coef': self._extract_parameter(key, info['dist_type'], mode)}
-        elif model_type == 'Series-2Parallel':
-            for name, info in self.distributions.items():
-                key = 'xs' if info['dist_type'] == 'series' else 'xp%d' % info['order']
-                self.distribution_fits[name] = {'coef': self._extract_parameter(key, info['dist_type'], mode)}
-        self.R_inf = self._extract_parameter('Rinf', 'series', mode)
-        self.inductance = self._extract_parameter('induc', 'series', mode)
-        self.error_fit['sigma_min'] = self._rescale_coef(sigma_min, 'series')
-        for p_ in ['sigma_tot', 'sigma_res']:
-            self.error_fit[p_] = self._extract_parameter(p_, 'series', mode)
-        for p_ in ['alpha_prop', 'alpha_re', 'alpha_im']:
-            self.error_fit[p_] = self._extract_parameter(p_, None, mode)
-        if outliers == True:
-            self.error_fit['sigma_out'] = self._extract_parameter('sigma_out', 'series', mode)
-        self.fit_type = 'map' if mode == 'optimize' else 'bayes'
+        self._store_bayes_fit(model_type, mode, sigma_min, outliers)
         if outliers == False and check_outliers:
-            idx = self.check_outliers(frequencies, Z_sorted, threshold=3.5, use_existing_fit=True)
+            idx = self.check_outliers(frequencies, self.Z_train, threshold=3.5, use_existing_fit=True)
             if len(idx) > 0:
                 warnings.warn('Possible outliers were identified at indices {}, f={} Hz. Check the residuals and consider '
                               're-running with outliers=True'.format(idx, frequencies[idx]))
+
+    @staticmethod
+    def _fit_argument_checks(part, mode, fitY, SA, SASY, n_starts, algorithm):
+        if fitY or SA or SASY:
+            raise NotImplementedError('fitY / SA / SASY are experimental flags of the reference ("for testing only") and '
+                                      'are not part of this build')
+        if part not in ('both', 'real', 'imag'):
+            raise ValueError(f"Invalid part {part}. Options are 'both', 'real', or 'imag'")
+        if mode not in ('optimize', 'sample'):
+            raise ValueError("mode must be 'optimize' or 'sample'")
+        if n_starts is not None and (not isinstance(n_starts, (int, np.integer)) or n_starts < 1):
+            raise ValueError('n_starts must be a positive integer or None')
+        if algorithm not in (None, 'LBFGS', 'LBFGS+Newton'):
+            raise ValueError("algorithm must be None, 'LBFGS' or 'LBFGS+Newton'")
+
+    def _map_extra_starts(self, n_starts, init_from_ridge, model_str, frequencies, Z, nonneg, outliers, inductance_scale, ridge_kw):
+        """Further MAP starting points next to the designated one (see `fit`).  The hierarchical posterior has poor local
+        maxima -- everything explained as noise, or a huge Z_hat with a proportionally huge error -- that a single random
+        start reaches on sparse or outlier-ridden spectra; the extra starts cost no wall time, the batch runs in
+        lock-step on the GPU."""
+        if n_starts is None and os.environ.get('BDRT_MAP_SINGLE_START'):
+            n_starts = 1
+        if n_starts == 1:
+            return []
+        single = len(self.distributions) == 1 and model_str is None
+        extra = []
+        if init_from_ridge:
+            extra.append('random')                       # the ridge start stays the designated one
+        elif single:
+            # the under-fitted ridge solution as second start; ridge_fit overwrites fit attributes on the way, which a
+            # Bayesian fit would not touch: put them back
+            saved = {k: getattr(self, k) for k in self._RIDGE_SIDE_EFFECTS if hasattr(self, k)}
+            try:
+                extra.append(self._get_init_from_ridge(frequencies, Z, 'optimize', nonneg=nonneg, outliers=outliers,
+                                                       inductance_scale=inductance_scale, ridge_kw=ridge_kw))
+            except Exception as e:                       # the ridge candidate is optional: the random start remains
+                warnings.warn('ridge starting point not available (%s): MAP from the random start only' % e)
+            finally:
+                for k in self._RIDGE_SIDE_EFFECTS:
+                    if k in saved:
+                        setattr(self, k, saved[k])
+                    elif hasattr(self, k):
+                        delattr(self, k)
+        want = (n_starts - 1) if n_starts is not None else (len(extra) if (single or init_from_ridge) else 3)
+        draw = 1
+        while len(extra) < want:
+            extra.append(('random', draw)); draw += 1    # another draw of the random start
+        return extra[:want]
+
+    def _bayes_matrices(self, frequencies, Z, part, scale_Z, outliers, init_from_ridge, ridge_kw):
+        """Matrices of the Bayesian fit ('discrete' penalty) and the resolved `outliers` flag ('auto': a ridge-based check
+        decides, reference :1172-1187)."""
+        def prep(f_, Z_):
+            out = self._prep_matrices(f_, Z_, part, weights=None, dZ=False, scale_Z=scale_Z, penalty='discrete', fit_type='map')
+            return out[0], out[1], out[6]
+        frequencies, Z_scaled, dist_mat = prep(frequencies, Z)
+        if outliers == 'auto':
+            Z_sorted = self.Z_train
+            idx = self.check_outliers(frequencies, Z_sorted, threshold=4, use_existing_fit=bool(init_from_ridge), **ridge_kw)
+            outliers = len(idx) > 0
+            if outliers:
+                warnings.warn('Identified likely outliers at indices {}, f={} Hz. An outlier-robust error model will be '
+                              'used. To disable this behavior, pass outliers=False.'.format(idx, frequencies[idx]))
+            # check_outliers may have re-run ridge_fit with its own penalty: back to the matrices of the Bayesian fit
+            frequencies, Z_scaled, dist_mat = prep(frequencies, Z_sorted)
+        return frequencies, Z_scaled, dist_mat, outliers
+
+    def _store_bayes_fit(self, model_type, mode, sigma_min, outliers):
+        """Engine result -> the attributes the reference sets (:1223-1262): coefficients per distribution, offsets, error
+        structure, fit type."""
+        coef_key = {'Series': lambda info: 'x', 'Parallel': lambda info: 'x',
+                    'Series-Parallel': lambda info: 'xs' if info['dist_type'] == 'series' else 'xp',
+                    'Series-2Parallel': lambda info: 'xs' if info['dist_type'] == 'series' else 'xp%d' % info['order']}[model_type]
+        self.distribution_fits = {}
+        for name, info in self.distributions.items():
+            if model_type in ('Series', 'Parallel') and info['dist_type'] != model_type.lower():
+                continue
+            self.distribution_fits[name] = {'coef': self._extract_parameter(coef_key(info), info['dist_type'], mode)}
+            if model_type in ('Series', 'Parallel'):
+                break
+        self.R_inf = self._extract_parameter('Rinf', 'series', mode)
+        self.inductance = self._extract_parameter('induc', 'series', mode)
+        self.error_fit = {'sigma_min': self._rescale_coef(sigma_min, 'series')}
+        for key, kind in (('sigma_tot', 'series'), ('sigma_res', 'series'), ('alpha_prop', None), ('alpha_re', None),
+                          ('alpha_im', None)) + ((('sigma_out', 'series'),) if outliers == True else ()):
+            self.error_fit[key] = self._extract_parameter(key, kind, mode)
+        self.fit_type = 'map' if mode == 'optimize' else 'bayes'
 
     def drift_map_fit(self, *a, **k):
         raise NotImplementedError('drift fits: the reference ships no Stan model files for them (SURVEY section 2 row 15)')

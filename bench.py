@@ -135,7 +135,23 @@ def physical_cores():
                 cores.add(fh.read().strip())
         except OSError:
             cores.add(str(cpu))
-    return max(1, len(cores))
+    n = max(1, len(cores))
+    # a container may see every CPU of the host and still be throttled to a few cores' worth of time: the CPU bandwidth
+    # quota of the cgroup bounds what any number of processes can use
+    for path, parse in (('/sys/fs/cgroup/cpu.max', lambda t: (t.split()[0], t.split()[1])),
+                        ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', lambda t: (t.strip(), None))):
+        try:
+            with open(path) as fh:
+                quota, period = parse(fh.read())
+            if period is None:
+                with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fh:
+                    period = fh.read().strip()
+            if quota not in ('max', '-1') and float(quota) > 0:
+                n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def cpu_baseline(seconds=8.0):
@@ -146,6 +162,9 @@ def cpu_baseline(seconds=8.0):
     ncores = physical_cores()
     single = _cpu_leg(1, seconds)
     allc = _cpu_leg(ncores, seconds)
+    # a box that grants fewer cores than it shows (no readable quota) gives itself away by the aggregate: report the
+    # parallelism actually obtained beside the process count
+    effective = allc / single if single > 0 else float(ncores)
     model = ''
     try:
         with open('/proc/cpuinfo') as fh:
@@ -153,7 +172,7 @@ def cpu_baseline(seconds=8.0):
     except OSError:
         pass
     return dict(value=allc, unit='evals/s', cores=ncores, kind='port', tuning=CPU_PORT_NOTE, single_core=single,
-                cpu_model=model, logical_cpus=os.cpu_count(), pystan_derived=PYSTAN_DERIVED,
+                cpu_model=model, logical_cpus=os.cpu_count(), effective_parallelism=effective, pystan_derived=PYSTAN_DERIVED,
                 sample='leapfrogs of real NUTS warm-up transitions (oracle/nuts_oracle.c driving oracle/bdrt_oracle.c, '
                        'Series_pos 81x161, jacobian on), gcc -O3 -march=native: 1 process x %.0f s (single_core), then %d '
                        'processes x %.0f s, one chain per core (value)' % (seconds, ncores, seconds))

@@ -277,6 +277,82 @@ def gen_csv():
     save('csv_2RC_uniform_0.25_4x1000', Gout_bayes=g, Gout_bayes_cols=c)
 
 
+def gen_hmc_suite():
+    """The reference's published HMC study as ONE fixture: the 60 simulated DRT spectra `Run fits.ipynb` cell 3 selects, the
+    posterior mean / 2.5 % / 97.5 % curves it stored for each (bayes_results/Gout_*.csv, 2 chains x (200 + 200), cell 5), the
+    MAP curves (map_results/Gout_*.csv, cell 4) and the sampler diagnostics pystan printed into the notebook for each run:
+    iterations that saturated tree depth 10, divergent iterations, wall time.  Arrays and numbers only."""
+    import json
+    import re
+    import pandas as pd
+    nb = json.load(open(os.path.join(REF, 'code_EchemActa', 'Run fits.ipynb')))
+
+    def cell_text(cell):
+        out = []
+        for o in cell.get('outputs', []):
+            t = o.get('text') or o.get('data', {}).get('text/plain') or ''
+            out.append(''.join(t))
+        return '\n'.join(out)
+
+    def parse(text):
+        """file stem -> dict(saturated, divergent, iterations, seconds) from the printed stream of one loop cell."""
+        res, cur = {}, None
+        for line in text.splitlines():
+            m = re.search(r'Z_([^\\/]+)\.csv', line)
+            if m:
+                cur = m.group(1)
+                res[cur] = dict(saturated=0, divergent=0, iterations=0, seconds=np.nan)
+                continue
+            if cur is None:
+                continue
+            m = re.search(r'(\d+) of (\d+) iterations saturated the maximum tree depth of (\d+)', line)
+            if m:
+                res[cur]['saturated'], res[cur]['iterations'] = int(m.group(1)), int(m.group(2))
+            m = re.search(r'(\d+) of (\d+) iterations ended with a divergence', line)
+            if m:
+                res[cur]['divergent'], res[cur]['iterations'] = int(m.group(1)), int(m.group(2))
+            m = re.search(r'File fit time: ([0-9.]+) seconds', line)
+            if m:
+                res[cur]['seconds'] = float(m.group(1))
+        return res
+
+    cells = [c for c in nb['cells'] if c['cell_type'] == 'code']
+    mcmc = next(c for c in cells if ''.join(c['source']).startswith('"MCMC sampling"'))
+    mapc = next(c for c in cells if ''.join(c['source']).startswith('"MAP fits"'))
+    four = next(c for c in cells if '4 chains, 1000 iterations' in ''.join(c['source']))
+    diag, diag_map = parse(cell_text(mcmc)), parse(cell_text(mapc))
+    stems = sorted(diag)
+    stems = [s for s in stems if os.path.exists(os.path.join(REF, 'code_EchemActa/bayes_results/Gout_%s.csv' % s))]
+    Zs, Gb, Gm, gt, rows = [], [], [], [], []
+    for s in stems:
+        z = pd.read_csv(os.path.join(REF, 'data/simulated/Z_%s.csv' % s))
+        Zs.append(np.array([z['Freq'].values, z['Zreal'].values, z['Zimag'].values]).T)
+        gb = pd.read_csv(os.path.join(REF, 'code_EchemActa/bayes_results/Gout_%s.csv' % s))
+        Gb.append(gb[['tau', 'gamma', 'gamma_lo', 'gamma_hi']].values.astype(float))
+        gm = pd.read_csv(os.path.join(REF, 'code_EchemActa/map_results/Gout_%s.csv' % s))
+        Gm.append(gm[['tau', 'gamma']].values.astype(float))
+        circ = s.split('_')[0]
+        pg = os.path.join(REF, 'data/simulated/gamma_%s.csv' % circ)
+        if os.path.exists(pg):                      # RC / 2RC have delta-function distributions: no curve file
+            g = pd.read_csv(pg)
+            g = g[[c for c in g.columns if not c.startswith('Unnamed')]].values.astype(float)
+            gt.append(g[:, :2])
+        else:
+            gt.append(np.full((200, 2), np.nan))
+        d = diag[s]
+        rows.append([d['saturated'], d['divergent'], d['iterations'] or 400, d['seconds'], diag_map.get(s, {}).get('seconds', np.nan)])
+    t4 = cell_text(four)
+    m_sat = re.search(r'(\d+) of (\d+) iterations saturated', t4)
+    m_div = re.search(r'(\d+) of (\d+) iterations ended with a divergence', t4)
+    m_sec = re.search(r'File fit time: ([0-9.]+) seconds', t4)
+    assert len({z.shape for z in Zs}) == 1 and len({g.shape for g in gt}) == 1
+    save('hmc_suite', stems=np.array(stems), Z=np.array(Zs), Gout_bayes=np.array(Gb), Gout_map=np.array(Gm),
+         gamma_true=np.array(gt), diag=np.array(rows, dtype=float),
+         diag_cols=np.array(['saturated_treedepth10', 'divergent', 'iterations', 'hmc_seconds', 'map_seconds']),
+         run4x1000=np.array([int(m_sat.group(1)), int(m_div.group(1)), int(m_sat.group(2)), float(m_sec.group(1))]),
+         run4x1000_cols=np.array(['saturated_treedepth10', 'divergent', 'iterations', 'seconds']))
+
+
 def gen_predict():
     # predict_distribution / predict_Z / predict_sigma for a *given* coefficient vector (no Stan needed):
     # inversion.py:3298-3311 (gamma = Phi @ coef), :2942-2959 (Z_hat), :3089-3139 (sigma)
@@ -414,6 +490,6 @@ def gen_ridge():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['matrices', 'ddt', 'dat', 'kats', 'csv', 'predict', 'host', 'ridge']
+    which = sys.argv[1:] or ['matrices', 'ddt', 'dat', 'kats', 'csv', 'predict', 'host', 'ridge', 'hmc_suite']
     for w in which:
         globals()['gen_' + w]()

@@ -74,8 +74,9 @@ def test_fit_sample_2zarc_within_reference_mc_error():
     print('HMC gamma mean rel-L2 vs reference: %.4f, lo %.4f, hi %.4f; leapfrogs %d, divergent %d, treedepth hits %d'
           % (rel_l2(g, ref[:, 1]), rel_l2(lo, ref[:, 2]), rel_l2(hi, ref[:, 3]), fit.n_leapfrog, fit.n_divergent,
              fit.n_max_treedepth))
-    assert rel_l2(g, ref[:, 1]) < 0.04
-    assert rel_l2(hi, ref[:, 3]) < 0.10 and rel_l2(lo, ref[:, 2]) < 0.35
+    # SURVEY 8(c)(3) bands (the reference's own scatter between its two runs of one spectrum: 0.8 % / 5.6 % / 1.8 %)
+    assert rel_l2(g, ref[:, 1]) < 0.02
+    assert rel_l2(hi, ref[:, 3]) < 0.06 and rel_l2(lo, ref[:, 2]) < 0.07
     assert np.all(lo <= g + 1e-12) and np.all(g <= hi + 1e-12)
     # split R-hat of the coefficients that matter
     x = fit.chain_draws('x')
