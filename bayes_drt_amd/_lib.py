@@ -64,12 +64,12 @@ class ChainDiag(C.Structure):
 
 # every symbol include/bdrt.h declares (tests/test_abi.py checks the library exports each of them)
 SYMBOLS = [
-    'bdrt_build_A', 'bdrt_build_L', 'bdrt_build_M',
+    'bdrt_build_A', 'bdrt_build_A_basis', 'bdrt_build_L', 'bdrt_build_L_rect', 'bdrt_build_M',
     'bdrt_problem_create', 'bdrt_problem_destroy', 'bdrt_num_params', 'bdrt_param_is_pos', 'bdrt_problem_set_Z',
     'bdrt_logp_grad', 'bdrt_logp_grad_dev', 'bdrt_transformed',
     'bdrt_opt_defaults', 'bdrt_optimize',
     'bdrt_nuts_defaults', 'bdrt_sampler_create', 'bdrt_sampler_destroy', 'bdrt_sampler_advance', 'bdrt_sampler_sync',
-    'bdrt_sampler_run', 'bdrt_sampler_results', 'bdrt_sampler_tail_units', 'bdrt_sampler_kind', 'bdrt_sampler_total_leapfrogs', 'bdrt_sampler_kernel_time',
+    'bdrt_sampler_run', 'bdrt_sampler_results', 'bdrt_sampler_tail_units', 'bdrt_sampler_compactions', 'bdrt_sampler_kind', 'bdrt_sampler_total_leapfrogs', 'bdrt_sampler_kernel_time',
     'bdrt_sampler_phase_profile',
     'bdrt_sample',
     'bdrt_gram', 'bdrt_qp_box', 'bdrt_qp_box_batch', 'bdrt_ridge',
@@ -133,7 +133,10 @@ def load_library():
     lib.bdrt_transformed.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp]
     lib.bdrt_build_A.argtypes = [vp, C.c_int, vp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                  C.c_int, vp]
+    lib.bdrt_build_A_basis.argtypes = [vp, C.c_int, vp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                       C.c_int, C.c_int, vp]
     lib.bdrt_build_L.argtypes = [vp, C.c_int, C.c_double, vp, vp]
+    lib.bdrt_build_L_rect.argtypes = [vp, C.c_int, vp, C.c_int, C.c_double, vp, C.c_int, vp]
     lib.bdrt_build_M.argtypes = [vp, C.c_int, C.c_double, vp, C.c_int, vp]
     lib.bdrt_opt_defaults.argtypes = [C.POINTER(OptOptions)]
     lib.bdrt_opt_defaults.restype = None
@@ -149,6 +152,8 @@ def load_library():
     lib.bdrt_sampler_run.argtypes = [vp]
     lib.bdrt_sampler_results.argtypes = [vp, vp, vp, vp]
     lib.bdrt_sampler_tail_units.argtypes = [vp]
+    lib.bdrt_sampler_compactions.argtypes = [vp]
+    lib.bdrt_sampler_compactions.restype = C.c_int
     lib.bdrt_sampler_kind.argtypes = [vp]
     lib.bdrt_sampler_kind.restype = C.c_int
     lib.bdrt_sampler_tail_units.restype = C.c_int

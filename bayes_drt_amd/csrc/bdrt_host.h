@@ -79,6 +79,13 @@ struct Problem {
 int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
                      double *d_grad, double *d_params, double *d_Zhat, double *d_sig, hipStream_t stream);
 
+// Few points (B <= #CUs): one WORKGROUP per point with the Toeplitz / banded structure of the problem instead of one
+// 16-column MFMA tile with B live columns (bdrt_solo.h / bdrt_solo_wide.h evaluators; defined in bdrt_nuts.hip).  Returns 1
+// when the problem / batch does not take that path (nothing launched), 0 when launched, < 0 on error.  Same formulas, other
+// summation order: results agree with the tile evaluator to ~1e-13 relative, not bit for bit.
+int launch_logp_grad_few(Problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp, double *d_grad,
+                         hipStream_t stream);
+
 // percentiles of X Phi^T + bias (Phi == nullptr: of X itself) over the rows of a DEVICE matrix X; Phi, bias, q, out: host
 // expcol[K] (host, Phi == nullptr only): columns whose samples are exp(X); mean[ncols] (host): sample means; both optional
 int post_percentiles_device(const double *dX, int rows, int K, long ldx, const double *Phi, int M, const double *bias,

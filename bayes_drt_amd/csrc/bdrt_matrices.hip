@@ -47,11 +47,20 @@ __device__ __forceinline__ cplx ctanh_d(cplx z)
     return {sinh(2.0 * z.re) / d, sin(2.0 * z.im) / d};
 }
 
-// integrand of get_A_func (matrices.py:27-117), gaussian basis (matrices.py:12-13)
-__device__ __forceinline__ double integrand(double y, double w_n, double t_m, double eps, int kernel, int part,
-                                            int dist_series, int use_ct, double k_ct)
+// get_basis_func (matrices.py:8-24): gaussian (:12-13), Cole-Cole (:15-17), Zic (:19-21; epsilon unused)
+__device__ __forceinline__ double basis_phi(double y, double eps, int basis)
 {
-    const double phi = exp(-(eps * y) * (eps * y));
+    if (basis == BDRT_BASIS_COLE_COLE)
+        return (1.0 / (2.0 * M_PI)) * sin((1.0 - eps) * M_PI) / (cosh(eps * y) - cos((1.0 - eps) * M_PI));
+    if (basis == BDRT_BASIS_ZIC) return 2.0 * exp(y) / (1.0 + exp(2.0 * y));
+    return exp(-(eps * y) * (eps * y));
+}
+
+// integrand of get_A_func (matrices.py:27-117)
+__device__ __forceinline__ double integrand(double y, double w_n, double t_m, double eps, int kernel, int part,
+                                            int dist_series, int use_ct, double k_ct, int basis)
+{
+    const double phi = basis_phi(y, eps, basis);
     if (kernel == BDRT_KERNEL_DRT) {
         const double den = 1.0 + exp(2.0 * (y + log(w_n * t_m)));
         if (part == 0) return phi / den;                          // :48-49
@@ -78,7 +87,7 @@ __device__ __forceinline__ double quad_y(int i)
 // one wave per entry.  toeplitz: entry e < nf -> (w_e, t_0), else (w_0, t_{e-nf}).  general: (w_{e/k}, t_{e%k})
 __global__ __launch_bounds__(256) void build_A_entries(const double *freq, int nf, const double *tau, int k, double eps,
                                                        int kernel, int part, int dist_series, int use_ct, double k_ct,
-                                                       int toeplitz, int nentries, double *vals)
+                                                       int toeplitz, int nentries, int basis, double *vals)
 {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= nentries) return;
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void build_A_entries(const double *freq, int n
     for (int i = lane; i < NQUAD; i += 64) {
         const double y = quad_y(i);
         const double lo = i > 0 ? quad_y(i - 1) : y, hi = i < NQUAD - 1 ? quad_y(i + 1) : y;
-        s += integrand(y, w_n, t_m, eps, kernel, part, dist_series, use_ct, k_ct) * (0.5 * (hi - lo));
+        s += integrand(y, w_n, t_m, eps, kernel, part, dist_series, use_ct, k_ct, basis) * (0.5 * (hi - lo));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
@@ -106,16 +115,19 @@ __global__ void toeplitz_expand(const double *vals, int nf, int k, double *out)
     out[i] = n >= m ? vals[n - m] : vals[nf + (m - n)];      // scipy.linalg.toeplitz(c, r)
 }
 
-// L[n,m] = sum_j coef[j] d^j/dy^j exp(-(eps y)^2), y = ln(1/(w_n t_m)), w_n = 2 pi (1/(2 pi t_n))   (matrices.py:268-325)
-__global__ void build_L_kernel(const double *tau, int k, double eps, double c0, double c1, double c2, double c3,
-                               double *out)
+// L[n,m] = sum_j coef[j] d^j/dy^j exp(-(eps y)^2), y = ln(1/(w_n t_m))   (matrices.py:268-325)
+// freq == nullptr: the collocated case w_n = 2 pi (1/(2 pi t_n)) Inverter uses (nf = k); else any frequencies, [nf x k].
+// Zic basis: the function itself, order 0 only (matrices.py:316-318).
+__global__ void build_L_kernel(const double *freq, int nf, const double *tau, int k, double eps, double c0, double c1, double c2,
+                               double c3, int basis, double *out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= k * k) return;
+    if (i >= nf * k) return;
     const int n = i / k, m = i % k;
-    const double f_n = 1.0 / (2.0 * M_PI * tau[n]);
+    const double f_n = freq ? freq[n] : 1.0 / (2.0 * M_PI * tau[n]);
     const double w_n = 2.0 * M_PI * f_n;
     const double y = log(1.0 / (w_n * tau[m]));
+    if (basis == BDRT_BASIS_ZIC) { out[i] = c0 * basis_phi(y, eps, basis); return; }
     const double g = exp(-(eps * y) * (eps * y));
     const double e2 = eps * eps;
     double v = 0.0;
@@ -163,8 +175,19 @@ extern "C" {
 int bdrt_build_A(const double *freq, int nf, const double *tau, int k, double eps, int kernel_id, int part,
                  int dist_series, int use_ct, double k_ct, int toeplitz, double *out)
 {
-    if (!freq || !tau || !out || nf <= 0 || k <= 0 || kernel_id < 0 || kernel_id > 3 || (part != 0 && part != 1)) {
+    return bdrt_build_A_basis(freq, nf, tau, k, eps, kernel_id, part, dist_series, use_ct, k_ct, toeplitz, BDRT_BASIS_GAUSSIAN, out);
+}
+
+int bdrt_build_A_basis(const double *freq, int nf, const double *tau, int k, double eps, int kernel_id, int part,
+                       int dist_series, int use_ct, double k_ct, int toeplitz, int basis_id, double *out)
+{
+    if (!freq || !tau || !out || nf <= 0 || k <= 0 || kernel_id < 0 || kernel_id > 3 || (part != 0 && part != 1) ||
+        basis_id < BDRT_BASIS_GAUSSIAN || basis_id > BDRT_BASIS_ZIC) {
         set_error("bdrt_build_A: bad arguments");
+        return -1;
+    }
+    if (basis_id == BDRT_BASIS_COLE_COLE && !(eps > 0.0 && eps < 1.0)) {
+        set_error("bdrt_build_A: the Cole-Cole basis needs 0 < epsilon < 1");
         return -1;
     }
     bind_process_device();
@@ -177,7 +200,7 @@ int bdrt_build_A(const double *freq, int nf, const double *tau, int k, double ep
     BDRT_HIP(hipMemcpy(dT.p, tau, k * sizeof(double), hipMemcpyHostToDevice));
     const int wpb = 4;   // waves per block
     hipLaunchKernelGGL(build_A_entries, dim3((nent + wpb - 1) / wpb), dim3(64 * wpb), 0, 0, dF.as<double>(), nf,
-                       dT.as<double>(), k, eps, kernel_id, part, dist_series, use_ct, k_ct, toeplitz, nent,
+                       dT.as<double>(), k, eps, kernel_id, part, dist_series, use_ct, k_ct, toeplitz, nent, basis_id,
                        toeplitz ? dV.as<double>() : dO.as<double>());
     BDRT_HIP(hipGetLastError());
     if (toeplitz) {
@@ -198,16 +221,34 @@ int bdrt_build_A(const double *freq, int nf, const double *tau, int k, double ep
 
 int bdrt_build_L(const double *tau, int k, double eps, const double *coef4, double *out)
 {
-    if (!tau || !coef4 || !out || k <= 0) { set_error("bdrt_build_L: bad arguments"); return -1; }
+    return bdrt_build_L_rect(nullptr, k, tau, k, eps, coef4, BDRT_BASIS_GAUSSIAN, out);
+}
+
+int bdrt_build_L_rect(const double *freq, int nf, const double *tau, int k, double eps, const double *coef4, int basis_id,
+                      double *out)
+{
+    if (!tau || !coef4 || !out || k <= 0 || nf <= 0 || (!freq && nf != k) ||
+        (basis_id != BDRT_BASIS_GAUSSIAN && basis_id != BDRT_BASIS_ZIC)) {
+        set_error("bdrt_build_L: bad arguments");
+        return -1;
+    }
+    if (basis_id == BDRT_BASIS_ZIC && (coef4[1] != 0.0 || coef4[2] != 0.0 || coef4[3] != 0.0)) {
+        set_error("bdrt_build_L: the Zic basis has order 0 only (matrices.py:316-318)");
+        return -1;
+    }
     bind_process_device();
-    DevBuf dT, dO;
+    DevBuf dF, dT, dO;
     int rc;
-    if ((rc = dT.alloc(k * sizeof(double))) || (rc = dO.alloc((size_t)k * k * sizeof(double)))) return rc;
+    if ((rc = dT.alloc(k * sizeof(double))) || (rc = dO.alloc((size_t)nf * k * sizeof(double)))) return rc;
+    if (freq) {
+        if ((rc = dF.alloc(nf * sizeof(double)))) return rc;
+        BDRT_HIP(hipMemcpy(dF.p, freq, nf * sizeof(double), hipMemcpyHostToDevice));
+    }
     BDRT_HIP(hipMemcpy(dT.p, tau, k * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(build_L_kernel, dim3((k * k + 255) / 256), dim3(256), 0, 0, dT.as<double>(), k, eps, coef4[0],
-                       coef4[1], coef4[2], coef4[3], dO.as<double>());
+    hipLaunchKernelGGL(build_L_kernel, dim3((nf * k + 255) / 256), dim3(256), 0, 0, freq ? dF.as<double>() : (const double *)nullptr,
+                       nf, dT.as<double>(), k, eps, coef4[0], coef4[1], coef4[2], coef4[3], basis_id, dO.as<double>());
     BDRT_HIP(hipGetLastError());
-    BDRT_HIP(hipMemcpy(out, dO.p, (size_t)k * k * sizeof(double), hipMemcpyDeviceToHost));
+    BDRT_HIP(hipMemcpy(out, dO.p, (size_t)nf * k * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -461,8 +461,11 @@ int bdrt_logp_grad_dev(bdrt_problem *p, const double *d_theta, const int *d_spec
                        double *d_grad, void *stream)
 {
     if (!p || !d_theta) { set_error("bdrt_logp_grad_dev: null argument"); return -1; }
-    return launch_logp_grad(&p->impl, d_theta, d_spec, B, jacobian, d_lp, d_grad, nullptr, nullptr, nullptr,
-                            stream ? (hipStream_t)stream : p->impl.stream);
+    hipStream_t st = stream ? (hipStream_t)stream : p->impl.stream;
+    // a handful of points: one workgroup per point (a 16-column tile with one live column costs the same 24 us as a full one)
+    const int few = launch_logp_grad_few(&p->impl, d_theta, d_spec, B, jacobian, d_lp, d_grad, st);
+    if (few <= 0) return few;
+    return launch_logp_grad(&p->impl, d_theta, d_spec, B, jacobian, d_lp, d_grad, nullptr, nullptr, nullptr, st);
 }
 
 int bdrt_logp_grad(bdrt_problem *p, const double *theta, const int *spec, int B, int jacobian, double *lp, double *grad)
@@ -476,8 +479,10 @@ int bdrt_logp_grad(bdrt_problem *p, const double *theta, const int *spec, int B,
     const size_t nb = (size_t)B * P.dev.D * sizeof(double);
     BDRT_HIP(hipMemcpyAsync(P.d_theta, theta, nb, hipMemcpyHostToDevice, P.stream));
     if (spec) BDRT_HIP(hipMemcpyAsync(P.d_spec, spec, (size_t)B * sizeof(int), hipMemcpyHostToDevice, P.stream));
-    if ((rc = launch_logp_grad(&P, P.d_theta, spec ? P.d_spec : nullptr, B, jacobian, P.d_lp, grad ? P.d_grad : nullptr,
-                               nullptr, nullptr, nullptr, P.stream)))
+    rc = launch_logp_grad_few(&P, P.d_theta, spec ? P.d_spec : nullptr, B, jacobian, P.d_lp, grad ? P.d_grad : nullptr, P.stream);
+    if (rc < 0) return rc;
+    if (rc > 0 && (rc = launch_logp_grad(&P, P.d_theta, spec ? P.d_spec : nullptr, B, jacobian, P.d_lp, grad ? P.d_grad : nullptr,
+                                         nullptr, nullptr, nullptr, P.stream)))
         return rc;
     if (lp) BDRT_HIP(hipMemcpyAsync(lp, P.d_lp, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, P.stream));
     if (grad) BDRT_HIP(hipMemcpyAsync(grad, P.d_grad, nb, hipMemcpyDeviceToHost, P.stream));

@@ -62,7 +62,9 @@ struct NutsArgs {
     unsigned long long *leap_counter;   // total leapfrogs (all chains)
     int *done_counter;     // workgroups whose chains are all finished
     int n_units;
-    int cpw;               // chains per workgroup (1..16): few chains are spread over many workgroups / waves
+    const int *slot_unit;  // 16-chain kernel: [n_wg][16] unit held by slot k of workgroup wg (-1: empty).  Unit <-> slot is an
+                           // indirection so that live chains can be re-packed into fewer workgroups during a run (compaction)
+    int cpw;               // chains per workgroup at creation (1..16): few chains are spread over many workgroups / waves
     int rounds;
     int ds;                // row stride of the state vectors (D rounded up to 32)
     long long *prof;       // optional [n_wg][32] cycle counters (phase profile)
@@ -93,11 +95,10 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     // Unit u = wg * cpw + k sits in column slot_col(k): the first eight chains of a workgroup get one wave each (even
     // columns = lanes 0..31 of waves 0..7), the next eight the other half-waves.  With few chains per workgroup the per-chain
     // VALU work of a round is then spread over the four SIMDs instead of piling up on one.
-    const int c0 = wg * a.cpw;
-    const int nvalid = min(a.cpw, a.n_units - c0);
-    const int kslot = col_slot(c);                       // this column's chain index within the workgroup
-    const bool valid = kslot < nvalid;
-    const int unit = c0 + kslot;
+    const int *su = a.slot_unit + (size_t)wg * NC;
+    const int kslot = col_slot(c);                       // this column's slot within the workgroup
+    const int unit = su[kslot];
+    const bool valid = unit >= 0;
 
     // LDS carve-up: [tile region | (fast S1 path: theta rows of the 16 chains) | lp of the 16 chains | chain states | spectrum ids]
     const size_t tile_doubles = MODE == 4 ? hw_lds_doubles(P) : (MODE >= 2 ? s1_lds_doubles(P) : lds_doubles(P));
@@ -117,10 +118,10 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     auto row = [&](int v) -> double * { return V + ((size_t)v * NC + c) * DS; };   // this chain's row of vector v
 
     if (tid < NC) {
-        const int k = col_slot(tid);
-        if (k < nvalid) sts[tid] = a.states[c0 + k];
+        const int u = su[col_slot(tid)];
+        if (u >= 0) sts[tid] = a.states[u];
         else { memset(&sts[tid], 0, sizeof(ChainState)); sts[tid].phase = PH_DONE; }
-        spec[tid] = k < nvalid ? sts[tid].spec : 0;
+        spec[tid] = u >= 0 ? sts[tid].spec : 0;
         thoff[tid] = (SPEC && sts[tid].thsel) ? TH2OFF : 0;
     }
     __syncthreads();
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             {
                 WideCtx wx;
                 wx.P = Pp; wx.np = &np; wx.a = &a; wx.V = V; wx.smem = smem; wx.sts = sts; wx.lpn = lpn; wx.hvy = hvy; wx.hvk = hvk;
-                wx.prof = io.prof; wx.D = D; wx.DS = DS; wx.TH2OFF = TH2OFF; wx.c0 = c0; wx.nvalid = nvalid; wx.ncol = NC; wx.hot_base = nullptr; wx.hot_slot = nullptr;
+                wx.prof = io.prof; wx.D = D; wx.DS = DS; wx.TH2OFF = TH2OFF; wx.c0 = 0; wx.nvalid = 0; wx.slot_unit = su; wx.ncol = NC; wx.hot_base = nullptr; wx.hot_slot = nullptr;
                 for (int hc = 0; hc < NC; ++hc) {
                     const int kind = hvy[hc];
                     if (kind) wide_coop_tail<(NJ * 32 + WIDE_NT - 1) / WIDE_NT>(wx, hc, kind == 2, my_leaps, tid);
@@ -840,7 +841,8 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 // One chain per workgroup (bdrt_solo.h): the same transition logic as nuts_kernel, element j of every vector in thread j,
 // all vectors in LDS.  Global state layout: vecs [n_units][SG_COUNT][ds]; states [n_units].
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SOLO_NT) void nuts_solo_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, SoloGeom g)
+template <int WPE>   // waves per SIMD the register budget allows: 2 = one workgroup per CU, 4 = two (when their LDS fits)
+__global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, SoloGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevProblem &P = *Pp;
@@ -1211,7 +1213,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
     }
     WideCtx wx;
     wx.P = Pp; wx.np = &np; wx.a = &a; wx.V = V; wx.smem = scr; wx.sts = sts; wx.lpn = lpn; wx.hvy = nullptr; wx.hvk = nullptr;
-    wx.prof = nullptr; wx.D = D; wx.DS = DS; wx.TH2OFF = 0; wx.c0 = unit; wx.nvalid = 1; wx.ncol = 1;
+    wx.prof = nullptr; wx.D = D; wx.DS = DS; wx.TH2OFF = 0; wx.c0 = unit; wx.nvalid = 1; wx.slot_unit = nullptr; wx.ncol = 1;
     wx.hot_base = hot; wx.hot_slot = hslot;
     unsigned long long my_leaps = 0;
     for (int round = 0; round < a.rounds; ++round) {
@@ -1259,10 +1261,10 @@ __global__ __launch_bounds__(SOLO_NT) void wide1_eval_kernel(const DevProblem *_
 // finishes faster (8.3 us per leapfrog, one chain per CU at a time: below ~4 chains per CU), the live chains move there:
 // this kernel copies a chain's rows from the 16-chain layout [wg][V_*][column][ds16] to [slot][SV_* / SG_*][dss].
 // Same counter-based random numbers and the same arithmetic up to summation order, so the chains continue as they were.
-__global__ void nuts_migrate_kernel(const double *v16, int ds16, int cpw, const int *unit_map, double *vsolo, int dss, int D)
+__global__ void nuts_migrate_kernel(const double *v16, int ds16, const int *unit_loc, const int *unit_map, double *vsolo, int dss, int D)
 {
     const int slot = blockIdx.x, u = unit_map[slot];
-    const int wg = u / cpw, col = slot_col(u % cpw);
+    const int wg = unit_loc[u] >> 4, col = slot_col(unit_loc[u] & 15);      // where the unit sits in the 16-chain layout
     const double *src = v16 + (size_t)wg * V_COUNT * NC * ds16;
     double *dst = vsolo + (size_t)slot * SG_COUNT * dss;
     for (int r = 0; r < SG_COUNT; ++r) {
@@ -1279,10 +1281,10 @@ static_assert(SOLO_MAXD == MAXD, "the two kernels keep the same number of checkp
 
 // the same hand-over for the models of the general one-chain kernel (bdrt_solo_wide.h): rows keep their meaning, the chain's
 // column of [wg][V_*][16][ds] becomes [slot][V_*][ds]
-__global__ void nuts_migrate_wide1_kernel(const double *v16, int ds, int cpw, const int *unit_map, double *v1, ChainState *states)
+__global__ void nuts_migrate_wide1_kernel(const double *v16, int ds, const int *unit_loc, const int *unit_map, double *v1, ChainState *states)
 {
     const int slot = blockIdx.x, u = unit_map[slot];
-    const int wg = u / cpw, col = slot_col(u % cpw);
+    const int wg = unit_loc[u] >> 4, col = slot_col(unit_loc[u] & 15);
     const double *src = v16 + (size_t)wg * V_COUNT * NC * ds;
     double *dst = v1 + (size_t)slot * V_COUNT * ds;
     const int live = states[u].thsel ? V_TH2 : V_TH;       // the one-chain kernel keeps theta in V_TH
@@ -1292,6 +1294,34 @@ __global__ void nuts_migrate_wide1_kernel(const double *v16, int ds, int cpw, co
     }
     __syncthreads();
     if (threadIdx.x == 0) states[u].thsel = 0;
+}
+
+// Compaction of a large run.  A finished chain leaves its column of the 16-column MFMA tile empty, and a workgroup costs the
+// same ~33 us per round however few of its columns are live.  While there are more workgroups than CUs (more than 16 live
+// chains per CU), the live chains are therefore re-packed into fewer, full workgroups from time to time: workgroup `blockIdx.x`
+// of the NEW layout gathers the rows of its up to 16 units from wherever they sat in the old one.  Rows are copied verbatim and
+// every random number is keyed by (seed, chain id, iteration, ...), never by the slot, so the chains continue bit for bit
+// (tests/test_gpu_config4.py).  Empty slots get the finite placeholders of a fresh sampler (inverse metric 1, zeros elsewhere).
+__global__ __launch_bounds__(256) void nuts_compact_kernel(const double *vold, const int *old_loc, const int *new_slot_unit,
+                                                           double *vnew, int ds)
+{
+    const int wg = blockIdx.x;
+    const size_t rowlen = (size_t)ds;
+    for (int k = 0; k < NC; ++k) {
+        const int u = new_slot_unit[wg * NC + k];
+        const int col = slot_col(k);
+        double *dst = vnew + (size_t)wg * V_COUNT * NC * rowlen;
+        if (u < 0) {
+            for (int v = 0; v < V_COUNT; ++v)
+                for (int j = threadIdx.x; j < ds; j += blockDim.x) dst[((size_t)v * NC + col) * rowlen + j] = v == V_MINV ? 1.0 : 0.0;
+            continue;
+        }
+        const int owg = old_loc[u] >> 4, ocol = slot_col(old_loc[u] & 15);
+        const double *src = vold + (size_t)owg * V_COUNT * NC * rowlen;
+        for (int v = 0; v < V_COUNT; ++v)
+            for (int j = threadIdx.x; j < ds; j += blockDim.x)
+                dst[((size_t)v * NC + col) * rowlen + j] = src[((size_t)v * NC + ocol) * rowlen + j];
+    }
 }
 
 struct Sampler {
@@ -1324,6 +1354,13 @@ struct Sampler {
     double *vecs16 = nullptr;         // the 16-chain rows, kept until the sampler is destroyed
     int *d_unit_map = nullptr;
     int n_solo = 0;                   // workgroups of the one-chain-per-workgroup kernel (= n_units unless migrated)
+    // unit <-> slot of the 16-chain kernel (compaction: nuts_compact_kernel)
+    std::vector<int> slot_unit;       // host copy of args.slot_unit: [n_wg][16]
+    std::vector<int> unit_loc;        // unit -> wg * 16 + slot (-1: retired: the chain had finished when its workgroup was re-packed)
+    int *d_slot_unit = nullptr, *d_unit_loc = nullptr;
+    size_t vecs_capacity = 0;         // doubles allocated behind args.vecs
+    bool may_compact = false;
+    int n_compactions = 0;
 };
 
 // as many LDS-resident rows as fit beside the evaluator (160 KiB minus a margin)
@@ -1341,6 +1378,44 @@ static size_t nuts_lds_bytes(const DevProblem &P, bool s1)
     const int nj = P.D <= 32 * 11 ? 11 : 16;
     const size_t tile = s1 ? s1_lds_doubles(P) + (size_t)NC * 32 * nj : lds_doubles(P);   // s1: + theta rows
     return (tile + (size_t)3 * NC) * sizeof(double) + NC * sizeof(ChainState) + 3 * NC * sizeof(int) + 16;
+}
+
+int launch_logp_grad_few(Problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp, double *d_grad,
+                         hipStream_t stream)
+{
+    Problem &P = *p;
+    const char *sw = getenv("BDRT_FEW_POINTS");                     // diagnostics / tests: 0 = the tile evaluator whatever B is
+    const bool off = sw && atoi(sw) == 0;
+    if (off || B < 1 || !d_grad || !d_lp) return 1;
+    const bool solo = solo_capable(P.dev), w1 = !solo && wide1_capable(P.dev);
+    if (!solo && !w1) return 1;
+    BDRT_HIP(hipSetDevice(P.device));
+    static int n_cu[64] = {};
+    int &ncu = n_cu[P.device & 63];
+    if (ncu == 0) {
+        hipDeviceProp_t prop;
+        ncu = (hipGetDeviceProperties(&prop, P.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    // up to one workgroup per CU: beyond that the 16-column tiles win (B = 512: 26 us)
+    if (B > ncu) return 1;
+    static LdsAttrCache attr_solo, attr_w1;
+    if (solo) {
+        const SoloGeom g = solo_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
+        const size_t lds = (size_t)g.total * sizeof(double) + 64;
+        BDRT_HIP(attr_solo.ensure(lds, [&]() {
+            return hipFuncSetAttribute((const void *)solo_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }));
+        hipLaunchKernelGGL(solo_eval_kernel, dim3(B), dim3(SOLO_NT), lds, stream, (const DevProblem *)P.d_dev, g, d_theta, d_spec,
+                           jacobian, d_lp, d_grad);
+    } else {
+        const Wide1Geom G = wide1_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D, P.dev.nblocks);
+        const size_t lds = (size_t)G.total * sizeof(double) + 64;
+        BDRT_HIP(attr_w1.ensure(lds, [&]() {
+            return hipFuncSetAttribute((const void *)wide1_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }));
+        hipLaunchKernelGGL(wide1_eval_kernel, dim3(B), dim3(SOLO_NT), lds, stream, (const DevProblem *)P.d_dev, G, d_theta, d_spec,
+                           jacobian, d_lp, d_grad);
+    }
+    BDRT_HIP(hipGetLastError());
+    return 0;
 }
 
 }  // namespace bdrt
@@ -1376,6 +1451,8 @@ void bdrt_sampler_destroy(bdrt_sampler *s)
     if (S.d_active) hipFree(S.d_active);
     if (S.vecs16) hipFree(S.vecs16);
     if (S.d_unit_map) hipFree(S.d_unit_map);
+    if (S.d_slot_unit) hipFree(S.d_slot_unit);
+    if (S.d_unit_loc) hipFree(S.d_unit_loc);
     if (S.stream) hipStreamDestroy(S.stream);
     delete s;
 }
@@ -1500,6 +1577,24 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
             double *V = hv.data() + (size_t)wg * V_COUNT * NC * DS;
             for (int j = 0; j < S.D; ++j) V[((size_t)V_MINV * NC + slot_col(k)) * DS + j] = 1.0;
         }
+    if (!S.solo && !S.wide1) {
+        S.slot_unit.assign((size_t)S.n_wg * NC, -1);
+        S.unit_loc.assign((size_t)n_units, -1);
+        for (int u = 0; u < n_units; ++u) {
+            const int wg = u / S.args.cpw, k = u % S.args.cpw;
+            S.slot_unit[(size_t)wg * NC + k] = u;
+            S.unit_loc[u] = wg * NC + k;
+        }
+        if (hipMalloc((void **)&S.d_slot_unit, S.slot_unit.size() * sizeof(int)) != hipSuccess) return fail("hipMalloc(slot map) failed");
+        if (hipMalloc((void **)&S.d_unit_loc, S.unit_loc.size() * sizeof(int)) != hipSuccess) return fail("hipMalloc(slot map) failed");
+        if (hipMemcpy(S.d_slot_unit, S.slot_unit.data(), S.slot_unit.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(S.d_unit_loc, S.unit_loc.data(), S.unit_loc.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+            return fail("bdrt_sampler_create: upload of the slot map failed");
+        S.args.slot_unit = S.d_slot_unit;
+        // more workgroups than CUs: finished chains can be squeezed out of the tiles (BDRT_COMPACTION=0 keeps the layout)
+        S.may_compact = S.n_wg > n_cu && !(getenv("BDRT_COMPACTION") && atoi(getenv("BDRT_COMPACTION")) == 0);
+    }
+    S.vecs_capacity = nvec;
     if (hipMalloc((void **)&S.args.vecs, nvec * sizeof(double)) != hipSuccess) return fail("hipMalloc(vecs) failed");
     if (hipMalloc((void **)&S.args.states, hs.size() * sizeof(ChainState)) != hipSuccess) return fail("hipMalloc(states) failed");
     const size_t nd = (size_t)n_units * std::max(n_draws, 1) * S.D;
@@ -1535,7 +1630,9 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
                                (const void *)nuts_kernel<11, 2>, (const void *)nuts_kernel<16, 2>,
                                (const void *)nuts_kernel<11, 3>, (const void *)nuts_kernel<16, 3>,
                                (const void *)nuts_kernel<11, 4>, (const void *)nuts_kernel<16, 4>, (const void *)nuts_kernel<27, 4>};
-        hipError_t e = hipFuncSetAttribute((const void *)nuts_solo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)nuts_solo_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)nuts_solo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)nuts_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         for (int i = 0; i < 13 && e == hipSuccess; ++i)
@@ -1590,7 +1687,13 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             hipLaunchKernelGGL(nuts_wide1_kernel, dim3(S.n_wg), dim3(SOLO_NT), wide1_lds_bytes(S.geom1, S.args.ds, S.nhot1), S.stream, dp,
                                S.np, S.args, S.geom1, S.nhot1);
         else if (S.solo)
-            hipLaunchKernelGGL(nuts_solo_kernel, dim3(S.n_solo), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
+        {
+            static const int wpe = getenv("BDRT_SOLO_WPE") ? atoi(getenv("BDRT_SOLO_WPE")) : 2;
+            if (wpe == 4 && 2 * S.lds_bytes <= 160 * 1024)
+                hipLaunchKernelGGL(nuts_solo_kernel<4>, dim3(S.n_solo), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
+            else
+                hipLaunchKernelGGL(nuts_solo_kernel<2>, dim3(S.n_solo), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
+        }
         else if (S.use_s1 && S.D <= 32 * 11)
             hipLaunchKernelGGL((nuts_kernel<11, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
         else if (S.use_s1)
@@ -1631,12 +1734,67 @@ int bdrt_sampler_sync(bdrt_sampler *s)
     return harvest_events(s->impl, true);
 }
 
+// frees its device pointers unless they were handed over (error paths of the two re-layout passes below)
+struct DevTmp {
+    void *p = nullptr;
+    ~DevTmp() { if (p) hipFree(p); }
+    void *release() { void *q = p; p = nullptr; return q; }
+};
+
+// Re-pack the live chains of a 16-chain run into fewer workgroups (nuts_compact_kernel).  Called between launches with the
+// stream idle and `active` = live chains after the last launch.  Worth it only while the run has more workgroups than CUs:
+// with one workgroup per CU a round costs the same whatever the number of live columns, and fewer workgroups would only idle CUs.
+static int maybe_compact(Sampler &S, int active)
+{
+    if (!S.may_compact || S.migrated || S.solo || S.wide1 || active <= 0) return 0;
+    const int target = std::max(S.n_cu, (active + NC - 1) / NC);
+    // at least a quarter of the columns empty, and at least 1/8 fewer workgroups afterwards
+    if ((long long)active * 4 > (long long)S.n_wg * NC * 3 || (long long)target * 8 > (long long)S.n_wg * 7) return 0;
+    std::vector<ChainState> hs((size_t)S.n_units);
+    BDRT_HIP(hipMemcpy(hs.data(), S.args.states, hs.size() * sizeof(ChainState), hipMemcpyDeviceToHost));
+    std::vector<int> live;
+    for (int wgk = 0; wgk < (int)S.slot_unit.size(); ++wgk) {            // slot order: keeps neighbours (same spectrum) together
+        const int u = S.slot_unit[wgk];
+        if (u >= 0 && (hs[u].phase == PH_INIT || hs[u].phase == PH_EPS || hs[u].phase == PH_TREE)) live.push_back(u);
+    }
+    if (live.empty()) return 0;
+    const int n_wg = std::max(std::min(S.n_cu, (int)live.size()), ((int)live.size() + NC - 1) / NC);
+    const int cpw = ((int)live.size() + n_wg - 1) / n_wg;
+    std::vector<int> slot_unit((size_t)n_wg * NC, -1), unit_loc((size_t)S.n_units, -1);
+    for (size_t i = 0; i < live.size(); ++i) {
+        const int wg = (int)(i / cpw), k = (int)(i % cpw);
+        slot_unit[(size_t)wg * NC + k] = live[i];
+        unit_loc[live[i]] = wg * NC + k;
+    }
+    const size_t nvec = (size_t)n_wg * V_COUNT * NC * S.args.ds;
+    DevTmp vnew, dslot;
+    if (hipMalloc(&vnew.p, nvec * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return 0; }      // (keep going as is)
+    if (hipMalloc(&dslot.p, slot_unit.size() * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    BDRT_HIP(hipMemcpyAsync(dslot.p, slot_unit.data(), slot_unit.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
+    // d_unit_loc still holds the OLD locations: the kernel reads them, then they are replaced
+    hipLaunchKernelGGL(nuts_compact_kernel, dim3(n_wg), dim3(256), 0, S.stream, (const double *)S.args.vecs, (const int *)S.d_unit_loc,
+                       (const int *)dslot.p, (double *)vnew.p, S.args.ds);
+    BDRT_HIP(hipGetLastError());
+    BDRT_HIP(hipMemcpyAsync(S.d_unit_loc, unit_loc.data(), unit_loc.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
+    BDRT_HIP(hipStreamSynchronize(S.stream));
+    hipFree(S.args.vecs);
+    hipFree(S.d_slot_unit);
+    S.args.vecs = (double *)vnew.release();
+    S.d_slot_unit = (int *)dslot.release();
+    S.args.slot_unit = S.d_slot_unit;
+    S.vecs_capacity = nvec;
+    S.slot_unit.swap(slot_unit);
+    S.unit_loc.swap(unit_loc);
+    S.n_wg = n_wg;
+    S.n_compactions += 1;
+    if (S.d_prof) { S.args.prof = nullptr; }              // (the phase-profile slots were laid out for the old workgroups)
+    return 0;
+}
+
 // Hand the live chains of a 16-chain run to the one-chain-per-workgroup kernel when that finishes them sooner (see
 // nuts_migrate_kernel).  Called between launches with the stream idle.
-static int maybe_migrate_tail(Sampler &S)
+static int maybe_migrate_tail(Sampler &S, int active)
 {
-    int active = 0;
-    BDRT_HIP(hipMemcpy(&active, S.d_active, sizeof(int), hipMemcpyDeviceToHost));
     // the one-chain kernels run one chain per CU at a time, ~4x faster per leapfrog: the LDS-resident one wins below ~4 live
     // chains per CU, the general one below ~2.5
     const bool to_solo = solo_capable(S.prob->dev);
@@ -1647,26 +1805,25 @@ static int maybe_migrate_tail(Sampler &S)
     for (int u = 0; u < S.n_units; ++u)
         if (hs[u].phase == PH_INIT || hs[u].phase == PH_EPS || hs[u].phase == PH_TREE) map.push_back(u);
     if (map.empty()) return 0;
+    DevTmp vnew, dmap;
     if (!to_solo) {
         // general one-chain kernel: the 16-chain rows, one column
         const Wide1Geom G = wide1_geometry(S.prob->dev.nf, S.prob->dev.blk[0].K, S.prob->dev.D, S.prob->dev.nblocks);
         int nhot = W1_HOT_MAX;                                // as many LDS-resident rows as the LDS limit set at creation allows
         while (nhot > 0 && wide1_lds_bytes(G, S.args.ds, nhot) > std::min(S.lds_bytes, (size_t)158 * 1024)) --nhot;
         if (wide1_lds_bytes(G, S.args.ds, nhot) > S.lds_bytes) return 0;
-        double *v1 = nullptr;
-        int *dmap1 = nullptr;
-        if (hipMalloc((void **)&v1, map.size() * (size_t)V_COUNT * S.args.ds * sizeof(double)) != hipSuccess) return 0;
-        if (hipMalloc((void **)&dmap1, map.size() * sizeof(int)) != hipSuccess) { hipFree(v1); return 0; }
-        BDRT_HIP(hipMemcpy(dmap1, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (hipMalloc(&vnew.p, map.size() * (size_t)V_COUNT * S.args.ds * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        if (hipMalloc(&dmap.p, map.size() * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        BDRT_HIP(hipMemcpy(dmap.p, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(nuts_migrate_wide1_kernel, dim3((unsigned)map.size()), dim3(256), 0, S.stream, (const double *)S.args.vecs, S.args.ds,
-                           S.args.cpw, (const int *)dmap1, v1, S.args.states);
+                           (const int *)S.d_unit_loc, (const int *)dmap.p, (double *)vnew.p, S.args.states);
         BDRT_HIP(hipGetLastError());
         BDRT_HIP(hipStreamSynchronize(S.stream));
         S.vecs16 = S.args.vecs;
         S.args.prof = nullptr;
-        S.args.vecs = v1;
-        S.d_unit_map = dmap1;
-        S.args.unit_map = dmap1;
+        S.args.vecs = (double *)vnew.release();
+        S.d_unit_map = (int *)dmap.release();
+        S.args.unit_map = S.d_unit_map;
         S.geom1 = G;
         S.nhot1 = nhot;
         S.wide1 = true;
@@ -1678,21 +1835,19 @@ static int maybe_migrate_tail(Sampler &S)
     const SoloGeom g = solo_geometry(S.prob->dev.nf, S.prob->dev.blk[0].K, S.prob->dev.D);
     const size_t lds = (size_t)g.total * sizeof(double) + 64;
     if (lds > S.lds_bytes) return 0;                      // (bdrt_sampler_create raised every kernel's LDS limit to the 16-chain size)
-    double *vsolo = nullptr;
-    int *dmap = nullptr;
-    if (hipMalloc((void **)&vsolo, map.size() * (size_t)SG_COUNT * g.DSS * sizeof(double)) != hipSuccess) return 0;   // (keep going as is)
-    if (hipMalloc((void **)&dmap, map.size() * sizeof(int)) != hipSuccess) { hipFree(vsolo); return 0; }
-    BDRT_HIP(hipMemcpy(dmap, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (hipMalloc(&vnew.p, map.size() * (size_t)SG_COUNT * g.DSS * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return 0; }   // (keep going as is)
+    if (hipMalloc(&dmap.p, map.size() * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    BDRT_HIP(hipMemcpy(dmap.p, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(nuts_migrate_kernel, dim3((unsigned)map.size()), dim3(256), 0, S.stream, (const double *)S.args.vecs, S.args.ds,
-                       S.args.cpw, (const int *)dmap, vsolo, g.DSS, S.D);
+                       (const int *)S.d_unit_loc, (const int *)dmap.p, (double *)vnew.p, g.DSS, S.D);
     BDRT_HIP(hipGetLastError());
     BDRT_HIP(hipStreamSynchronize(S.stream));
     S.vecs16 = S.args.vecs;
     S.args.prof = nullptr;                                // (the phase-profile slots are laid out per 16-chain workgroup)
-    S.args.vecs = vsolo;
+    S.args.vecs = (double *)vnew.release();
     S.args.ds = g.DSS;
-    S.d_unit_map = dmap;
-    S.args.unit_map = dmap;
+    S.d_unit_map = (int *)dmap.release();
+    S.args.unit_map = S.d_unit_map;
     S.geom = g;
     S.lds_bytes = lds;
     S.solo = true;
@@ -1715,7 +1870,12 @@ int bdrt_sampler_run(bdrt_sampler *s)
         int rc = bdrt_sampler_advance(s, S.rounds_default, &done);
         if (rc) return rc;
         spent += S.rounds_default;
-        if (!done && S.may_migrate && !S.migrated && (rc = maybe_migrate_tail(S))) return rc;
+        if (!done && !S.migrated && (S.may_migrate || S.may_compact)) {
+            int active = 0;
+            BDRT_HIP(hipMemcpy(&active, S.d_active, sizeof(int), hipMemcpyDeviceToHost));
+            if (S.may_migrate && (rc = maybe_migrate_tail(S, active))) return rc;
+            if (!S.migrated && (rc = maybe_compact(S, active))) return rc;
+        }
     }
     if (!done) { set_error("bdrt_sampler_run: chains did not finish within the leapfrog bound"); return -3; }
     return 0;
@@ -1745,6 +1905,7 @@ int bdrt_sampler_results(bdrt_sampler *s, double *draws, double *lp, bdrt_chain_
 }
 
 int bdrt_sampler_tail_units(bdrt_sampler *s) { return s && s->impl.migrated ? s->impl.n_solo : 0; }
+int bdrt_sampler_compactions(bdrt_sampler *s) { return s ? s->impl.n_compactions : -1; }
 int bdrt_sampler_kind(bdrt_sampler *s) { return !s ? -1 : (s->impl.wide1 ? 2 : (s->impl.solo ? 1 : 0)); }
 
 int64_t bdrt_sampler_total_leapfrogs(bdrt_sampler *s)

@@ -31,6 +31,7 @@ struct WideCtx {
     const double *hvk;      // [NC][2] LDS: kinetic energy / non-finite gradient count of the kind-2 chains
     long long *prof;        // optional cycle counters (slots 10..16: stages of the cooperative phase, thread 0)
     int D, DS, TH2OFF, c0, nvalid;
+    const int *slot_unit;   // 16-chain kernel: unit of each of the workgroup's 16 slots (-1: empty); nullptr: unit = c0 + slot
     int ncol;               // columns of the row layout: V[(v * ncol + column) * DS] (16; 1 for the one-chain kernel of bdrt_solo_wide.h)
     // one-chain kernel (HOT = true): rows of the chain that live in LDS for the launch -- hot_slot[v] >= 0: hot_base + slot * DS
     double *hot_base;
@@ -81,8 +82,8 @@ __device__ inline void wide_coop_tail(const WideCtx &x, int hc, bool c_done, uns
         return x.V + ((size_t)v * x.ncol + hc) * DS;
     };
     const int kslot = col_slot(hc);
-    const bool valid = kslot < x.nvalid;
-    const int unit = x.c0 + kslot;
+    const int unit = x.slot_unit ? x.slot_unit[kslot] : x.c0 + kslot;
+    const bool valid = x.slot_unit ? unit >= 0 : kslot < x.nvalid;
     double *scr = x.smem, *zrow = x.smem + 512;        // (9 * 2 * MAXD = 180 doubles of reduction scratch)
     double *TH = row(V_TH) + (s.thsel ? x.TH2OFF : 0), *Pm = row(V_P), *G = row(V_G), *MI = row(V_MINV);
 

@@ -430,6 +430,10 @@ class Sampler:
         """Chains that `run` handed from the 16-chain kernel to the one-chain-per-workgroup kernel for the tail (0: none)."""
         return int(self._lib.bdrt_sampler_tail_units(self.handle))
 
+    def compactions(self):
+        """How often `run` re-packed the live chains into fewer 16-chain workgroups (runs with more than 16 units per CU)."""
+        return int(self._lib.bdrt_sampler_compactions(self.handle))
+
     def kernel_time(self, reset=False):
         ms = C.c_double(); nl = C.c_int64()
         check(self._lib.bdrt_sampler_kernel_time(self.handle, C.byref(ms), C.byref(nl), int(reset)), 'bdrt_sampler_kernel_time')

@@ -7,6 +7,13 @@ from ._lib import check, f64, ptr
 from .utils import is_loguniform, rel_round
 
 _KERNEL_ID = {('blocking', 'planar'): 1, ('blocking', 'spherical'): 2, ('transmissive', 'planar'): 3}
+_BASIS_ID = {'gaussian': 0, 'Cole-Cole': 1, 'Zic': 2}            # get_basis_func (reference matrices.py:8-24)
+
+
+def _basis_id(basis):
+    if basis not in _BASIS_ID:
+        raise ValueError(f'Invalid basis {basis}. Options are gaussian')
+    return _BASIS_ID[basis]
 
 
 def _kernel_id(kernel, dist_type, symmetry, bc, ct, k_ct):
@@ -58,10 +65,10 @@ def _toeplitz_decision(frequencies, tau, tau_given, ct):
 
 def construct_A(frequencies, part, tau=None, basis='gaussian', fit_inductance=False, epsilon=1, kernel='DRT',
                 dist_type='series', symmetry='planar', bc=None, ct=False, k_ct=None, integrate_method='trapz'):
-    """A' / A'' matrix ([len(frequencies) x len(tau)]).  Same arguments as the reference; only the gaussian basis
-    and the trapezoid quadrature (the reference's defaults and the only ones Inverter uses) are implemented."""
-    if basis != 'gaussian':
-        raise ValueError(f'Invalid basis {basis}. Options are gaussian')
+    """A' / A'' matrix ([len(frequencies) x len(tau)]).  Same arguments as the reference: basis 'gaussian' (what Inverter
+    uses), 'Cole-Cole' (0 < epsilon < 1) or 'Zic'; the trapezoid quadrature (the reference's default and the only one any
+    caller uses) is the one implemented."""
+    bid = _basis_id(basis)
     if integrate_method != 'trapz':
         raise ValueError("only integrate_method='trapz' (the reference default) is implemented")
     if part not in ('real', 'imag'):
@@ -73,9 +80,9 @@ def construct_A(frequencies, part, tau=None, basis='gaussian', fit_inductance=Fa
     toep = _toeplitz_decision(f, t, tau_given, bool(ct))
     out = np.empty((len(f), len(t)))
     lib = _lib.require_gpu()
-    rc = lib.bdrt_build_A(ptr(f), len(f), ptr(t), len(t), float(epsilon), kid, 0 if part == 'real' else 1,
-                          int(dist_type == 'series'), int(bool(ct)), float(k_ct) if k_ct is not None else 0.0,
-                          int(toep), ptr(out))
+    rc = lib.bdrt_build_A_basis(ptr(f), len(f), ptr(t), len(t), float(epsilon), kid, 0 if part == 'real' else 1,
+                                int(dist_type == 'series'), int(bool(ct)), float(k_ct) if k_ct is not None else 0.0,
+                                int(toep), bid, ptr(out))
     if rc == -2:
         raise Exception('First entries of first row and column are not equal')
     check(rc, 'bdrt_build_A')
@@ -98,17 +105,19 @@ def _order_coefs(order, n):
 
 
 def construct_L(frequencies, tau=None, basis='gaussian', epsilon=1, order=1):
-    """Differentiation matrix; L@coef gives the order-th derivative of the distribution at the basis tau.
-    Like Inverter (inversion.py:2302-2307) this takes the collocated case frequencies = 1/(2 pi tau)."""
-    if basis != 'gaussian':
-        raise ValueError('only the gaussian basis is implemented')
+    """Differentiation matrix [len(frequencies) x len(tau)]: L@coef gives the order-th derivative of the distribution at
+    ln tau = -ln(2 pi frequencies) (reference :268-325).  Inverter calls it collocated, frequencies = 1/(2 pi tau)
+    (inversion.py:2302-2307); any other pair of grids works the same way.  basis: 'gaussian' (orders 0-3, fractional, 3-list
+    mixes) or 'Zic' (order 0, the only case the reference defines, :316-318)."""
+    bid = _basis_id(basis)
+    if basis == 'Cole-Cole' or (basis == 'Zic' and not (type(order) != list and order == 0)):
+        raise ValueError(f'construct_L: no derivative of order {order} is defined for the {basis} basis')
     f = f64(frequencies)
     t = f64(tau) if tau is not None else f64(1 / (2 * np.pi * f))
-    if len(f) != len(t) or not np.allclose(f * 2 * np.pi * t, 1.0, rtol=1e-9):
-        raise ValueError('construct_L is implemented for collocated grids: frequencies = 1/(2*pi*tau)')
-    out = np.empty((len(t), len(t)))
+    out = np.empty((len(f), len(t)))
     lib = _lib.require_gpu()
-    check(lib.bdrt_build_L(ptr(t), len(t), float(epsilon), ptr(_order_coefs(order, 4)), ptr(out)), 'bdrt_build_L')
+    check(lib.bdrt_build_L_rect(ptr(f), len(f), ptr(t), len(t), float(epsilon), ptr(_order_coefs(order, 4)), bid, ptr(out)),
+          'bdrt_build_L')
     return out
 
 

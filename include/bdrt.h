@@ -36,6 +36,13 @@ enum {
     BDRT_KERNEL_DDT_TRANS_PLANAR = 3  /* matrices.py:83-92 */
 };
 
+/* basis function ids: bayes_drt/matrices.py:8-24 get_basis_func */
+enum {
+    BDRT_BASIS_GAUSSIAN = 0,          /* matrices.py:12-13 (the only one Inverter accepts, inversion.py:38-39) */
+    BDRT_BASIS_COLE_COLE = 1,         /* matrices.py:15-17, 0 < epsilon < 1 */
+    BDRT_BASIS_ZIC = 2                /* matrices.py:19-21, epsilon unused */
+};
+
 /* ---- (1) matrix construction ------------------------------------------------------------------ */
 
 /* replaces construct_A (matrices.py:120-265).  out: [nf x k] row-major.  part 0=real 1=imag.
@@ -43,8 +50,16 @@ enum {
  * (matrices.py:213-242), returns -2 if r[0]!=c[0] (matrices.py:239-241). */
 int bdrt_build_A(const double *freq, int nf, const double *tau, int k, double eps, int kernel_id, int part,
                  int dist_series, int use_ct, double k_ct, int toeplitz, double *out);
-/* replaces construct_L (matrices.py:268-325); coef4 weights derivative orders 0..3.  out: [k x k] */
+/* construct_A with another basis function (the `basis` argument of matrices.py:120); bdrt_build_A = gaussian */
+int bdrt_build_A_basis(const double *freq, int nf, const double *tau, int k, double eps, int kernel_id, int part,
+                       int dist_series, int use_ct, double k_ct, int toeplitz, int basis_id, double *out);
+/* replaces construct_L (matrices.py:268-325) in the collocated form Inverter calls it (frequencies = 1/(2 pi tau),
+ * inversion.py:2302-2307); coef4 weights derivative orders 0..3.  out: [k x k] */
 int bdrt_build_L(const double *tau, int k, double eps, const double *coef4, double *out);
+/* construct_L as the function is written: any `frequencies` against any `tau`, out [nf x k]; freq == NULL: collocated
+ * (nf == k).  basis_id: gaussian, or Zic with order 0 only (matrices.py:316-318); Cole-Cole has no derivative there. */
+int bdrt_build_L_rect(const double *freq, int nf, const double *tau, int k, double eps, const double *coef4, int basis_id,
+                      double *out);
 /* replaces construct_M (matrices.py:366-411); coef3 weights orders 0..2.  out: [k x k] */
 int bdrt_build_M(const double *tau, int k, double eps, const double *coef3, int toeplitz, double *out);
 
@@ -178,6 +193,10 @@ int bdrt_sampler_results(bdrt_sampler *s, double *draws_unconstrained, double *l
  * live chains to the one-chain-per-workgroup kernel once that finishes them sooner (BDRT_TAIL_MIGRATION=0 forbids it);
  * bdrt_sampler_tail_units tells how many chains were handed over (0: none). */
 int bdrt_sampler_tail_units(bdrt_sampler *s);
+/* A run with more than 16 units per CU re-packs its live chains into fewer 16-chain workgroups whenever a quarter of the tile
+ * columns has fallen empty (finished chains), so that the MFMA tiles stay full until fewer than 16 live chains per CU are left;
+ * the chains continue bit for bit.  Number of such re-packings so far (BDRT_COMPACTION=0 disables them). */
+int bdrt_sampler_compactions(bdrt_sampler *s);
 /* which kernel advances the chains now: 0 sixteen chains per workgroup (bdrt_nuts.hip), 1 one chain per workgroup with its
  * state in LDS (bdrt_solo.h: few chains of the single-DRT family), 2 one chain per workgroup, general block model
  * (bdrt_solo_wide.h: few chains of any other model on log-uniform grids) */

@@ -328,11 +328,20 @@ int orc_forward(const orc_model *m, const double *theta, double *Z_hat, double *
  * ============================================================================================== */
 #define ORC_NQUAD 1000
 
-/* integrand of get_A_func (matrices.py:27-117); gaussian basis phi(y)=exp(-(eps y)^2) (:12-13) */
-static double integrand(double y, double w_n, double t_m, double eps, int kernel, int part, int dist_series,
-                        int use_ct, double k_ct)
+/* get_basis_func (matrices.py:8-24): 0 gaussian exp(-(eps y)^2) (:12-13); 1 Cole-Cole (:15-17); 2 Zic, eps unused (:19-21) */
+static double basis_phi(double y, double eps, int basis)
 {
-    const double phi = exp(-(eps * y) * (eps * y));
+    if (basis == ORC_BASIS_COLE_COLE)
+        return (1.0 / (2.0 * M_PI)) * sin((1.0 - eps) * M_PI) / (cosh(eps * y) - cos((1.0 - eps) * M_PI));
+    if (basis == ORC_BASIS_ZIC) return 2.0 * exp(y) / (1.0 + exp(2.0 * y));
+    return exp(-(eps * y) * (eps * y));
+}
+
+/* integrand of get_A_func (matrices.py:27-117) */
+static double integrand(double y, double w_n, double t_m, double eps, int kernel, int part, int dist_series,
+                        int use_ct, double k_ct, int basis)
+{
+    const double phi = basis_phi(y, eps, basis);
     if (kernel == ORC_KERNEL_DRT) {
         const double den = 1.0 + exp(2.0 * (y + log(w_n * t_m)));
         if (part == 0) return phi / den;                       /* :48-49 */
@@ -351,14 +360,14 @@ static double integrand(double y, double w_n, double t_m, double eps, int kernel
 
 /* np.trapz(func(y), x=y) with y = np.linspace(-20, 20, 1000)  (matrices.py:236-238, :262-263) */
 static double trapz_entry(double w_n, double t_m, double eps, int kernel, int part, int dist_series, int use_ct,
-                          double k_ct)
+                          double k_ct, int basis)
 {
     const double step = 40.0 / (ORC_NQUAD - 1);
     double s = 0.0, yprev = -20.0;
-    double fprev = integrand(yprev, w_n, t_m, eps, kernel, part, dist_series, use_ct, k_ct);
+    double fprev = integrand(yprev, w_n, t_m, eps, kernel, part, dist_series, use_ct, k_ct, basis);
     for (int i = 1; i < ORC_NQUAD; ++i) {
         double y = (i == ORC_NQUAD - 1) ? 20.0 : -20.0 + i * step;
-        double f = integrand(y, w_n, t_m, eps, kernel, part, dist_series, use_ct, k_ct);
+        double f = integrand(y, w_n, t_m, eps, kernel, part, dist_series, use_ct, k_ct, basis);
         s += (y - yprev) * (f + fprev) / 2.0;
         yprev = y; fprev = f;
     }
@@ -368,12 +377,18 @@ static double trapz_entry(double w_n, double t_m, double eps, int kernel, int pa
 int orc_build_A(const double *freq, int nf, const double *tau, int k, double eps, int kernel, int part,
                 int dist_series, int use_ct, double k_ct, int toeplitz, double *out)
 {
+    return orc_build_A_basis(freq, nf, tau, k, eps, kernel, part, dist_series, use_ct, k_ct, toeplitz, ORC_BASIS_GAUSSIAN, out);
+}
+
+int orc_build_A_basis(const double *freq, int nf, const double *tau, int k, double eps, int kernel, int part,
+                      int dist_series, int use_ct, double k_ct, int toeplitz, int basis, double *out)
+{
     if (toeplitz) {
         double *c = (double *)malloc(sizeof(double) * (size_t)nf);
         double *r = (double *)malloc(sizeof(double) * (size_t)k);
         const double w0 = freq[0] * 2.0 * M_PI, t0 = tau[0];
-        for (int n = 0; n < nf; ++n) c[n] = trapz_entry(freq[n] * 2.0 * M_PI, t0, eps, kernel, part, dist_series, use_ct, k_ct);
-        for (int j = 0; j < k; ++j) r[j] = trapz_entry(w0, tau[j], eps, kernel, part, dist_series, use_ct, k_ct);
+        for (int n = 0; n < nf; ++n) c[n] = trapz_entry(freq[n] * 2.0 * M_PI, t0, eps, kernel, part, dist_series, use_ct, k_ct, basis);
+        for (int j = 0; j < k; ++j) r[j] = trapz_entry(w0, tau[j], eps, kernel, part, dist_series, use_ct, k_ct, basis);
         int bad = (r[0] != c[0]);                     /* matrices.py:239-241 */
         for (int n = 0; n < nf; ++n)
             for (int j = 0; j < k; ++j) out[(size_t)n * k + j] = (n >= j) ? c[n - j] : r[j - n];  /* toeplitz(c, r) */
@@ -382,8 +397,22 @@ int orc_build_A(const double *freq, int nf, const double *tau, int k, double eps
     }
     for (int n = 0; n < nf; ++n)
         for (int j = 0; j < k; ++j)
-            out[(size_t)n * k + j] = trapz_entry(freq[n] * 2.0 * M_PI, tau[j], eps, kernel, part, dist_series, use_ct, k_ct);
+            out[(size_t)n * k + j] = trapz_entry(freq[n] * 2.0 * M_PI, tau[j], eps, kernel, part, dist_series, use_ct, k_ct, basis);
     return 0;
+}
+
+static double l_entry(double w_n, double t_m, double eps, const double *coef4, int basis)
+{
+    const double y = log(1.0 / (w_n * t_m));                     /* matrices.py:323 */
+    if (basis == ORC_BASIS_ZIC) return coef4[0] * basis_phi(y, eps, basis);       /* :316-318: order 0 only */
+    const double g = exp(-(eps * y) * (eps * y));
+    const double e2 = eps * eps;
+    double val = 0.0;
+    if (coef4[0] != 0.0) val += coef4[0] * g;                                              /* :288 */
+    if (coef4[1] != 0.0) val += coef4[1] * (-2.0 * e2 * y * g);                            /* :292 */
+    if (coef4[2] != 0.0) val += coef4[2] * ((-2.0 * e2 + 4.0 * e2 * e2 * y * y) * g);      /* :296 */
+    if (coef4[3] != 0.0) val += coef4[3] * ((12.0 * e2 * e2 * y - 8.0 * e2 * e2 * e2 * y * y * y) * g); /* :300 */
+    return val;
 }
 
 void orc_build_L(const double *tau, int k, double eps, const double *coef4, double *out)
@@ -392,17 +421,17 @@ void orc_build_L(const double *tau, int k, double eps, const double *coef4, doub
     for (int n = 0; n < k; ++n) {
         const double f_n = 1.0 / (2.0 * M_PI * tau[n]);
         const double w_n = 2.0 * M_PI * f_n;
-        for (int j = 0; j < k; ++j) {
-            const double y = log(1.0 / (w_n * tau[j]));          /* matrices.py:323 */
-            const double g = exp(-(eps * y) * (eps * y));
-            const double e2 = eps * eps;
-            double val = 0.0;
-            if (coef4[0] != 0.0) val += coef4[0] * g;                                              /* :288 */
-            if (coef4[1] != 0.0) val += coef4[1] * (-2.0 * e2 * y * g);                            /* :292 */
-            if (coef4[2] != 0.0) val += coef4[2] * ((-2.0 * e2 + 4.0 * e2 * e2 * y * y) * g);      /* :296 */
-            if (coef4[3] != 0.0) val += coef4[3] * ((12.0 * e2 * e2 * y - 8.0 * e2 * e2 * e2 * y * y * y) * g); /* :300 */
-            out[(size_t)n * k + j] = val;
-        }
+        for (int j = 0; j < k; ++j) out[(size_t)n * k + j] = l_entry(w_n, tau[j], eps, coef4, ORC_BASIS_GAUSSIAN);
+    }
+}
+
+/* construct_L as the function itself is written (matrices.py:268-325): any `frequencies` against any `tau`, [nf x k] */
+void orc_build_L_rect(const double *freq, int nf, const double *tau, int k, double eps, const double *coef4, int basis,
+                      double *out)
+{
+    for (int n = 0; n < nf; ++n) {
+        const double w_n = 2.0 * M_PI * freq[n];
+        for (int j = 0; j < k; ++j) out[(size_t)n * k + j] = l_entry(w_n, tau[j], eps, coef4, basis);
     }
 }
 

@@ -75,6 +75,15 @@ void orc_unconstrain(const orc_model *m, const double *params, double *theta);
  * r[0]!=c[0] (matrices.py:239-241). */
 int orc_build_A(const double *freq, int nf, const double *tau, int k, double eps, int kernel, int part,
                 int dist_series, int use_ct, double k_ct, int toeplitz, double *out);
+/* the same with another basis function of get_basis_func (matrices.py:8-24) */
+#define ORC_BASIS_GAUSSIAN 0
+#define ORC_BASIS_COLE_COLE 1
+#define ORC_BASIS_ZIC 2
+int orc_build_A_basis(const double *freq, int nf, const double *tau, int k, double eps, int kernel, int part,
+                      int dist_series, int use_ct, double k_ct, int toeplitz, int basis, double *out);
+/* construct_L for any frequencies against any tau ([nf x k]); basis Zic: order 0 only (matrices.py:316-318) */
+void orc_build_L_rect(const double *freq, int nf, const double *tau, int k, double eps, const double *coef4, int basis,
+                      double *out);
 /* L[n,m] = sum_j coef[j] * d^j/dy^j exp(-(eps y)^2) at y = ln(1/(w_n t_m)), w_n = 2 pi (1/(2 pi t_n))
  * (matrices.py:268-325); coef[4] weights derivative orders 0..3 */
 void orc_build_L(const double *tau, int k, double eps, const double *coef4, double *out);

@@ -57,6 +57,7 @@ def lib():
         _LIB.orc_logp_grad.restype = C.c_int
         _LIB.orc_forward.restype = C.c_int
         _LIB.orc_build_A.restype = C.c_int
+        _LIB.orc_build_A_basis.restype = C.c_int
     return _LIB
 
 
@@ -192,17 +193,20 @@ def a_is_toeplitz(frequencies, tau, ct=False):
     return False
 
 
+BASIS_IDS = {'gaussian': 0, 'Cole-Cole': 1, 'Zic': 2}
+
+
 def construct_A(frequencies, part, tau=None, epsilon=1.0, kernel='DRT', dist_type='series', symmetry='planar',
-                bc=None, ct=False, k_ct=None, toeplitz=None):
+                bc=None, ct=False, k_ct=None, toeplitz=None, basis='gaussian'):
     f = _f64(frequencies)
     tau = _f64(1 / (2 * np.pi * f) if tau is None else tau)
     if toeplitz is None:
         toeplitz = a_is_toeplitz(f, tau, ct)
     kid = KERNEL_IDS[('DRT', None, None)] if kernel == 'DRT' else KERNEL_IDS[('DDT', bc, symmetry)]
     out = np.empty((len(f), len(tau)))
-    rc = lib().orc_build_A(_p(f), len(f), _p(tau), len(tau), C.c_double(epsilon), kid,
-                           0 if part == 'real' else 1, int(dist_type == 'series'), int(bool(ct)),
-                           C.c_double(k_ct if k_ct is not None else 0.0), int(toeplitz), _p(out))
+    rc = lib().orc_build_A_basis(_p(f), len(f), _p(tau), len(tau), C.c_double(epsilon), kid,
+                                 0 if part == 'real' else 1, int(dist_type == 'series'), int(bool(ct)),
+                                 C.c_double(k_ct if k_ct is not None else 0.0), int(toeplitz), BASIS_IDS[basis], _p(out))
     if rc != 0:
         raise Exception('First entries of first row and column are not equal')
     return out
@@ -227,6 +231,17 @@ def construct_L(tau, epsilon, order):
     tau = _f64(tau)
     out = np.empty((len(tau), len(tau)))
     lib().orc_build_L(_p(tau), len(tau), C.c_double(epsilon), _p(_order_coefs(order, 4)), _p(out))
+    return out
+
+
+def construct_L_rect(frequencies, tau, epsilon, order, basis='gaussian'):
+    """construct_L for any frequencies against any tau (matrices.py:268-325): [len(frequencies) x len(tau)]."""
+    f, tau = _f64(frequencies), _f64(tau)
+    if basis == 'Zic' and order != 0:
+        raise ValueError('the Zic basis has order 0 only (matrices.py:316-318)')
+    out = np.empty((len(f), len(tau)))
+    lib().orc_build_L_rect(_p(f), len(f), _p(tau), len(tau), C.c_double(epsilon), _p(_order_coefs(order, 4)),
+                           BASIS_IDS[basis], _p(out))
     return out
 
 

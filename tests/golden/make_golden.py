@@ -71,8 +71,21 @@ def save(name, **arrs):
 
 def read_Z(path):
     import pandas as pd
-    a = pd.read_csv(path)
-    return a['Freq'].values.astype(float), a['Zreal'].values + 1j * a['Zimag'].values
+    if path.endswith('.csv'):
+        a = pd.read_csv(path)
+        return a['Freq'].values.astype(float), a['Zreal'].values + 1j * a['Zimag'].values
+    with open(path, 'rb') as fh:
+        lines = fh.read().decode('latin-1').splitlines()
+    start = [i for i, l in enumerate(lines) if l.startswith('ZCURVE')]
+    if start:
+        # instrument export (data/experimental/PDAC_*.txt): 'ZCURVE TABLE', a header line naming the tab-separated columns,
+        # a units line, then the rows
+        cols = lines[start[0] + 1].split('\t')
+        rows = [l.split('\t') for l in lines[start[0] + 3:] if l.strip()]
+        get = lambda name: np.array([float(r[cols.index(name)]) for r in rows])
+        return get('Freq'), get('Zreal') + 1j * get('Zimag')
+    a = np.array([[float(v) for v in l.split()] for l in lines if l.strip()])      # three bare columns (DRTtools export)
+    return a[:, 0], a[:, 1] + 1j * a[:, 2]
 
 
 # ---------------------------------------------------------------------------------------- matrices
@@ -239,7 +252,10 @@ def gen_kats():
             out['info__%s__symmetry' % n] = np.array(str(info.get('symmetry', '')))
         # measured data, when the simulated file of the same name exists
         zf = os.path.join(REF, 'data/simulated/Z_%s.csv' % name)
-        exp = {'LIB_data_qtr': 'DRTtools_LIB_data_qtr.csv', 'LIB_data_qtr_DRT-TpDDT': 'DRTtools_LIB_data_qtr.csv'}
+        pdac = 'PDAC_COM3_02109_Contact10_2065C_500C.txt'                   # Run fits.ipynb cells 24, 28
+        exp = {'LIB_data_qtr': 'DRTtools_LIB_data_qtr.csv', 'LIB_data_qtr_DRT-TpDDT': 'DRTtools_LIB_data_qtr.csv',
+               'LIB_data': 'DRTtools_LIB_data.txt', 'LIB_data_DRT-TpDDT': 'DRTtools_LIB_data.txt',
+               'PDAC': pdac, 'PDAC_outliers': pdac, 'PDAC_DRT-TpDDT': pdac, 'PDAC_DRT-TpDDT_outliers': pdac}
         if name in exp:
             zf = os.path.join(REF, 'data/experimental', exp[name])
         if os.path.exists(zf):
@@ -275,6 +291,32 @@ def gen_csv():
     p = os.path.join(REF, 'code_EchemActa/bayes_results/Gout_2RC_uniform_0.25_4x1000.csv')
     g, c = csv(p)
     save('csv_2RC_uniform_0.25_4x1000', Gout_bayes=g, Gout_bayes_cols=c)
+
+
+def gen_basis():
+    """construct_A with the Cole-Cole and Zic basis functions (matrices.py:14-21; Toeplitz path on a log-uniform grid and the
+    general double loop on an irregular one, DRT and one DDT kernel), construct_L for the Zic basis (order 0, :316-318) and
+    construct_L on NON-collocated grids (any frequencies against any tau, :268-325)."""
+    out = {}
+    f_lu = np.logspace(4, -2, 25)
+    tau_sup = 1 / (2 * np.pi * np.logspace(5, -3, 33))           # log-uniform superset of 1/(2 pi f): Toeplitz path
+    rs = np.random.RandomState(11)
+    f_ir = np.sort(10 ** rs.uniform(-2, 4, 9))[::-1]
+    tau_ir = np.sort(10 ** rs.uniform(-5, 1, 7))
+    out.update(f_lu=f_lu, tau_sup=tau_sup, f_ir=f_ir, tau_ir=tau_ir)
+    for basis, eps in (('Cole-Cole', 0.8), ('Zic', 1.0)):
+        tag = basis.replace('-', '')
+        for part in ('real', 'imag'):
+            out['A_%s_toep_%s' % (tag, part)] = rm.construct_A(f_lu, part, tau=tau_sup, basis=basis, epsilon=eps)
+            out['A_%s_coll_%s' % (tag, part)] = rm.construct_A(f_lu, part, basis=basis, epsilon=eps)
+            out['A_%s_gen_%s' % (tag, part)] = rm.construct_A(f_ir, part, tau=tau_ir, basis=basis, epsilon=eps)
+            out['A_%s_ddt_%s' % (tag, part)] = rm.construct_A(f_ir, part, tau=tau_ir, basis=basis, epsilon=eps, kernel='DDT',
+                                                            dist_type='parallel', symmetry='planar', bc='transmissive')
+        out['eps_' + tag] = np.array(eps)
+    out['L_Zic_0'] = rm.construct_L(f_lu, tau=tau_sup, basis='Zic', epsilon=1.0, order=0)
+    for order, tag in ((0, '0'), (1, '1'), (2, '2'), (3, '3'), (0.5, 'h'), (1.25, 'q'), ([0.2, 0.5, 0.3], 'mix')):
+        out['L_rect_' + tag] = rm.construct_L(f_ir, tau=tau_sup, epsilon=2.5, order=order)
+    save('basis_functions', **out)
 
 
 def gen_hmc_suite():
@@ -490,6 +532,6 @@ def gen_ridge():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['matrices', 'ddt', 'dat', 'kats', 'csv', 'predict', 'host', 'ridge', 'hmc_suite']
+    which = sys.argv[1:] or ['matrices', 'ddt', 'dat', 'kats', 'csv', 'predict', 'host', 'ridge', 'hmc_suite', 'basis']
     for w in which:
         globals()['gen_' + w]()

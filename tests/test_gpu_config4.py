@@ -112,3 +112,49 @@ def test_tail_of_a_large_run_moves_to_the_one_chain_kernel(monkeypatch):
     assert np.mean(err == 0.0) > 0.2 and np.mean(err < 1e-6) > 0.9, (np.mean(err == 0.0), np.mean(err < 1e-6))
     n1, n0 = sum(x['n_leapfrog'] for x in g1), sum(x['n_leapfrog'] for x in g0)
     assert abs(n1 - n0) < 0.01 * n0
+
+
+def test_compaction_of_an_oversubscribed_run_is_bit_identical(monkeypatch):
+    """More than 16 units per CU (3 x BASELINE config 4's shard: 1536 spectra x 8 chains = 12288 units = 768 workgroups):
+    `run` re-packs the live chains into fewer full workgroups as chains finish (nuts_compact_kernel), so that the 16-column
+    MFMA tiles stay full.  Every chain continues bit for bit: draws, lp and per-chain diagnostics equal the run with the
+    layout frozen (BDRT_COMPACTION=0), and picks equal the same chains sampled alone."""
+    import bench
+    from bayes_drt_amd import _lib
+    from bayes_drt_amd.engine import Sampler
+    from bayes_drt_amd.model import Problem
+    from bayes_drt_amd.parallel import make_units
+    lib = _lib.require_gpu()
+    ns = 3 * bench.N_SPECTRA
+    kw = bench.build_problem_kwargs(ns)
+    blocks, Z, freq = kw.pop('blocks'), kw.pop('Z'), kw.pop('freq')
+    prob = Problem(blocks, Z, freq, **kw)
+    spec, chain = make_units(ns, bench.CHAINS_PER_SPECTRUM)
+    ctrl = _lib.NutsControl(); lib.bdrt_nuts_defaults(C.byref(ctrl))
+    ctrl.adapt_delta, ctrl.adapt_t0, ctrl.max_treedepth = 0.9, 10.0, 6
+    warm, nd = 24, 8                                   # chain lengths spread over a factor > 2: columns empty out early
+
+    def run(compaction):
+        monkeypatch.setenv('BDRT_COMPACTION', '1' if compaction else '0')
+        monkeypatch.setenv('BDRT_TAIL_MIGRATION', '0')          # (the hand-over to the one-chain kernel re-orders sums: own test)
+        with Sampler(prob, len(spec), warm, nd, 77, ctrl, spec=spec, chain_ids=chain) as smp:
+            assert smp.kind() == 0
+            smp.run()
+            return smp.results() + (smp.compactions(),)
+    d1, lp1, g1, nc1 = run(True)
+    d0, lp0, g0, nc0 = run(False)
+    assert nc0 == 0 and nc1 >= 2, (nc0, nc1)
+    assert np.all(np.isfinite(d1)) and np.array_equal(d1, d0) and np.array_equal(lp1, lp0)
+    assert [x['n_leapfrog'] for x in g1] == [x['n_leapfrog'] for x in g0]
+    assert [x['stepsize'] for x in g1] == [x['stepsize'] for x in g0]
+    lens = np.array([x['n_leapfrog'] for x in g1])
+    assert lens.max() > 1.5 * np.median(lens)
+    # and the slot a chain runs in never mattered: three of them alone
+    pick = [5, 6001, 12287]
+    monkeypatch.setenv('BDRT_SOLO', '0')                        # (three chains would otherwise take the one-chain kernel)
+    with Sampler(prob, 3, warm, nd, 77, ctrl, spec=spec[pick], chain_ids=chain[pick]) as smp:
+        assert smp.kind() == 0
+        smp.run()
+        da, lpa, _ = smp.results()
+    assert np.array_equal(da, d1[pick]) and np.array_equal(lpa, lp1[pick])
+    prob.close()

@@ -196,25 +196,52 @@ def test_map_gpu_vs_oracle(tag):
     assert rep[0]['lp'] > rep3[0]['lp']
 
 
-@pytest.mark.parametrize('name', ['RC-ZARC_uniform_0.25', 'RC-ZARC_noiseless', 'RC-ZARC_Macdonald_1.0'])
+def _usable_kats():
+    from tests.helpers import kat_names, kat_to_model
+    out = []
+    for n in kat_names():
+        k = kat_to_model(n)
+        if k is not None and k['has_Z']:
+            out.append(n)
+    return out
+
+
+# distance between the stored coefficients (an L-BFGS iterate that stopped by a tolerance test) and the
+# stationary point reached from them, per model family: measured maxima (profiles/r03/map_kats.txt) with head-room.  The
+# sign-free `Series` fits of the truncated spectra sit in long flat valleys (stored gradient max-norm up to 10): there the
+# iterate is far from the optimum in coefficient space while both reproduce the spectrum.
+_COEF_BOUND = {'Series_pos': 0.75, 'Series-Parallel_pos': 1.0, 'Series-2Parallel_pos': 0.4, 'Series': 4.6,
+               'Series_outliers': 4.6, 'Series-Parallel_pos_outliers': 1.0}
+
+
+@pytest.mark.parametrize('name', _usable_kats())
 def test_map_vs_reference_stored_fit(name):
-    """Against the reference's own stored Stan MAP (map_results/obj_*.pkl): our MAP started from the stored point
-    has a log-posterior at least as high, evaluated with the same density (SURVEY H1 ladder (c)); the gamma
-    difference is reported, not asserted to 1e-4 (the stored point is an un-converged L-BFGS iterate)."""
+    """Against EVERY usable stored Stan MAP of the reference (code_EchemActa/map_results/obj_*.pkl, 36 of 37; all model families
+    incl. Series-Parallel_pos_outliers): started from the stored point, our MAP reaches a log-posterior at least as high,
+    evaluated with the same density (SURVEY H1 ladder (c)); the impedance it predicts stays on the stored one; the distance in
+    coefficient space is reported and bounded per family, not asserted to 1e-4 (the stored point is an un-converged iterate)."""
     from bayes_drt_amd.model import Problem
     from bayes_drt_amd.engine import optimize_batch
     from tests.helpers import kat_to_model
     k = kat_to_model(name)
     prob = Problem(**k['kw'])
+    lay = prob.layout()
     th_ref = prob.unconstrain(k['params'])
     lp_ref, g_ref = prob.logp_grad(th_ref[None], jacobian=False)
     out, rep = optimize_batch(prob, th_ref[None])
-    assert rep[0]['lp'] >= lp_ref[0] - 1e-9
-    K = prob.Ks[0]
-    d = rel_l2(np.exp(out[0][2:2 + K]), k['params'][2:2 + K])
-    print('%s: lp_ref %.4f lp_map %.4f coef rel-L2 %.3e |g_ref|inf %.3e' % (name, lp_ref[0], rep[0]['lp'], d,
-                                                                             np.max(np.abs(g_ref))))
-    assert d < 0.2
+    assert rep[0]['lp'] >= lp_ref[0] - 1e-9 * max(1.0, abs(lp_ref[0]))
+    assert rep[0]['return_code'] in (0, 2), rep[0]             # 2: the optimum presses against the x_sum >= 0 wall (DESIGN 8)
+    con = prob.constrain(out)
+
+    def coef(p):
+        return np.concatenate([p[lay['x'][b]:lay['x'][b] + K] for b, K in enumerate(prob.Ks)])
+    d = rel_l2(coef(con[0]), coef(k['params']))
+    _, Zh, _ = prob.transformed(out)
+    dz = rel_l2(Zh[0], k['opt']['Z_hat'])
+    print('%s [%s]: lp stored %.4f -> %.4f, |g stored|inf %.3e, coef rel-L2 %.3e, Z_hat rel-L2 %.3e, rc %d'
+          % (name, k['family'], lp_ref[0], rep[0]['lp'], np.max(np.abs(g_ref)), d, dz, rep[0]['return_code']))
+    assert d < _COEF_BOUND[k['family']], (k['family'], d)
+    assert dz < 0.05, dz
 
 
 def test_batched_optimize_equals_single_fits():

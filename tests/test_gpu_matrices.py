@@ -92,4 +92,40 @@ def test_bad_arguments():
     with pytest.raises(ValueError):
         gm.construct_A(f, 'real', kernel='DDT', bc='blocking', symmetry='planar', dist_type='parallel', ct=True)
     with pytest.raises(ValueError):
-        gm.construct_A(f, 'real', basis='Zic')
+        gm.construct_A(f, 'real', basis='lorentzian')
+    with pytest.raises(ValueError):
+        gm.construct_L(f, basis='Cole-Cole')              # the reference defines no derivative for it (matrices.py:316-318)
+    with pytest.raises(ValueError):
+        gm.construct_L(f, basis='Zic', order=1)
+
+
+@pytest.mark.parametrize('basis', ['Cole-Cole', 'Zic'])
+def test_other_basis_functions_vs_golden(basis):
+    """the Cole-Cole and Zic basis functions of get_basis_func (matrices.py:14-21) through construct_A on
+    the GPU, against the reference's own outputs: Toeplitz path, collocated default tau, general path, a DDT kernel."""
+    from bayes_drt_amd import matrices as gm
+    d = load('basis_functions')
+    tag = basis.replace('-', '')
+    eps = float(d['eps_' + tag])
+    for part in ('real', 'imag'):
+        for got, key in ((gm.construct_A(d['f_lu'], part, tau=d['tau_sup'], epsilon=eps, basis=basis), 'toep'),
+                         (gm.construct_A(d['f_lu'], part, epsilon=eps, basis=basis), 'coll'),
+                         (gm.construct_A(d['f_ir'], part, tau=d['tau_ir'], epsilon=eps, basis=basis), 'gen'),
+                         (gm.construct_A(d['f_ir'], part, tau=d['tau_ir'], epsilon=eps, basis=basis, kernel='DDT',
+                                         dist_type='parallel', symmetry='planar', bc='transmissive'), 'ddt')):
+            want = d['A_%s_%s_%s' % (tag, key, part)]
+            assert got.shape == want.shape
+            assert np.max(np.abs(got - want)) <= 1e-11 * np.max(np.abs(want)), (basis, part, key)
+
+
+def test_construct_L_non_collocated_and_zic_vs_golden():
+    """construct_L for any frequencies against any tau (matrices.py:268-325): [Nf x K], all orders; Zic order 0."""
+    from bayes_drt_amd import matrices as gm
+    d = load('basis_functions')
+    for order, tag in ((0, '0'), (1, '1'), (2, '2'), (3, '3'), (0.5, 'h'), (1.25, 'q'), ([0.2, 0.5, 0.3], 'mix')):
+        got = gm.construct_L(d['f_ir'], tau=d['tau_sup'], epsilon=2.5, order=order)
+        want = d['L_rect_' + tag]
+        assert got.shape == want.shape == (9, 33)
+        assert np.max(np.abs(got - want)) <= 1e-11 * np.max(np.abs(want)), tag
+    got = gm.construct_L(d['f_lu'], tau=d['tau_sup'], basis='Zic', epsilon=1.0, order=0)
+    assert np.max(np.abs(got - d['L_Zic_0'])) <= 1e-11 * np.max(np.abs(d['L_Zic_0']))

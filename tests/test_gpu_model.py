@@ -12,6 +12,13 @@ from tests.helpers import kat_names, kat_to_model, load
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _tile_evaluators(monkeypatch):
+    """These tests pin the 16-column tile evaluators.  Batches of up to one point per CU would otherwise take the
+    one-workgroup-per-point evaluators (launch_logp_grad_few), which have their own tests below and in test_gpu_solo*.py."""
+    monkeypatch.setenv('BDRT_FEW_POINTS', '0')
+
+
 def _mods():
     from bayes_drt_amd.model import Problem
     from oracle import oracle as orc
@@ -239,3 +246,41 @@ def test_general_half_wave_tile_equals_generic_tile(monkeypatch, name):
         assert np.max(np.abs(a[fin] - b[fin])) <= 1e-12 * max(1.0, np.max(np.abs(b[fin])))
     if 'PDAC' not in name:                       # (the experimental PDAC grid is not log-uniform: generic evaluator either way)
         assert not np.array_equal(g_f, g_g)      # really two different code paths
+
+
+@pytest.mark.parametrize('B', [1, 4, 100, 256, 257])
+def test_few_points_take_the_one_workgroup_evaluator_headline_family(monkeypatch, B):
+    """bdrt_logp_grad with up to one point per CU: one workgroup per point with Toeplitz products (24 us -> ~7 us at B = 1);
+    B = 257 is back on the tiles.  Against the oracle, and against the tile evaluator on the same points."""
+    Problem, orc = _mods()
+    d, blk, kw = _bench_blocks('sample')
+    prob = Problem([blk], d['Z'], d['freq'], **kw)
+    om = orc.OracleModel([blk], d['Z'], d['freq'], **kw)
+    thetas = np.random.default_rng(100 + B).uniform(-2, 2, (B, prob.D))
+    monkeypatch.setenv('BDRT_FEW_POINTS', '1')
+    lp1, g1 = prob.logp_grad(thetas, jacobian=True)
+    for i in (0, B // 2, B - 1):
+        lp_ref, g_ref = om.logp_grad(thetas[i], jacobian=True)
+        assert abs(lp1[i] - lp_ref) <= 1e-10 * max(1.0, abs(lp_ref))
+        assert np.max(np.abs(g1[i] - g_ref)) <= 1e-10 * max(1.0, np.max(np.abs(g_ref)))
+    monkeypatch.setenv('BDRT_FEW_POINTS', '0')
+    lp0, g0 = prob.logp_grad(thetas, jacobian=True)
+    assert np.max(np.abs(lp1 - lp0)) <= 1e-11 * np.max(np.abs(lp0))
+    assert np.max(np.abs(g1 - g0)) <= 1e-10 * np.max(np.abs(g0))
+    if B <= 256:
+        assert not np.array_equal(g1, g0)          # really another kernel: same numbers in another summation order
+    else:
+        assert np.array_equal(g1, g0) and np.array_equal(lp1, lp0)
+
+
+@pytest.mark.parametrize('name', ['DRT-2-TpDDT_uniform_0.25', 'DRT-TpDDT-BpDDT_uniform_0.25'])
+def test_few_points_general_block_models(monkeypatch, name):
+    Problem, orc = _mods()
+    k = kat_to_model(name)
+    prob = Problem(**k['kw'])
+    om = orc.OracleModel(**k['kw'])
+    th0 = prob.unconstrain(k['params'])
+    thetas = th0[None] + 0.05 * np.random.default_rng(3).standard_normal((6, prob.D))
+    monkeypatch.setenv('BDRT_FEW_POINTS', '1')
+    _compare(prob, om, thetas, True)
+    _compare(prob, om, thetas, False)

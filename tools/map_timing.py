@@ -1,5 +1,5 @@
 """MAP timing on the GPU box: Inverter.fit(mode='optimize') on the reference's 2-ZARC spectrum at K = 81 / 101 / 161
-(L-BFGS 1000 iterations + device Newton polish), and the Stan-style iterate (algorithm='LBFGS', no polish) beside it, both
+(device-resident Newton iteration, two starts in one batch), and the Stan-style iterate (algorithm='LBFGS', no polish) beside it, both
 against the reference's committed MAP curve (map_results/Gout_2ZARC_uniform_0.25.csv)."""
 import os, sys, time, warnings
 import numpy as np

@@ -17,8 +17,13 @@ L = [gm.construct_L(bf, tau=tau, epsilon=eps, order=o) for o in (0, 1, 2)]
 prob = Problem([dict(A=A, L0=L[0], L1=L[1], L2=0.75 * L[2], nonneg=True)], Z, f, ups_alpha=1.0, ups_beta=0.1)
 spec = np.repeat(np.arange(ns, dtype=np.int32), nc)
 cid = np.tile(np.arange(nc, dtype=np.int32), ns)
+from bayes_drt_amd.engine import Sampler
 t0 = time.time()
-draws, lp, diag = sample_units(prob, ns * nc, warm, nd, 2026, None, spec=spec, chain_ids=cid)
+with Sampler(prob, ns * nc, warm, nd, 2026, None, spec=spec, chain_ids=cid) as smp:
+    smp.run()
+    draws, lp, diag = smp.results()
+    print('layout: %d re-packings of the 16-chain workgroups (compaction), %d chains handed to the one-chain kernel for the tail'
+          % (smp.compactions(), smp.tail_units()))
 t1 = time.time()
 nl = sum(d['n_leapfrog'] for d in diag)
 per = np.sort(np.array([d['n_leapfrog'] for d in diag], dtype=float))

@@ -5,6 +5,7 @@ import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ['BDRT_SOLO'] = '1'
+os.environ['BDRT_VERBOSE'] = '1'
 from bayes_drt_amd import _lib, matrices as gm
 from bayes_drt_amd.engine import Sampler
 from bayes_drt_amd.model import Problem
@@ -29,7 +30,8 @@ for nf, K in ((41, 41), (41, 61), (81, 81), (81, 121), (81, 161)):
             s = Sampler(prob, n, 1000000, 1, 7)
         except Exception as e:
             print(nf, K, n, 'refused:', e); continue
-        assert s.kind() == 1
+        if s.kind() != 1:
+            print(nf, K, n, 'kernel kind', s.kind(), '(not the one-chain kernel)'); s.close(); break
         s.advance(400); s.sync()
         n0 = s.total_leapfrogs(); s.kernel_time(reset=True)
         t0 = time.perf_counter()
