@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     double *hvk = lpn + NC;             // wide-vector path: [NC][2] results of a chain's own pass handed to the cooperative phase
     ChainState *sts = reinterpret_cast<ChainState *>(hvk + 2 * NC);
     int *spec = reinterpret_cast<int *>(sts + NC);
-    volatile int *slow = spec + NC;     // set by a chain that is about to do something long this round (see stage Z)
+    volatile int *slow = spec + NC;     // round stamp (round + 1) of the last round in which some chain did something long (see stage Z)
     int *thoff = spec + NC + 4;         // wide-vector path: offset of each chain's live theta row (0 or V_TH2 - V_TH rows)
     int *hvy = thoff + NC;              // wide-vector path: chains that the cooperative phase finishes (bdrt_nuts_wide.h)
     constexpr bool SPEC = NJ > 16 || (NJ > 11 && MODE < 2);      // wide-vector path (the S1 evaluator leaves room for 16 elements per lane)
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         else { memset(&sts[tid], 0, sizeof(ChainState)); sts[tid].phase = PH_DONE; }
         spec[tid] = u >= 0 ? sts[tid].spec : 0;
         thoff[tid] = (SPEC && sts[tid].thsel) ? TH2OFF : 0;
+        if (tid == 0) *slow = 0;
     }
     __syncthreads();
     ChainState &s = sts[c];
@@ -173,17 +174,25 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         TH = thr;                                           // every later theta access of this launch is an LDS access
         G = s1_grad_row(P, smem, c);                        // where the tile leaves d lp / d theta
     }
-    // one barrier per round boundary that also votes on whether any chain of the workgroup is still running
+    // Is any chain of the workgroup still running?  Voted at a barrier per round boundary -- except on the fast path (MODE 2),
+    // where between the end of the backward GEMM of one round and the first barrier of the next evaluation a wave touches only
+    // its own chains' LDS (theta / gradient rows, its columns of the operand tile): there the round boundary has NO barrier.
+    // Each chain leaves an activity flag, every thread reads the 16 flags right after the evaluator's first barrier, and a wave
+    // that finishes its bookkeeping early goes on with the next point's exponentials while another one still closes a subtree.
+    // (The verdict is one round late: a workgroup whose last chain has just finished runs one idle round.)
+    constexpr bool FREE_RUN = MODE == 2 && !SPEC;
+    int *actf = hvy;                    // (the wide-vector path's `hvy` slots are free on this path)
     int any_act;
     {
         const int ph = s.phase;
-        any_act = __syncthreads_or(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE);
+        const bool running = ph == PH_INIT || ph == PH_EPS || ph == PH_TREE;
+        if (FREE_RUN && l32 == 0) actf[c] = running ? 1 : 0;
+        any_act = __syncthreads_or(running);
     }
 
     for (int round = 0; round < a.rounds; ++round) {
         // keep per-lane address arithmetic inside the loop (see the note in bdrt_tile_s1.h): hoisted, it is spilled
         __asm__ volatile("" : "+v"(c), "+v"(l32));
-        if (tid == 0) *slow = 0;
         if (SPEC && tid < NC) hvy[tid] = 0;
         const int ph0 = s.phase;
         const bool act = ph0 == PH_INIT || ph0 == PH_EPS || ph0 == PH_TREE;
@@ -210,7 +219,32 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 }
             }
         };
-        if (MODE == 2) { logp_grad_tile_s1<true>(P, io, smem); load_state(); }
+        int any_next = 0;
+        if (MODE == 2) {
+            auto read_flags = [&]() {
+                if constexpr (FREE_RUN) {
+                    typedef int iv4 __attribute__((ext_vector_type(4)));
+                    typedef const __attribute__((address_space(3))) iv4 *lds_i4;
+                    int v = 0;
+#pragma unroll
+                    for (int q = 0; q < NC / 4; ++q) { const iv4 f = ((lds_i4)actf)[q]; v |= f.x | f.y | f.z | f.w; }
+                    any_next = v;
+                }
+            };
+            // the uniform that decides whether this leaf becomes the subtree's proposal depends on (leaf, depth, iteration)
+            // only: drawn right before the backward GEMM -- ~250 integer instructions that issue beside the other wave's
+            // MFMAs -- instead of in the serial stretch between two evaluations; handed over through the chain's `hvk` slot
+            auto draw_leaf_uniform = [&]() {
+                if constexpr (FREE_RUN) {
+                    if (act && ph0 == PH_TREE) {
+                        const double u = rng_uniform(rng, (uint32_t)s.leaf, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
+                        if (l32 == 0) hvk[2 * c] = u;
+                    }
+                }
+            };
+            logp_grad_tile_s1<true, 32, decltype(draw_leaf_uniform), decltype(read_flags)>(P, io, smem, draw_leaf_uniform, read_flags);
+            load_state();
+        }
         else if (MODE == 3) { logp_grad_tile_s1<false>(P, io, smem); load_state(); }
         else if (MODE == 4) { logp_grad_tile_hw(P, io, smem); load_state(); }
         else { logp_grad_tile<MODE == 1>(P, io, smem); load_state(); }
@@ -480,8 +514,9 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 next = nuts_stepsize_trial(s, np, lp, kin);
             } else {   // PH_TREE: one new leaf
                 if (l32 == 0) my_leaps += 1;
-                nuts_tree_leaf(s, np, rng, lp, kin, leaf_now, copyq, tree, nm, last, endt);      // (bdrt_nuts_device.h)
-                if (last) *slow = 1;                                // closing a subtree (and maybe the transition): a long round
+                const double u_leaf = FREE_RUN ? hvk[2 * c] : 0.0;
+                nuts_tree_leaf(s, np, rng, lp, kin, leaf_now, copyq, tree, nm, last, endt, FREE_RUN ? &u_leaf : nullptr);      // (bdrt_nuts_device.h)
+                if (last) *slow = round + 1;                        // closing a subtree (and maybe the transition): a long round
             }
         }
         BDRT_NUTS_PROF(12);
@@ -638,7 +673,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         {
             const bool heavy = !act || ph0 != PH_TREE || last || endt != 0 || next != 0;
             const bool wave_heavy = __builtin_amdgcn_ballot_w64(heavy) != 0;
-            if (!wave_heavy && *slow && s.z_iter != s.iter + 1) {
+            if (!wave_heavy && *slow == round + 1 && s.z_iter != s.iter + 1) {
                 double *ZN = row(V_ZN);
                 const uint32_t it1 = (uint32_t)(s.iter + 1);
 #pragma unroll
@@ -808,7 +843,13 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         if (io.prof && lane == 0 && next) atomicAdd((unsigned long long *)&io.prof[24], 1ull);
         {
             const int ph = s.phase;
-            any_act = __syncthreads_or(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE);
+            const bool running = ph == PH_INIT || ph == PH_EPS || ph == PH_TREE;
+            if constexpr (FREE_RUN) {
+                if (l32 == 0) actf[c] = running ? 1 : 0;
+                any_act = any_next;                         // (the same 16 flags were read by every thread after this round's first barrier)
+            } else {
+                any_act = __syncthreads_or(running);
+            }
         }
         BDRT_WAVE_PROF(23);
         BDRT_NUTS_PROF(10);
@@ -1324,6 +1365,13 @@ __global__ __launch_bounds__(256) void nuts_compact_kernel(const double *vold, c
     }
 }
 
+// liveness of every unit (1: the chain is still running), for the host's re-packing decision
+__global__ void nuts_live_kernel(const ChainState *states, int n, int *live)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < n) { const int ph = states[u].phase; live[u] = (ph == PH_INIT || ph == PH_EPS || ph == PH_TREE) ? 1 : 0; }
+}
+
 struct Sampler {
     Problem *prob = nullptr;
     NutsParams np;
@@ -1359,6 +1407,9 @@ struct Sampler {
     std::vector<int> unit_loc;        // unit -> wg * 16 + slot (-1: retired: the chain had finished when its workgroup was re-packed)
     int *d_slot_unit = nullptr, *d_unit_loc = nullptr;
     size_t vecs_capacity = 0;         // doubles allocated behind args.vecs
+    double *vecs_alt = nullptr;       // second buffer of the same size: re-packing ping-pongs between the two (no allocation,
+    int *d_slot_alt = nullptr;        //  hence no implicit device synchronisation, per pass)
+    int *d_live = nullptr;
     bool may_compact = false;
     int n_compactions = 0;
 };
@@ -1453,6 +1504,9 @@ void bdrt_sampler_destroy(bdrt_sampler *s)
     if (S.d_unit_map) hipFree(S.d_unit_map);
     if (S.d_slot_unit) hipFree(S.d_slot_unit);
     if (S.d_unit_loc) hipFree(S.d_unit_loc);
+    if (S.vecs_alt) hipFree(S.vecs_alt);
+    if (S.d_slot_alt) hipFree(S.d_slot_alt);
+    if (S.d_live) hipFree(S.d_live);
     if (S.stream) hipStreamDestroy(S.stream);
     delete s;
 }
@@ -1748,14 +1802,24 @@ static int maybe_compact(Sampler &S, int active)
 {
     if (!S.may_compact || S.migrated || S.solo || S.wide1 || active <= 0) return 0;
     const int target = std::max(S.n_cu, (active + NC - 1) / NC);
-    // at least a quarter of the columns empty, and at least 1/8 fewer workgroups afterwards
-    if ((long long)active * 4 > (long long)S.n_wg * NC * 3 || (long long)target * 8 > (long long)S.n_wg * 7) return 0;
-    std::vector<ChainState> hs((size_t)S.n_units);
-    BDRT_HIP(hipMemcpy(hs.data(), S.args.states, hs.size() * sizeof(ChainState), hipMemcpyDeviceToHost));
+    // worth a pass as soon as 1/16 of the workgroups can go: re-laying ~100 KB per live chain costs about a millisecond per
+    // 10^4 chains, one launch of 256 rounds on the workgroups saved several
+    if ((long long)target * 16 > (long long)S.n_wg * 15) return 0;
+    if (!S.vecs_alt) {
+        // the second buffer and the liveness flags, once (keep going as is when the memory is not there)
+        if (hipMalloc((void **)&S.vecs_alt, S.vecs_capacity * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); S.vecs_alt = nullptr; S.may_compact = false; return 0; }
+        if (hipMalloc((void **)&S.d_slot_alt, S.slot_unit.size() * sizeof(int)) != hipSuccess ||
+            hipMalloc((void **)&S.d_live, (size_t)S.n_units * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); S.may_compact = false; return 0; }
+    }
+    std::vector<int> alive((size_t)S.n_units);
+    hipLaunchKernelGGL(nuts_live_kernel, dim3((S.n_units + 255) / 256), dim3(256), 0, S.stream, (const ChainState *)S.args.states, S.n_units, S.d_live);
+    BDRT_HIP(hipGetLastError());
+    BDRT_HIP(hipMemcpyAsync(alive.data(), S.d_live, alive.size() * sizeof(int), hipMemcpyDeviceToHost, S.stream));
+    BDRT_HIP(hipStreamSynchronize(S.stream));
     std::vector<int> live;
     for (int wgk = 0; wgk < (int)S.slot_unit.size(); ++wgk) {            // slot order: keeps neighbours (same spectrum) together
         const int u = S.slot_unit[wgk];
-        if (u >= 0 && (hs[u].phase == PH_INIT || hs[u].phase == PH_EPS || hs[u].phase == PH_TREE)) live.push_back(u);
+        if (u >= 0 && alive[u]) live.push_back(u);
     }
     if (live.empty()) return 0;
     const int n_wg = std::max(std::min(S.n_cu, (int)live.size()), ((int)live.size() + NC - 1) / NC);
@@ -1766,23 +1830,16 @@ static int maybe_compact(Sampler &S, int active)
         slot_unit[(size_t)wg * NC + k] = live[i];
         unit_loc[live[i]] = wg * NC + k;
     }
-    const size_t nvec = (size_t)n_wg * V_COUNT * NC * S.args.ds;
-    DevTmp vnew, dslot;
-    if (hipMalloc(&vnew.p, nvec * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return 0; }      // (keep going as is)
-    if (hipMalloc(&dslot.p, slot_unit.size() * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    BDRT_HIP(hipMemcpyAsync(dslot.p, slot_unit.data(), slot_unit.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
+    BDRT_HIP(hipMemcpyAsync(S.d_slot_alt, slot_unit.data(), slot_unit.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
     // d_unit_loc still holds the OLD locations: the kernel reads them, then they are replaced
     hipLaunchKernelGGL(nuts_compact_kernel, dim3(n_wg), dim3(256), 0, S.stream, (const double *)S.args.vecs, (const int *)S.d_unit_loc,
-                       (const int *)dslot.p, (double *)vnew.p, S.args.ds);
+                       (const int *)S.d_slot_alt, S.vecs_alt, S.args.ds);
     BDRT_HIP(hipGetLastError());
     BDRT_HIP(hipMemcpyAsync(S.d_unit_loc, unit_loc.data(), unit_loc.size() * sizeof(int), hipMemcpyHostToDevice, S.stream));
-    BDRT_HIP(hipStreamSynchronize(S.stream));
-    hipFree(S.args.vecs);
-    hipFree(S.d_slot_unit);
-    S.args.vecs = (double *)vnew.release();
-    S.d_slot_unit = (int *)dslot.release();
+    BDRT_HIP(hipStreamSynchronize(S.stream));            // (the host vectors above are read by the asynchronous copies)
+    std::swap(S.args.vecs, S.vecs_alt);
+    std::swap(S.d_slot_unit, S.d_slot_alt);
     S.args.slot_unit = S.d_slot_unit;
-    S.vecs_capacity = nvec;
     S.slot_unit.swap(slot_unit);
     S.unit_loc.swap(unit_loc);
     S.n_wg = n_wg;

@@ -170,8 +170,11 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // `before_backward` runs right before the backward GEMM (the last ~10 k cycles of the evaluation): the sampler uses it to
 // issue the global loads of the state it needs next, so that their latency hides behind the MFMA work.
-template <bool LDSIO, int LPC = 32, class Hook = NoHook>
-__device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, double *smem, Hook before_backward = Hook())
+// `after_x_ready` runs right after the first barrier (X of all 16 chains published): the sampler reads the chains' activity
+// flags there -- every wave has finished its previous round by then -- instead of voting at a barrier of its own.
+template <bool LDSIO, int LPC = 32, class Hook = NoHook, class Hook1 = NoHook>
+__device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, double *smem, Hook before_backward = Hook(),
+                                         Hook1 after_x_ready = Hook1())
 {
     int tid = threadIdx.x;
     // Opaque to the optimiser: inside the sampler's round loop everything derived from the thread index is loop invariant,
@@ -260,6 +263,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     else if (l32 < 9) lp += -6.0 * st - 5.0 / sraw + jac * st;
     BDRT_S1_TRACE(1);
     __syncthreads();                                                   // B1: X of all 16 chains in the operand tile
+    after_x_ready();
     BDRT_S1_TRACE(2);
     BDRT_S1_PROF(1);
     // MFMA part, then the VALU part of this phase (the prior chain does not depend on A x, so no barrier in between).

@@ -193,8 +193,8 @@ int bdrt_sampler_results(bdrt_sampler *s, double *draws_unconstrained, double *l
  * live chains to the one-chain-per-workgroup kernel once that finishes them sooner (BDRT_TAIL_MIGRATION=0 forbids it);
  * bdrt_sampler_tail_units tells how many chains were handed over (0: none). */
 int bdrt_sampler_tail_units(bdrt_sampler *s);
-/* A run with more than 16 units per CU re-packs its live chains into fewer 16-chain workgroups whenever a quarter of the tile
- * columns has fallen empty (finished chains), so that the MFMA tiles stay full until fewer than 16 live chains per CU are left;
+/* A run with more than 16 units per CU re-packs its live chains into fewer 16-chain workgroups whenever 1/16 of the
+ * workgroups can be dropped (finished chains), so that the MFMA tiles stay full until fewer than 16 live chains per CU are left;
  * the chains continue bit for bit.  Number of such re-packings so far (BDRT_COMPACTION=0 disables them). */
 int bdrt_sampler_compactions(bdrt_sampler *s);
 /* which kernel advances the chains now: 0 sixteen chains per workgroup (bdrt_nuts.hip), 1 one chain per workgroup with its

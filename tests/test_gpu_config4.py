@@ -151,7 +151,8 @@ def test_compaction_of_an_oversubscribed_run_is_bit_identical(monkeypatch):
     assert lens.max() > 1.5 * np.median(lens)
     # and the slot a chain runs in never mattered: three of them alone
     pick = [5, 6001, 12287]
-    monkeypatch.setenv('BDRT_SOLO', '0')                        # (three chains would otherwise take the one-chain kernel)
+    monkeypatch.setenv('BDRT_SOLO', '0')                        # (three chains would otherwise take a one-chain kernel)
+    monkeypatch.setenv('BDRT_WIDE1', '0')
     with Sampler(prob, 3, warm, nd, 77, ctrl, spec=spec[pick], chain_ids=chain[pick]) as smp:
         assert smp.kind() == 0
         smp.run()
