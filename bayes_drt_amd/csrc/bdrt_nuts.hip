@@ -231,18 +231,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     any_next = v;
                 }
             };
-            // the uniform that decides whether this leaf becomes the subtree's proposal depends on (leaf, depth, iteration)
-            // only: drawn right before the backward GEMM -- ~250 integer instructions that issue beside the other wave's
-            // MFMAs -- instead of in the serial stretch between two evaluations; handed over through the chain's `hvk` slot
-            auto draw_leaf_uniform = [&]() {
-                if constexpr (FREE_RUN) {
-                    if (act && ph0 == PH_TREE) {
-                        const double u = rng_uniform(rng, (uint32_t)s.leaf, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
-                        if (l32 == 0) hvk[2 * c] = u;
-                    }
-                }
-            };
-            logp_grad_tile_s1<true, 32, decltype(draw_leaf_uniform), decltype(read_flags)>(P, io, smem, draw_leaf_uniform, read_flags);
+            logp_grad_tile_s1<true, 32, NoHook, decltype(read_flags)>(P, io, smem, NoHook(), read_flags);
             load_state();
         }
         else if (MODE == 3) { logp_grad_tile_s1<false>(P, io, smem); load_state(); }
@@ -267,7 +256,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             constexpr int MB = NJ % 8 == 0 ? 8 : 9;
             static_assert(NJ % MB == 0, "chunk size must divide NJ");
             constexpr int NS2 = (32 * NJ + 63) / 64;            // 64-element slices of a row
-            constexpr int LMAX = 4;                             // merge levels a chain's own pass can take
+            constexpr int LMAX = 6;                             // merge levels a chain's own pass can take (1 leaf in 128 closes more)
             typedef double dv2 __attribute__((ext_vector_type(2)));
             auto ld2 = [](const double *q) -> dv2 { return *reinterpret_cast<const dv2 *>(q); };
             auto st2 = [](double *q, dv2 v) { *reinterpret_cast<dv2 *>(q) = v; };
@@ -361,8 +350,9 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     };
                     {
                         const bool w1 = __builtin_amdgcn_ballot_w64(nmf > 0) != 0, w2 = __builtin_amdgcn_ballot_w64(nmf > 1) != 0,
-                                   w3 = __builtin_amdgcn_ballot_w64(nmf > 2) != 0;
-                        if (w3) pass(std::integral_constant<int, LMAX>{}, std::integral_constant<int, 2>{});
+                                   w3 = __builtin_amdgcn_ballot_w64(nmf > 2) != 0, w5 = __builtin_amdgcn_ballot_w64(nmf > 4) != 0;
+                        if (w5) pass(std::integral_constant<int, LMAX>{}, std::integral_constant<int, 1>{});
+                        else if (w3) pass(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
                         else if (w2) pass(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
                         else if (w1) pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
                         else pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
@@ -514,8 +504,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 next = nuts_stepsize_trial(s, np, lp, kin);
             } else {   // PH_TREE: one new leaf
                 if (l32 == 0) my_leaps += 1;
-                const double u_leaf = FREE_RUN ? hvk[2 * c] : 0.0;
-                nuts_tree_leaf(s, np, rng, lp, kin, leaf_now, copyq, tree, nm, last, endt, FREE_RUN ? &u_leaf : nullptr);      // (bdrt_nuts_device.h)
+                nuts_tree_leaf(s, np, rng, lp, kin, leaf_now, copyq, tree, nm, last, endt);      // (bdrt_nuts_device.h)
                 if (last) *slow = round + 1;                        // closing a subtree (and maybe the transition): a long round
             }
         }
@@ -1802,9 +1791,11 @@ static int maybe_compact(Sampler &S, int active)
 {
     if (!S.may_compact || S.migrated || S.solo || S.wide1 || active <= 0) return 0;
     const int target = std::max(S.n_cu, (active + NC - 1) / NC);
-    // worth a pass as soon as 1/16 of the workgroups can go: re-laying ~100 KB per live chain costs about a millisecond per
-    // 10^4 chains, one launch of 256 rounds on the workgroups saved several
-    if ((long long)target * 16 > (long long)S.n_wg * 15) return 0;
+    // A launch runs its workgroups in turns of one per CU, and every turn lasts the full `rounds` however many CUs it fills:
+    // what a re-packing buys is a whole turn, so it is done when -- and only when -- the live chains fit in one turn less
+    // (measured on 1536 spectra x 8 chains: re-packing at every 1/16 of the workgroups, 15 passes, 32.7 s; at the turn
+    // boundaries 8192 and 4096 live chains ... see profiles/r03/oversubscribed.txt; frozen layout 36.6 s)
+    if ((target + S.n_cu - 1) / S.n_cu >= (S.n_wg + S.n_cu - 1) / S.n_cu) return 0;
     if (!S.vecs_alt) {
         // the second buffer and the liveness flags, once (keep going as is when the memory is not there)
         if (hipMalloc((void **)&S.vecs_alt, S.vecs_capacity * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); S.vecs_alt = nullptr; S.may_compact = false; return 0; }

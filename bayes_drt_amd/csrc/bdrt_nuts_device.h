@@ -216,11 +216,9 @@ __host__ __device__ inline int nuts_stepsize_trial(S &s, const NutsParams &np, d
 // divergence test, acceptance statistic, and the uniform sampling inside the subtree (keep leaf i with probability
 // w_i / W_i).  Outputs: endt = 2 on divergence; otherwise tree = true, copyq (this leaf becomes the subtree's proposal),
 // nm (trailing one bits of the leaf index = sub-subtrees that end here), last (the subtree is complete).
-// u_pre: the leaf's uniform when the caller has drawn it ahead of time (it depends on (leaf, depth, iteration) only: the
-// 16-chain kernel's fast path draws it in the shadow of the backward GEMM), nullptr: drawn here.
 template <class S>
 __host__ __device__ inline void nuts_tree_leaf(S &s, const NutsParams &np, const Philox &rng, double lp, double kin, int leaf_now,
-                                               bool &copyq, bool &tree, int &nm, bool &last, int &endt, const double *u_pre = nullptr)
+                                               bool &copyq, bool &tree, int &nm, bool &last, int &endt)
 {
     s.n_leap_iter = s.n_leap_iter + 1;
     double h = -lp + kin;
@@ -234,7 +232,7 @@ __host__ __device__ inline void nuts_tree_leaf(S &s, const NutsParams &np, const
         return;
     }
     const double lsw_new = log_sum_exp2(s.lsw_sub, w);
-    const double u = u_pre ? *u_pre : rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
+    const double u = rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
     if (leaf_now == 0 || u < exp(w - lsw_new)) { copyq = true; s.lpq = lp; }
     s.lsw_sub = lsw_new;
     tree = true;

@@ -27,6 +27,7 @@ import json
 import os
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -398,22 +399,6 @@ def main():
         s4.close()
         p1.close()
 
-    # ---- N > 1: one complete sample_sharded call (broadcast + short run + summary gather), timed apart from the rate ----
-    roundtrip = None
-    if use_dist:
-        small = dict(kw, Z=np.atleast_2d(Zall)[:8 * world]) if rank == 0 else None
-        dist.barrier()
-        t_rt = time.perf_counter()
-        try:
-            res = par.sample_sharded(small, 8 * world, args.chains, 6, 4, seed=1234, control={'max_treedepth': 5},
-                                     gather='summary')
-            torch.cuda.synchronize()
-            dist.barrier()
-            roundtrip = {'ms': (time.perf_counter() - t_rt) * 1e3, 'spectra': 8 * world, 'chains': args.chains,
-                         'warmup': 6, 'draws': 4, 'gather': 'summary', 'finite': bool(np.all(np.isfinite(res['mean'])))}
-        except Exception as exc:                  # reported in the line; the steady-state rate above stands on its own
-            roundtrip = {'error': '%s: %s' % (type(exc).__name__, exc)}
-
     ranks_seen, devices_seen, backend = 1, [local_rank], 'none (single process)'
     if use_dist:
         # who actually took part: every rank contributes 1 and its device index
@@ -482,8 +467,6 @@ def main():
                          'traffic_source': traffic_src,
                          'executed_tflops_structured_path': achieved * FLOP_PER_EVAL_EXECUTED / FLOP_PER_EVAL},
         }
-        if roundtrip is not None:
-            line['config']['dist_roundtrip'] = roundtrip
         if one_device:
             line['config']['test_mode'] = 'all %d ranks on ONE device over gloo (BDRT_BENCH_ONE_DEVICE): not a scaling measurement' % world
         if sweep is not None:
@@ -492,9 +475,46 @@ def main():
             line['config']['few_chains'] = few
         if cpu is not None:
             line['cpu_baseline'] = cpu
-        print(json.dumps(line))
+    else:
+        line = None
+
+    # ---- N > 1: one complete sample_sharded call (broadcast of the problem + short run + summary gather over RCCL), timed
+    # apart from the rate and AFTER it has been secured: a watchdog prints the line and ends the process should the exercise
+    # (or the teardown of the process group) not come back -- the steady-state measurement must not hang on it
+    printed = threading.Event()
+    finished = threading.Event()
+
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            print(json.dumps(line), flush=True)
+
+    if use_dist:
+        def watchdog():
+            if not finished.wait(float(os.environ.get('BDRT_BENCH_ROUNDTRIP_TIMEOUT', '180'))):
+                if rank == 0 and not printed.is_set():
+                    line['config']['dist_roundtrip'] = {'error': 'timed out; the rate above was measured before it'}
+                emit()
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        small = dict(kw, Z=np.atleast_2d(Zall)[:8 * world]) if rank == 0 else None
+        t_rt = time.perf_counter()
+        try:
+            dist.barrier()
+            res = par.sample_sharded(small, 8 * world, args.chains, 6, 4, seed=1234, control={'max_treedepth': 5},
+                                     gather='summary')
+            torch.cuda.synchronize()
+            dist.barrier()
+            roundtrip = {'ms': (time.perf_counter() - t_rt) * 1e3, 'spectra': 8 * world, 'chains': args.chains,
+                         'warmup': 6, 'draws': 4, 'gather': 'summary', 'finite': bool(np.all(np.isfinite(res['mean'])))}
+        except Exception as exc:                  # reported in the line; the steady-state rate stands on its own
+            roundtrip = {'error': '%s: %s' % (type(exc).__name__, exc)}
+        if rank == 0:
+            line['config']['dist_roundtrip'] = roundtrip
+    emit()
     if use_dist:
         dist.destroy_process_group()
+    finished.set()
 
 
 if __name__ == '__main__':
