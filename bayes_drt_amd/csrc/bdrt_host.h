@@ -86,6 +86,10 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
 int launch_logp_grad_few(Problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp, double *d_grad,
                          hipStream_t stream);
 
+// the Stan-style L-BFGS of n fits as one launch (bdrt_lbfgs_dev.h; defined in bdrt_nuts.hip); 1: not applicable to this problem
+int lbfgs_device(Problem &P, const double *x0, const int *spec, int n, const bdrt_opt_options &o, double *x_out, double *g_out,
+                 int *iters, int *n_evals, int *rc, double *f);
+
 // percentiles of X Phi^T + bias (Phi == nullptr: of X itself) over the rows of a DEVICE matrix X; Phi, bias, q, out: host
 // expcol[K] (host, Phi == nullptr only): columns whose samples are exp(X); mean[ncols] (host): sample means; both optional
 int post_percentiles_device(const double *dX, int rows, int K, long ldx, const double *Phi, int M, const double *bias,

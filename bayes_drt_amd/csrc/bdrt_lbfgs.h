@@ -1,5 +1,5 @@
-// bdrt_lbfgs.h -- host-side L-BFGS state machine (no HIP dependency: also compiled by tests/host/ on the CPU
-// to test the optimiser logic on analytic functions; the product only ever feeds it GPU evaluations).
+// bdrt_lbfgs.h -- the L-BFGS state machine behind `algorithm='LBFGS'` (no HIP dependency in the logic: it is also compiled by
+// tests/host/ on the CPU and run on analytic functions).
 //
 // What it restates: the optimiser behind `StanModel.optimizing` (reference bayes_drt/inversion.py:1216), i.e. Stan 2.19.1's
 // BFGSMinimizer<..., LBFGSUpdate<5>> -- pystan==2.19.1.1 is a third-party dependency that is absent from /root/reference, so
@@ -17,34 +17,56 @@
 //     g^T H g / max(|f|, 1) < tol_rel_grad * eps (H = the L-BFGS inverse Hessian); |dx| < tol_param; iteration cap.
 // Stan's exact iterate path is not reproducible (summation order of its autodiff gradient): the contract is the
 // same kind of iterate -- one that stops by a tolerance test long before a stationary point on this ill-conditioned posterior.
+//
+// ONE logic, two vector back ends: `LbfgsCore<V>` holds the scalars and every decision; `V` holds the vectors and provides
+// the handful of vector operations.  `HostVecs` (std::vector; the host-driven path of bdrt_lbfgs.hip feeds it GPU evaluations,
+// tests/host feeds it analytic functions) and the device back end of bdrt_lbfgs_dev.h (element j in thread j, history rows in
+// LDS / HBM, dot products as workgroup reductions) -- so the device-resident optimiser takes the decisions this file takes.
 #pragma once
-#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
-#include <deque>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/bdrt.h"
 
+#if defined(__HIPCC__)
+#define BDRT_HD __host__ __device__
+#else
+#define BDRT_HD
+#endif
+
 namespace bdrt {
 
-struct LbfgsFit {
+using std::isfinite;
+
+constexpr int LBFGS_MAX_HISTORY = 8;
+
+// Vector back end contract (all methods uniform across the threads that share a fit on the device):
+//   double dot_g_p(), dot_g_g();           g.p, g.g at the current iterate
+//   double dot_gt_p(bool &finite);         gt.p at the trial point; finite = every component of gt finite
+//   void p_minus_g();                      p = -g
+//   void set_trial(double a);              xt = x + a p
+//   void accept(int slot, double &sy, double &yy, double &ss);   S[slot] = xt - x, Y[slot] = gt - g, then x = xt, g = gt
+//   void q_from_g(); double dot_S_q(int slot), dot_Y_q(int slot); void q_axpy_Y(int slot, double c), q_axpy_S(int slot, double c);
+//   void q_scale(double c); void p_minus_q();
+template <class V>
+struct LbfgsCore {
     enum Phase { START, BRACKET, ZOOM, DONE };
     // return codes: 0 a convergence test fired, 1 iteration cap, -1 no finite start, -2 line search failed twice (TERM_LSFAIL)
     static constexpr double C1 = 1e-4, C2 = 0.9, MIN_ALPHA = 1e-12, MIN_RANGE = 1e-16;
     static constexpr int MAX_LS_ITS = 20, MAX_LS_RESTARTS = 10;
 
-    int D = 0;
-    const bdrt_opt_options *opt = nullptr;
+    V v;
+    bdrt_opt_options opt;
     Phase phase = START;
     int iters = 0, n_evals = 0, rc = 1;
     int ls_fail_resets = 0;           // how often a failed line search reset the history (diagnostic)
-    std::vector<double> x, g, xt, gt, p;
     double f = 0.0, ft = 0.0;
-    // history (newest at the back)
-    std::deque<std::vector<double>> S, Y;
-    std::deque<double> RHO;
+    // history: circular buffer of `hist_n` pairs, newest at slot (hist_head + hist_n - 1) % history
+    int hist_head = 0, hist_n = 0;
+    double rho[LBFGS_MAX_HISTORY];
     double gammak = 1.0;
     // the previous accepted step, for the first trial step of the next line search
     double alpha = 0.0;               // Stan's _alpha: last accepted step length (rescaled after a reset)
@@ -58,73 +80,56 @@ struct LbfgsFit {
     double alo = 0, aloF = 0, aloDFp = 0, ahi = 0, ahiF = 0, ahiDFp = 0;
     int zoom_its = 0;
 
-    static double dot(const std::vector<double> &a, const std::vector<double> &b)
-    {
-        double s = 0;
-        for (size_t i = 0; i < a.size(); ++i) s += a[i] * b[i];
-        return s;
-    }
+    BDRT_HD int history() const { return opt.history < 1 ? 1 : (opt.history > LBFGS_MAX_HISTORY ? LBFGS_MAX_HISTORY : opt.history); }
+    BDRT_HD int slot(int i) const { return (hist_head + i) % history(); }          // i = 0 oldest .. hist_n - 1 newest
 
-    void init(int D_, const double *x0, const bdrt_opt_options *o)
+    BDRT_HD void search_direction()     // p = -H g (two-loop recursion, initial scaling gammak)
     {
-        D = D_; opt = o;
-        x.assign(x0, x0 + D); g.assign(D, 0.0); xt = x; gt = g; p = g;
-        phase = START;
-    }
-    const double *trial() const { return phase == START ? x.data() : xt.data(); }
-
-    void search_direction()     // p = -H g (two-loop recursion, initial scaling gammak)
-    {
-        std::vector<double> q = g;
-        const int m = (int)S.size();
-        std::vector<double> al(m);
-        for (int i = m - 1; i >= 0; --i) {
-            al[i] = RHO[i] * dot(S[i], q);
-            for (int j = 0; j < D; ++j) q[j] -= al[i] * Y[i][j];
+        double al[LBFGS_MAX_HISTORY];
+        v.q_from_g();
+        for (int i = hist_n - 1; i >= 0; --i) {
+            al[i] = rho[slot(i)] * v.dot_S_q(slot(i));
+            v.q_axpy_Y(slot(i), -al[i]);
         }
-        for (int j = 0; j < D; ++j) q[j] *= gammak;
-        for (int i = 0; i < m; ++i) {
-            const double be = RHO[i] * dot(Y[i], q);
-            for (int j = 0; j < D; ++j) q[j] += S[i][j] * (al[i] - be);
+        v.q_scale(gammak);
+        for (int i = 0; i < hist_n; ++i) {
+            const double be = rho[slot(i)] * v.dot_Y_q(slot(i));
+            v.q_axpy_S(slot(i), al[i] - be);
         }
-        for (int j = 0; j < D; ++j) p[j] = -q[j];
+        v.p_minus_q();
     }
 
     // Minimiser over [loX, hiX] of the cubic c(t) with c(0) = 0, c'(0) = df0, c(x1) = f1, c'(x1) = df1 (Stan's CubicInterp)
-    static double cubic_interp(double df0, double x1, double f1, double df1, double loX, double hiX)
+    BDRT_HD static double cubic_interp(double df0, double x1, double f1, double df1, double loX, double hiX)
     {
         const double c3 = (-12.0 * f1 + 6.0 * x1 * (df0 + df1)) / (x1 * x1 * x1);
         const double c2 = -(4.0 * df0 + 2.0 * df1) / x1 + 6.0 * f1 / (x1 * x1);
         const double c1 = df0;
-        const double t_s = std::sqrt(c2 * c2 - 2.0 * c1 * c3);
+        const double t_s = sqrt(c2 * c2 - 2.0 * c1 * c3);
         const double s1 = -(c2 + t_s) / c3, s2 = -(c2 - t_s) / c3;
-        auto val = [&](double t) { return t * (t * (t * c3 / 3.0 + c2) / 2.0 + c1); };
-        double minF = val(loX), minX = loX;
-        double tmp = val(hiX);
+        double minF = loX * (loX * (loX * c3 / 3.0 + c2) / 2.0 + c1), minX = loX;
+        double tmp = hiX * (hiX * (hiX * c3 / 3.0 + c2) / 2.0 + c1);
         if (tmp < minF) { minF = tmp; minX = hiX; }
-        if (loX < s1 && s1 < hiX) { tmp = val(s1); if (tmp < minF) { minF = tmp; minX = s1; } }
-        if (loX < s2 && s2 < hiX) { tmp = val(s2); if (tmp < minF) { minF = tmp; minX = s2; } }
+        if (loX < s1 && s1 < hiX) { tmp = s1 * (s1 * (s1 * c3 / 3.0 + c2) / 2.0 + c1); if (tmp < minF) { minF = tmp; minX = s1; } }
+        if (loX < s2 && s2 < hiX) { tmp = s2 * (s2 * (s2 * c3 / 3.0 + c2) / 2.0 + c1); if (tmp < minF) { minF = tmp; minX = s2; } }
         return minX;
     }
 
-    void set_trial(double a)
-    {
-        alpha = a;
-        for (int j = 0; j < D; ++j) xt[j] = x[j] + a * p[j];
-    }
+    BDRT_HD void set_trial(double a) { alpha = a; v.set_trial(a); }
 
     // one iteration of Stan's step(): choose the direction / first trial step and enter the line search
-    void begin_iteration(int reset_code)
+    BDRT_HD void begin_iteration(int reset_code)
     {
         reset = reset_code;
-        if (reset) for (int j = 0; j < D; ++j) p[j] = -g[j];
-        dfp = dot(g, p);
+        if (reset) v.p_minus_g();
+        dfp = v.dot_g_p();
         double a0;
         if (iters > 0 && reset != 2) {
-            a0 = std::min(1.0, 1.01 * cubic_interp(prev_dfp, alpha, f - f_prev, dfp, MIN_ALPHA, 1.0));
-            if (!(a0 > 0.0) || !std::isfinite(a0)) a0 = opt->init_alpha;      // (a NaN cubic: Stan would fail the search and reset)
+            const double ci = cubic_interp(prev_dfp, alpha, f - f_prev, dfp, MIN_ALPHA, 1.0);
+            a0 = 1.01 * ci < 1.0 ? 1.01 * ci : 1.0;
+            if (!(a0 > 0.0) || !isfinite(a0)) a0 = opt.init_alpha;      // (a NaN cubic: Stan would fail the search and reset)
         } else {
-            a0 = opt->init_alpha;
+            a0 = opt.init_alpha;
         }
         c1dfp = C1 * dfp; c2dfp = C2 * dfp;
         ls_alpha0 = MIN_ALPHA; ls_prevF = f; ls_prevDFp = dfp;
@@ -133,88 +138,93 @@ struct LbfgsFit {
         set_trial(a0);
     }
 
-    void linesearch_failed()
+    BDRT_HD void linesearch_failed()
     {
         if (reset) { rc = -2; phase = DONE; return; }       // already from steepest descent: nothing else to try
-        S.clear(); Y.clear(); RHO.clear(); gammak = 1.0;
+        hist_n = 0; hist_head = 0; gammak = 1.0;
         ls_fail_resets += 1;
         begin_iteration(2);
     }
 
-    bool accept()      // (xt, ft, gt) satisfies the Wolfe conditions; returns true when the fit terminates
+    BDRT_HD bool accept()      // the trial point satisfies the Wolfe conditions; returns true when the fit terminates
     {
-        std::vector<double> s(D), y(D);
-        double snorm2 = 0.0;
-        for (int j = 0; j < D; ++j) { s[j] = xt[j] - x[j]; y[j] = gt[j] - g[j]; snorm2 += s[j] * s[j]; }
-        f_prev = f; prev_dfp = dfp;
-        x = xt; g = gt; f = ft;
+        const int H = history();
+        if (reset) { hist_n = 0; hist_head = 0; }
+        int sl;
+        if (hist_n < H) sl = slot(hist_n);
+        else { sl = hist_head; hist_head = (hist_head + 1) % H; hist_n = H - 1; }      // the new pair overwrites the oldest one
+        double sy, yy, ss;
+        v.accept(sl, sy, yy, ss);
+        f_prev = f; prev_dfp = dfp; f = ft;
         iters += 1;
-        const double sy = dot(s, y), yy = dot(y, y);
         if (reset) {
             // the first pair after a reset scales the initial Hessian; the remembered step is rescaled with it
             const double B0fact = yy / sy;
-            S.clear(); Y.clear(); RHO.clear();
-            if (std::isfinite(B0fact) && B0fact > 0.0) { prev_dfp /= B0fact; alpha *= B0fact; }
+            if (isfinite(B0fact) && B0fact > 0.0) { prev_dfp /= B0fact; alpha *= B0fact; }
         }
-        if (sy > 0.0 && std::isfinite(sy)) {                // (always true under the strong Wolfe conditions)
-            S.push_back(s); Y.push_back(y); RHO.push_back(1.0 / sy);
+        if (sy > 0.0 && isfinite(sy)) {                     // (always true under the strong Wolfe conditions)
+            rho[sl] = 1.0 / sy;
             gammak = sy / yy;
-            if ((int)S.size() > opt->history) { S.pop_front(); Y.pop_front(); RHO.pop_front(); }
+            hist_n += 1;
         }
         search_direction();                                 // direction of the next iteration; also H g for the tol_rel_grad test
         const double eps = DBL_EPSILON;
-        const double df = std::fabs(f_prev - f);
-        if (df < opt->tol_obj) { rc = 0; return true; }
-        if (df < opt->tol_rel_obj * eps * std::max(std::fabs(f_prev), std::max(std::fabs(f), 1.0))) { rc = 0; return true; }
-        if (std::sqrt(dot(g, g)) < opt->tol_grad) { rc = 0; return true; }
-        if (-dot(g, p) / std::max(std::fabs(f), 1.0) < opt->tol_rel_grad * eps) { rc = 0; return true; }
-        if (std::sqrt(snorm2) < opt->tol_param) { rc = 0; return true; }
-        if (iters >= opt->max_iter) { rc = 1; return true; }
+        const double df = fabs(f_prev - f);
+        const double fm = fabs(f_prev) > fabs(f) ? fabs(f_prev) : fabs(f);
+        if (df < opt.tol_obj) { rc = 0; return true; }
+        if (df < opt.tol_rel_obj * eps * (fm > 1.0 ? fm : 1.0)) { rc = 0; return true; }
+        if (sqrt(v.dot_g_g()) < opt.tol_grad) { rc = 0; return true; }
+        if (-v.dot_g_p() / (fabs(f) > 1.0 ? fabs(f) : 1.0) < opt.tol_rel_grad * eps) { rc = 0; return true; }
+        if (sqrt(ss) < opt.tol_param) { rc = 0; return true; }
+        if (iters >= opt.max_iter) { rc = 1; return true; }
         return false;
     }
 
-    void next_zoom_trial()
+    BDRT_HD void next_zoom_trial()
     {
         zoom_its += 1;
-        if (std::fabs(alo - ahi) < MIN_RANGE) { linesearch_failed(); return; }
+        if (fabs(alo - ahi) < MIN_RANGE) { linesearch_failed(); return; }
         double a;
         if (zoom_its % 5 == 0) {
             a = 0.5 * (alo + ahi);
         } else {
             const double d1 = aloDFp + ahiDFp - 3.0 * (aloF - ahiF) / (alo - ahi);
-            double d2 = std::sqrt(d1 * d1 - aloDFp * ahiDFp);
+            double d2 = sqrt(d1 * d1 - aloDFp * ahiDFp);
             if (ahi < alo) d2 = -d2;
             a = ahi - (ahi - alo) * (ahiDFp + d2 - d1) / (ahiDFp - aloDFp + 2.0 * d2);
-            const double lo = std::min(alo, ahi), hi = std::max(alo, ahi), w = std::fabs(alo - ahi);
-            if (!std::isfinite(a) || a < lo + 0.01 * w || a > hi - 0.01 * w) a = 0.5 * (alo + ahi);
+            const double lo = alo < ahi ? alo : ahi, hi = alo < ahi ? ahi : alo, w = fabs(alo - ahi);
+            if (!isfinite(a) || a < lo + 0.01 * w || a > hi - 0.01 * w) a = 0.5 * (alo + ahi);
         }
         phase = ZOOM;
         set_trial(a);
     }
 
-    void enter_zoom(double lo, double loF, double loD, double hi, double hiF, double hiD)
+    BDRT_HD void enter_zoom(double lo, double loF, double loD, double hi, double hiF, double hiD)
     {
         alo = lo; aloF = loF; aloDFp = loD; ahi = hi; ahiF = hiF; ahiDFp = hiD;
         zoom_its = 0;
         next_zoom_trial();
     }
 
-    // feed the evaluation at trial(): fval = -lp, grad = -grad lp
-    void feed(double lp, const double *grad_lp)
+    // the start point has been evaluated (gradient in the back end): fval = -lp
+    BDRT_HD void start(double fval)
     {
         n_evals += 1;
-        if (phase == START) {
-            f = -lp;
-            for (int j = 0; j < D; ++j) g[j] = -grad_lp[j];
-            if (!std::isfinite(f)) { rc = -1; phase = DONE; return; }
-            if (std::sqrt(dot(g, g)) < opt->tol_grad) { rc = 0; phase = DONE; return; }
-            if (opt->max_iter <= 0) { rc = 1; phase = DONE; return; }
-            begin_iteration(1);
-            return;
-        }
-        ft = -lp;
-        bool finite = std::isfinite(ft);
-        for (int j = 0; j < D; ++j) { gt[j] = -grad_lp[j]; finite = finite && std::isfinite(gt[j]); }
+        f = fval;
+        if (!isfinite(f)) { rc = -1; phase = DONE; return; }
+        if (sqrt(v.dot_g_g()) < opt.tol_grad) { rc = 0; phase = DONE; return; }
+        if (opt.max_iter <= 0) { rc = 1; phase = DONE; return; }
+        begin_iteration(1);
+    }
+
+    // the trial point has been evaluated (its gradient in the back end): fval = -lp
+    BDRT_HD void feed_trial(double fval)
+    {
+        n_evals += 1;
+        ft = fval;
+        bool gfinite = true;
+        const double newDFp = v.dot_gt_p(gfinite);
+        const bool finite = isfinite(ft) && gfinite;
         if (phase == BRACKET) {
             if (!finite) {                                  // Stan: func() != 0 -> pull the step back towards the last good one
                 if (ls_restarts >= MAX_LS_RESTARTS) { linesearch_failed(); return; }
@@ -223,12 +233,11 @@ struct LbfgsFit {
                 return;
             }
             ls_restarts = 0;
-            const double newDFp = dot(gt, p);
             if (ft > f + alpha * c1dfp || (ft >= ls_prevF && ls_its > 0)) {
                 enter_zoom(ls_alpha0, ls_prevF, ls_prevDFp, alpha, ft, newDFp);
                 return;
             }
-            if (std::fabs(newDFp) <= -c2dfp) {
+            if (fabs(newDFp) <= -c2dfp) {
                 if (accept()) { phase = DONE; return; }
                 begin_iteration(0);
                 return;
@@ -245,17 +254,16 @@ struct LbfgsFit {
         }
         // ZOOM
         if (!finite) {
-            const double lo = std::min(alo, ahi);
+            const double lo = alo < ahi ? alo : ahi;
             const double a = 0.5 * (alpha + lo);
-            if (std::fabs(lo - a) < MIN_RANGE) { linesearch_failed(); return; }
+            if (fabs(lo - a) < MIN_RANGE) { linesearch_failed(); return; }
             set_trial(a);
             return;
         }
-        const double newDFp = dot(gt, p);
         if (ft > f + alpha * c1dfp || ft >= aloF) {
             ahi = alpha; ahiF = ft; ahiDFp = newDFp;
         } else {
-            if (std::fabs(newDFp) <= -c2dfp) {
+            if (fabs(newDFp) <= -c2dfp) {
                 if (accept()) { phase = DONE; return; }
                 begin_iteration(0);
                 return;
@@ -265,9 +273,95 @@ struct LbfgsFit {
         }
         next_zoom_trial();
     }
+};
 
-    // entry point for callers (kept from the first version of this file, which had a second path)
-    void feed_any(double lp, const double *grad_lp) { feed(lp, grad_lp); }
+// ---- host back end --------------------------------------------------------------------------------------------------------
+struct HostVecs {
+    int D = 0;
+    std::vector<double> x, g, xt, gt, p, q;
+    std::vector<std::vector<double>> S, Y;
+    static double dot(const std::vector<double> &a, const std::vector<double> &b)
+    {
+        double s = 0;
+        for (size_t i = 0; i < a.size(); ++i) s += a[i] * b[i];
+        return s;
+    }
+    double dot_g_p() { return dot(g, p); }
+    double dot_g_g() { return dot(g, g); }
+    double dot_gt_p(bool &finite)
+    {
+        finite = true;
+        for (double t : gt) finite = finite && std::isfinite(t);
+        return finite ? dot(gt, p) : 0.0;
+    }
+    void p_minus_g() { for (int j = 0; j < D; ++j) p[j] = -g[j]; }
+    void set_trial(double a) { for (int j = 0; j < D; ++j) xt[j] = x[j] + a * p[j]; }
+    void accept(int slot, double &sy, double &yy, double &ss)
+    {
+        std::vector<double> &s = S[slot], &y = Y[slot];
+        for (int j = 0; j < D; ++j) { s[j] = xt[j] - x[j]; y[j] = gt[j] - g[j]; }
+        sy = dot(s, y); yy = dot(y, y); ss = dot(s, s);
+        x = xt; g = gt;
+    }
+    void q_from_g() { q = g; }
+    double dot_S_q(int slot) { return dot(S[slot], q); }
+    double dot_Y_q(int slot) { return dot(Y[slot], q); }
+    void q_axpy_Y(int slot, double c) { for (int j = 0; j < D; ++j) q[j] += c * Y[slot][j]; }
+    void q_axpy_S(int slot, double c) { for (int j = 0; j < D; ++j) q[j] += c * S[slot][j]; }
+    void q_scale(double c) { for (int j = 0; j < D; ++j) q[j] *= c; }
+    void p_minus_q() { for (int j = 0; j < D; ++j) p[j] = -q[j]; }
+};
+
+// the host-driven fit: asks for one evaluation at a time (`trial()`), is fed lp and the gradient of lp
+struct LbfgsFit {
+    typedef LbfgsCore<HostVecs> Core;
+    enum Phase { START = Core::START, BRACKET = Core::BRACKET, ZOOM = Core::ZOOM, DONE = Core::DONE };
+    Core c;
+    int D = 0;
+    // views the callers read
+    std::vector<double> &x = c.v.x, &g = c.v.g;
+    double &f = c.f;
+    int &iters = c.iters, &n_evals = c.n_evals, &rc = c.rc;
+    int phase = START;
+
+    static double dot(const std::vector<double> &a, const std::vector<double> &b) { return HostVecs::dot(a, b); }
+
+    void init(int D_, const double *x0, const bdrt_opt_options *o)
+    {
+        D = D_;
+        c.opt = *o;
+        HostVecs &v = c.v;
+        v.D = D;
+        v.x.assign(x0, x0 + D); v.g.assign(D, 0.0); v.xt = v.x; v.gt = v.g; v.p = v.g; v.q = v.g;
+        v.S.assign(LBFGS_MAX_HISTORY, std::vector<double>(D, 0.0));
+        v.Y = v.S;
+        c.phase = Core::START;
+        phase = START;
+    }
+    const double *trial() const { return c.phase == Core::START ? c.v.x.data() : c.v.xt.data(); }
+
+    // feed the evaluation at trial(): lp and the gradient of lp
+    void feed_any(double lp, const double *grad_lp)
+    {
+        if (c.phase == Core::START) {
+            for (int j = 0; j < D; ++j) c.v.g[j] = -grad_lp[j];
+            c.start(-lp);
+        } else {
+            for (int j = 0; j < D; ++j) c.v.gt[j] = -grad_lp[j];
+            c.feed_trial(-lp);
+        }
+        phase = (int)c.phase;
+    }
+    // result of a fit that ran elsewhere (the device-resident kernel): last iterate, gradient of -lp there, counters
+    void load(const double *x_, const double *g_, double f_, int iters_, int n_evals_, int rc_)
+    {
+        c.v.x.assign(x_, x_ + D); c.v.g.assign(g_, g_ + D);
+        c.f = f_; c.iters = iters_; c.n_evals = n_evals_; c.rc = rc_;
+        c.phase = Core::DONE; phase = DONE;
+    }
+    LbfgsFit() = default;
+    LbfgsFit(const LbfgsFit &o) : c(o.c), D(o.D), x(c.v.x), g(c.v.g), f(c.f), iters(c.iters), n_evals(c.n_evals), rc(c.rc), phase(o.phase) {}
+    LbfgsFit &operator=(const LbfgsFit &o) { c = o.c; D = o.D; phase = o.phase; return *this; }
 };
 
 }  // namespace bdrt

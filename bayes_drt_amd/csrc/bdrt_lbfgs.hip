@@ -61,6 +61,17 @@ int bdrt_optimize(bdrt_problem *p, const double *init_theta, const int *spec, in
     auto advance_stage = [&](FitDriver &F) {
         if (F.stage == 0 && F.L.phase == LbfgsFit::DONE) F.stage = 2;
     };
+    // The whole L-BFGS phase on the device when the problem takes one of the one-chain evaluators (every model on log-uniform
+    // grids): one launch, a workgroup per fit, the decisions of bdrt_lbfgs.h (bdrt_lbfgs_dev.h).  BDRT_HOST_LBFGS=1 keeps the
+    // host-driven loop below, which also serves the problems without a Toeplitz structure.
+    if (ol.max_iter > 0 && !getenv("BDRT_HOST_LBFGS")) {
+        std::vector<double> xo((size_t)n_fits * D), go((size_t)n_fits * D), fv(n_fits);
+        std::vector<int> it(n_fits), ne(n_fits), rcv(n_fits);
+        const int drc = lbfgs_device(P, init_theta, spec, n_fits, ol, xo.data(), go.data(), it.data(), ne.data(), rcv.data(), fv.data());
+        if (drc < 0) return drc;
+        if (drc == 0)
+            for (int i = 0; i < n_fits; ++i) fits[i].L.load(&xo[(size_t)i * D], &go[(size_t)i * D], fv[i], it[i], ne[i], rcv[i]);
+    }
     for (auto &F : fits) advance_stage(F);
 
     const size_t MAXCOLS = 16384;                      // columns per launch (PCIe staging bounded to ~45 MB each way)

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "bdrt_host.h"
+#include "bdrt_lbfgs.h"
 #include "bdrt_nuts_device.h"
 #include "bdrt_solo.h"
 
@@ -74,6 +75,7 @@ struct NutsArgs {
 
 #include "bdrt_nuts_wide.h"
 #include "bdrt_solo_wide.h"
+#include "bdrt_lbfgs_dev.h"
 
 // Thread mapping of the bookkeeping stages: chain c of the workgroup lives in ONE half-wave (wave c/2, lanes
 // 32*(c%2)..+31); its D-vectors are contiguous rows, lane l handles elements l, l+32, ...  Per-chain dot products are
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             constexpr int MB = NJ % 8 == 0 ? 8 : 9;
             static_assert(NJ % MB == 0, "chunk size must divide NJ");
             constexpr int NS2 = (32 * NJ + 63) / 64;            // 64-element slices of a row
-            constexpr int LMAX = 6;                             // merge levels a chain's own pass can take (1 leaf in 128 closes more)
+            constexpr int LMAX = 4;                             // merge levels a chain's own pass can take (6 measured: phase H -4 k cycles, phase P +4 k)
             typedef double dv2 __attribute__((ext_vector_type(2)));
             auto ld2 = [](const double *q) -> dv2 { return *reinterpret_cast<const dv2 *>(q); };
             auto st2 = [](double *q, dv2 v) { *reinterpret_cast<dv2 *>(q) = v; };
@@ -350,9 +352,8 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     };
                     {
                         const bool w1 = __builtin_amdgcn_ballot_w64(nmf > 0) != 0, w2 = __builtin_amdgcn_ballot_w64(nmf > 1) != 0,
-                                   w3 = __builtin_amdgcn_ballot_w64(nmf > 2) != 0, w5 = __builtin_amdgcn_ballot_w64(nmf > 4) != 0;
-                        if (w5) pass(std::integral_constant<int, LMAX>{}, std::integral_constant<int, 1>{});
-                        else if (w3) pass(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
+                                   w3 = __builtin_amdgcn_ballot_w64(nmf > 2) != 0;
+                        if (w3) pass(std::integral_constant<int, LMAX>{}, std::integral_constant<int, 2>{});
                         else if (w2) pass(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
                         else if (w1) pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
                         else pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
@@ -1361,6 +1362,12 @@ __global__ void nuts_live_kernel(const ChainState *states, int n, int *live)
     if (u < n) { const int ph = states[u].phase; live[u] = (ph == PH_INIT || ph == PH_EPS || ph == PH_TREE) ? 1 : 0; }
 }
 
+// device allocation freed on scope exit
+struct DevTmpBuf {
+    void *p = nullptr;
+    ~DevTmpBuf() { if (p) hipFree(p); }
+};
+
 struct Sampler {
     Problem *prob = nullptr;
     NutsParams np;
@@ -1455,6 +1462,54 @@ int launch_logp_grad_few(Problem *p, const double *d_theta, const int *d_spec, i
                            jacobian, d_lp, d_grad);
     }
     BDRT_HIP(hipGetLastError());
+    return 0;
+}
+
+// The Stan-style L-BFGS of n fits as one launch (bdrt_lbfgs_dev.h).  Returns 1 when the problem takes neither one-chain
+// evaluator (caller: host-driven path), 0 on success (x_out / g_out [n][D]: last iterate and the gradient of -lp there).
+int lbfgs_device(Problem &P, const double *x0, const int *spec, int n, const bdrt_opt_options &o, double *x_out, double *g_out,
+                 int *iters, int *n_evals, int *rc, double *f)
+{
+    const bool solo = solo_capable(P.dev), w1 = !solo && wide1_capable(P.dev);
+    if ((!solo && !w1) || n < 1 || o.history > LBFGS_MAX_HISTORY) return 1;
+    BDRT_HIP(hipSetDevice(P.device));
+    const int D = P.dev.D;
+    SoloGeom g = solo_geometry(P.dev.nf, P.dev.blk[0].K, D);
+    Wide1Geom G = wide1_geometry(P.dev.nf, P.dev.blk[0].K, D, P.dev.nblocks);
+    const int DS = (D + 7) & ~7;
+    size_t lds;
+    if (solo) {
+        lds = ((size_t)g.o_vec + (size_t)(2 + 2 * LBFGS_MAX_HISTORY) * g.DSS) * sizeof(double) + 64;
+        if (lds > 160 * 1024) return 1;
+    } else {
+        lds = ((size_t)G.total + 8) * sizeof(double) + 64;
+    }
+    DevTmpBuf dx0, dxo, dgo, drep, dspec, dwork;
+    const size_t nb = (size_t)n * D * sizeof(double);
+    BDRT_HIP(hipMalloc(&dx0.p, nb)); BDRT_HIP(hipMalloc(&dxo.p, nb)); BDRT_HIP(hipMalloc(&dgo.p, nb));
+    BDRT_HIP(hipMalloc(&drep.p, (size_t)n * sizeof(LbfgsDevReport)));
+    BDRT_HIP(hipMemcpy(dx0.p, x0, nb, hipMemcpyHostToDevice));
+    if (spec) { BDRT_HIP(hipMalloc(&dspec.p, (size_t)n * sizeof(int))); BDRT_HIP(hipMemcpy(dspec.p, spec, (size_t)n * sizeof(int), hipMemcpyHostToDevice)); }
+    if (!solo) BDRT_HIP(hipMalloc(&dwork.p, (size_t)n * LBFGS_WIDE_ROWS * DS * sizeof(double)));
+    const long long cap = (long long)std::max(o.max_iter, 0) * 4 + 64;
+    const int max_evals = (int)std::min<long long>(cap, 1LL << 30);
+    static LdsAttrCache attr_s, attr_w;
+    if (solo) {
+        BDRT_HIP(attr_s.ensure(lds, [&]() { return hipFuncSetAttribute((const void *)lbfgs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }));
+        hipLaunchKernelGGL(lbfgs_kernel<false>, dim3(n), dim3(SOLO_NT), lds, P.stream, (const DevProblem *)P.d_dev, g, G, (const double *)dx0.p,
+                           (const int *)dspec.p, o, max_evals, (double *)dxo.p, (double *)dgo.p, (LbfgsDevReport *)drep.p, (double *)nullptr, DS);
+    } else {
+        BDRT_HIP(attr_w.ensure(lds, [&]() { return hipFuncSetAttribute((const void *)lbfgs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }));
+        hipLaunchKernelGGL(lbfgs_kernel<true>, dim3(n), dim3(SOLO_NT), lds, P.stream, (const DevProblem *)P.d_dev, g, G, (const double *)dx0.p,
+                           (const int *)dspec.p, o, max_evals, (double *)dxo.p, (double *)dgo.p, (LbfgsDevReport *)drep.p, (double *)dwork.p, DS);
+    }
+    BDRT_HIP(hipGetLastError());
+    BDRT_HIP(hipStreamSynchronize(P.stream));
+    std::vector<LbfgsDevReport> reps((size_t)n);
+    BDRT_HIP(hipMemcpy(reps.data(), drep.p, reps.size() * sizeof(LbfgsDevReport), hipMemcpyDeviceToHost));
+    BDRT_HIP(hipMemcpy(x_out, dxo.p, nb, hipMemcpyDeviceToHost));
+    BDRT_HIP(hipMemcpy(g_out, dgo.p, nb, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) { iters[i] = reps[i].iters; n_evals[i] = reps[i].n_evals; rc[i] = reps[i].rc; f[i] = reps[i].f; }
     return 0;
 }
 

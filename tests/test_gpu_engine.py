@@ -356,3 +356,36 @@ def test_wide_path_long_run_matches_oracle(tile, seed, monkeypatch):
         assert np.all(err < 1e-5), err
         deep += diag[c]['n_leapfrog'] > 40 * nd
     assert deep > 0 or seed == 11                          # trees deeper than 5 doublings were built
+
+
+@pytest.mark.parametrize('family', ['headline', 'DRT-2-TpDDT_uniform_0.25', 'PDAC_DRT-TpDDT_outliers'])
+def test_device_resident_lbfgs_takes_the_host_state_machines_decisions(monkeypatch, family):
+    """algorithm='LBFGS' (Stan 2.19's L-BFGS restated, bdrt_lbfgs.h) runs as ONE kernel, a workgroup per fit
+    (bdrt_lbfgs_dev.h), with the decisions of the host state machine: over the first iterations the two paths -- device
+    reductions vs sequential host sums of the same products -- stay together to rounding; the complete run ends by one of
+    Stan's tolerance tests long before the iteration cap, as Stan's does on the reference's spectra."""
+    from bayes_drt_amd.model import Problem
+    from bayes_drt_amd.engine import optimize_batch
+    from tests.helpers import kat_to_model
+    if family == 'headline':
+        blk, Z, f, kw, d = _bench_problem('optimize', 'K81')
+        prob = Problem([blk], Z, f, **kw)
+        th0 = np.random.RandomState(1234).uniform(-2, 2, (2, prob.D))
+    else:
+        k = kat_to_model(family)
+        prob = Problem(**k['kw'])
+        th0 = prob.unconstrain(k['params'])[None] + 0.3 * np.random.RandomState(5).standard_normal((2, prob.D))
+    dev, rd = optimize_batch(prob, th0, max_iter=25, newton_max_iter=0)
+    monkeypatch.setenv('BDRT_HOST_LBFGS', '1')
+    host, rh = optimize_batch(prob, th0, max_iter=25, newton_max_iter=0)
+    monkeypatch.delenv('BDRT_HOST_LBFGS')
+    for i in range(2):
+        assert rd[i]['iterations'] == rh[i]['iterations'] == 25 and rd[i]['return_code'] == rh[i]['return_code'] == 1
+        assert rd[i]['n_evals'] == rh[i]['n_evals'], (rd[i], rh[i])                  # the same line-search decisions
+        assert abs(rd[i]['lp'] - rh[i]['lp']) <= 1e-7 * max(1.0, abs(rh[i]['lp'])), (rd[i]['lp'], rh[i]['lp'])
+        assert np.max(np.abs(dev[i] - host[i])) <= 1e-6 * max(1.0, np.max(np.abs(host[i])))
+    full, rf = optimize_batch(prob, th0[:1], max_iter=50000, newton_max_iter=0)
+    print('%s: L-BFGS alone ends after %d iterations (%d evaluations), rc %d, lp %.4f, |g|inf %.2e'
+          % (family, rf[0]['iterations'], rf[0]['n_evals'], rf[0]['return_code'], rf[0]['lp'], rf[0]['grad_inf']))
+    assert rf[0]['return_code'] in (0, -2) and 50 < rf[0]['iterations'] < 50000, rf[0]
+    assert rf[0]['lp'] > max(rd[0]['lp'], rh[0]['lp'])
