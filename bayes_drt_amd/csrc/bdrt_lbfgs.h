@@ -32,7 +32,8 @@
 #include "../../include/bdrt.h"
 
 #if defined(__HIPCC__)
-#define BDRT_HD __host__ __device__
+// (inlined into the device kernel: a call would force the whole state machine into scratch memory)
+#define BDRT_HD __host__ __device__ __forceinline__
 #else
 #define BDRT_HD
 #endif
@@ -83,18 +84,40 @@ struct LbfgsCore {
     BDRT_HD int history() const { return opt.history < 1 ? 1 : (opt.history > LBFGS_MAX_HISTORY ? LBFGS_MAX_HISTORY : opt.history); }
     BDRT_HD int slot(int i) const { return (hist_head + i) % history(); }          // i = 0 oldest .. hist_n - 1 newest
 
+    // rho[] by a run-time slot through compile-time indices only: a dynamically indexed member would pin the whole state
+    // machine in scratch memory on the device
+    BDRT_HD double rho_get(int sl) const
+    {
+        double r = 0.0;
+#pragma unroll
+        for (int k = 0; k < LBFGS_MAX_HISTORY; ++k) r = k == sl ? rho[k] : r;
+        return r;
+    }
+    BDRT_HD void rho_set(int sl, double val)
+    {
+#pragma unroll
+        for (int k = 0; k < LBFGS_MAX_HISTORY; ++k) rho[k] = k == sl ? val : rho[k];
+    }
+
     BDRT_HD void search_direction()     // p = -H g (two-loop recursion, initial scaling gammak)
     {
         double al[LBFGS_MAX_HISTORY];
         v.q_from_g();
-        for (int i = hist_n - 1; i >= 0; --i) {
-            al[i] = rho[slot(i)] * v.dot_S_q(slot(i));
-            v.q_axpy_Y(slot(i), -al[i]);
+#pragma unroll
+        for (int i = LBFGS_MAX_HISTORY - 1; i >= 0; --i) {
+            al[i] = 0.0;
+            if (i < hist_n) {
+                al[i] = rho_get(slot(i)) * v.dot_S_q(slot(i));
+                v.q_axpy_Y(slot(i), -al[i]);
+            }
         }
         v.q_scale(gammak);
-        for (int i = 0; i < hist_n; ++i) {
-            const double be = rho[slot(i)] * v.dot_Y_q(slot(i));
-            v.q_axpy_S(slot(i), al[i] - be);
+#pragma unroll
+        for (int i = 0; i < LBFGS_MAX_HISTORY; ++i) {
+            if (i < hist_n) {
+                const double be = rho_get(slot(i)) * v.dot_Y_q(slot(i));
+                v.q_axpy_S(slot(i), al[i] - be);
+            }
         }
         v.p_minus_q();
     }
@@ -163,7 +186,7 @@ struct LbfgsCore {
             if (isfinite(B0fact) && B0fact > 0.0) { prev_dfp /= B0fact; alpha *= B0fact; }
         }
         if (sy > 0.0 && isfinite(sy)) {                     // (always true under the strong Wolfe conditions)
-            rho[sl] = 1.0 / sy;
+            rho_set(sl, 1.0 / sy);
             gammak = sy / yy;
             hist_n += 1;
         }

@@ -30,9 +30,9 @@ struct DevVecs {
     __device__ __forceinline__ void bsum2(double &a, double &b) { solo_block_sum2(a, b, red, rslot, wave, lane); }
     __device__ __forceinline__ double bsum(double a) { double b = 0.0; bsum2(a, b); return a; }
 
-    __device__ double dot_g_p() { double a = 0.0; for (int k = 0; k < NE; ++k) a += own[k] ? g[k] * p[k] : 0.0; return bsum(a); }
-    __device__ double dot_g_g() { double a = 0.0; for (int k = 0; k < NE; ++k) a += own[k] ? g[k] * g[k] : 0.0; return bsum(a); }
-    __device__ double dot_gt_p(bool &finite)
+    __device__ __forceinline__ double dot_g_p() { double a = 0.0; for (int k = 0; k < NE; ++k) a += own[k] ? g[k] * p[k] : 0.0; return bsum(a); }
+    __device__ __forceinline__ double dot_g_g() { double a = 0.0; for (int k = 0; k < NE; ++k) a += own[k] ? g[k] * g[k] : 0.0; return bsum(a); }
+    __device__ __forceinline__ double dot_gt_p(bool &finite)
     {
         double a = 0.0, bad = 0.0;
         for (int k = 0; k < NE; ++k) if (own[k]) { a += gt[k] * p[k]; bad += isfinite(gt[k]) ? 0.0 : 1.0; }
@@ -41,9 +41,9 @@ struct DevVecs {
         finite = bad == 0.0;
         return finite ? a : 0.0;
     }
-    __device__ void p_minus_g() { for (int k = 0; k < NE; ++k) p[k] = -g[k]; }
-    __device__ void set_trial(double a) { for (int k = 0; k < NE; ++k) xt[k] = x[k] + a * p[k]; }
-    __device__ void accept(int slot, double &sy, double &yy, double &ss)
+    __device__ __forceinline__ void p_minus_g() { for (int k = 0; k < NE; ++k) p[k] = -g[k]; }
+    __device__ __forceinline__ void set_trial(double a) { for (int k = 0; k < NE; ++k) xt[k] = x[k] + a * p[k]; }
+    __device__ __forceinline__ void accept(int slot, double &sy, double &yy, double &ss)
     {
         double a = 0.0, b = 0.0, c = 0.0;
         for (int k = 0; k < NE; ++k) if (own[k]) {
@@ -56,13 +56,13 @@ struct DevVecs {
         c = bsum(c);
         sy = a; yy = b; ss = c;
     }
-    __device__ void q_from_g() { for (int k = 0; k < NE; ++k) q[k] = g[k]; }
-    __device__ double dot_S_q(int slot) { double a = 0.0; for (int k = 0; k < NE; ++k) a += own[k] ? *S(slot, k) * q[k] : 0.0; return bsum(a); }
-    __device__ double dot_Y_q(int slot) { double a = 0.0; for (int k = 0; k < NE; ++k) a += own[k] ? *Y(slot, k) * q[k] : 0.0; return bsum(a); }
-    __device__ void q_axpy_Y(int slot, double c) { for (int k = 0; k < NE; ++k) if (own[k]) q[k] += c * *Y(slot, k); }
-    __device__ void q_axpy_S(int slot, double c) { for (int k = 0; k < NE; ++k) if (own[k]) q[k] += c * *S(slot, k); }
-    __device__ void q_scale(double c) { for (int k = 0; k < NE; ++k) q[k] *= c; }
-    __device__ void p_minus_q() { for (int k = 0; k < NE; ++k) p[k] = -q[k]; }
+    __device__ __forceinline__ void q_from_g() { for (int k = 0; k < NE; ++k) q[k] = g[k]; }
+    __device__ __forceinline__ double dot_S_q(int slot) { double a = 0.0; for (int k = 0; k < NE; ++k) a += own[k] ? *S(slot, k) * q[k] : 0.0; return bsum(a); }
+    __device__ __forceinline__ double dot_Y_q(int slot) { double a = 0.0; for (int k = 0; k < NE; ++k) a += own[k] ? *Y(slot, k) * q[k] : 0.0; return bsum(a); }
+    __device__ __forceinline__ void q_axpy_Y(int slot, double c) { for (int k = 0; k < NE; ++k) if (own[k]) q[k] += c * *Y(slot, k); }
+    __device__ __forceinline__ void q_axpy_S(int slot, double c) { for (int k = 0; k < NE; ++k) if (own[k]) q[k] += c * *S(slot, k); }
+    __device__ __forceinline__ void q_scale(double c) { for (int k = 0; k < NE; ++k) q[k] *= c; }
+    __device__ __forceinline__ void p_minus_q() { for (int k = 0; k < NE; ++k) p[k] = -q[k]; }
 };
 
 // rows of global work space per fit of the general-model variant: theta, gradient, history
