@@ -395,6 +395,59 @@ def gen_hmc_suite():
          run4x1000_cols=np.array(['saturated_treedepth10', 'divergent', 'iterations', 'seconds']))
 
 
+def gen_hmc_suite2():
+    """The other families of the reference's published HMC study (Run fits.ipynb cells 10, 14, 18, 22 and the stored
+    bayes_results/Gout_*.csv): RC-ZARC (Series_pos on its own 51-point basis), trunc (Series, sign-free), BimodalTP-DDT /
+    BimodalBP-DDT (ONE parallel diffusion distribution = the `Parallel` model), DRT-k-TpDDT (Series-Parallel_pos) and
+    DRT-TpDDT-BpDDT (Series-2Parallel_pos): spectra, stored posterior mean / band curves (every column of the CSV), and the
+    diagnostics pystan printed.  Arrays and numbers only; one entry per spectrum, keyed by its file stem."""
+    import json
+    import re
+    import pandas as pd
+    nb = json.load(open(os.path.join(REF, 'code_EchemActa', 'Run fits.ipynb')))
+    diag = {}
+    for c in nb['cells']:
+        if c['cell_type'] != 'code' or not ''.join(c['source']).startswith('"MCMC sampling"'):
+            continue
+        cur = None
+        for o in c.get('outputs', []):
+            for line in ''.join(o.get('text') or '').splitlines():
+                m = re.search(r'Z_([^\\/]+)\.csv', line)
+                if m:
+                    cur = m.group(1); diag[cur] = [0, 0, 400, np.nan]; continue
+                if cur is None:
+                    continue
+                m = re.search(r'(\d+) of (\d+) iterations saturated', line)
+                if m: diag[cur][0] = int(m.group(1)); diag[cur][2] = int(m.group(2))
+                m = re.search(r'(\d+) of (\d+) iterations ended with a divergence', line)
+                if m: diag[cur][1] = int(m.group(1)); diag[cur][2] = int(m.group(2))
+                m = re.search(r'File fit time: ([0-9.]+) seconds', line)
+                if m: diag[cur][3] = float(m.group(1))
+    out = {}
+    stems = []
+    for pth in sorted(glob.glob(os.path.join(REF, 'code_EchemActa/bayes_results/Gout_*.csv'))):
+        stem = os.path.basename(pth)[5:-4]
+        fam = stem.split('_')[0]
+        if fam not in ('RC-ZARC', 'trunc', 'BimodalTP-DDT', 'BimodalBP-DDT', 'DRT-2-TpDDT', 'DRT-3-TpDDT', 'DRT-4-TpDDT',
+                       'DRT-TpDDT-BpDDT'):
+            continue
+        zf = os.path.join(REF, 'data/simulated/Z_%s.csv' % stem)
+        if not os.path.exists(zf):
+            continue
+        z = pd.read_csv(zf)
+        g = pd.read_csv(pth)
+        g = g[[c for c in g.columns if not c.startswith('Unnamed')]]
+        key = stem.replace('-', '').replace('.', 'p')
+        out['Z__' + key] = np.array([z['Freq'].values, z['Zreal'].values, z['Zimag'].values]).T
+        out['G__' + key] = g.values.astype(float)
+        out['Gcols__' + key] = np.array(list(g.columns))
+        out['diag__' + key] = np.array(diag.get(stem, [np.nan, np.nan, 400, np.nan]), dtype=float)
+        stems.append(stem)
+    out['stems'] = np.array(stems)
+    out['diag_cols'] = np.array(['saturated_treedepth10', 'divergent', 'iterations', 'hmc_seconds'])
+    save('hmc_suite2', **out)
+
+
 def gen_predict():
     # predict_distribution / predict_Z / predict_sigma for a *given* coefficient vector (no Stan needed):
     # inversion.py:3298-3311 (gamma = Phi @ coef), :2942-2959 (Z_hat), :3089-3139 (sigma)
@@ -532,6 +585,6 @@ def gen_ridge():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['matrices', 'ddt', 'dat', 'kats', 'csv', 'predict', 'host', 'ridge', 'hmc_suite', 'basis']
+    which = sys.argv[1:] or ['matrices', 'ddt', 'dat', 'kats', 'csv', 'predict', 'host', 'ridge', 'hmc_suite', 'hmc_suite2', 'basis']
     for w in which:
         globals()['gen_' + w]()

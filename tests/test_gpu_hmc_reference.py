@@ -79,3 +79,97 @@ def test_suite_spectrum_matches_stored_curves_and_saturation_class(stem):
     if d[0] >= 380:
         assert fit.n_max_treedepth >= 190, (fit.n_max_treedepth, d[0])
     assert fit.n_divergent <= 20
+
+
+MAP_SUITE = ['2ZARC_Orazem_1.0', '2ZARC_uniform_2.5', 'ZARC_Macdonald_1.0', 'ZARC_uniform_0.25', 'ZARC-RL_Macdonald_2.5',
+             'ZARC-RL_uniform_1.0', 'ZARC-RL_noiseless', '2ZARC_Macdonald_0.25']
+
+
+@pytest.mark.parametrize('stem', MAP_SUITE)
+def test_map_suite_spectrum_matches_the_published_map_curve(stem):
+    """The reference's published MAP study (Run fits.ipynb cell 4; stored curves map_results/Gout_*.csv) through
+    Inverter.fit(mode='optimize') with the notebook's settings.  The stored curves are Stan L-BFGS iterates that stopped by a
+    tolerance test; on these smooth (ZARC-type) spectra they sit within a few % of the stationary point, and so
+    does our default fit: asserted <= 4 % (measured 0.1-3 %, profiles/r03/map_suite.txt; north_star's 1e-4 is not attainable
+    against an unconverged iterate).  algorithm='LBFGS', n_starts=1 -- the reference's own kind of iterate -- is
+    printed beside it (7e-4 ... 0.19 depending on where each of the two stops)."""
+    from bayes_drt_amd.inversion import Inverter
+    S = load('hmc_suite')
+    i = [str(s) for s in S['stems']].index(stem)
+    f, Z = S['Z'][i][:, 0], S['Z'][i][:, 1] + 1j * S['Z'][i][:, 2]
+    ref = S['Gout_map'][i][:, 1]
+    kw = dict(nonneg=not stem.startswith('ZARC-RL'), mode='optimize', sigma_min=0.005 if 'noiseless' in stem else 0.002)
+    inv = Inverter(basis_freq=f)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        inv.fit(f, Z, **kw)
+        g = inv.predict_distribution('DRT', eval_tau=TAU_PLOT)
+        rep = inv._opt_report
+        inv.fit(f, Z, algorithm='LBFGS', n_starts=1, **kw)
+        gs = inv.predict_distribution('DRT', eval_tau=TAU_PLOT)
+    print('%s: default fit %.4f from the stored MAP curve (|grad|inf %.1e); Stan-style single-start iterate %.4f (%d iterations, rc %d)'
+          % (stem, rel_l2(g, ref), rep['grad_inf'], rel_l2(gs, ref), inv._opt_report['iterations'], inv._opt_report['return_code']))
+    assert rep['return_code'] == 0 and rep['grad_inf'] < 1e-7
+    assert rel_l2(g, ref) <= 0.04
+    assert rel_l2(gs, ref) <= 0.25 and inv._opt_report['return_code'] in (0, 1)
+
+
+def _suite2_setup(stem):
+    """Inverter and fit arguments as Run fits.ipynb builds them (cells 8/10 RC-ZARC, 16/18 DDT, 20 DRT-TpDDT)."""
+    from bayes_drt_amd.inversion import Inverter
+    fam = stem.split('_')[0]
+    sm = 0.005 if 'noiseless' in stem else 0.002
+    if fam == 'RC-ZARC':
+        return (Inverter(basis_freq=1 / (2 * np.pi * np.logspace(-2, 3, 51))), dict(nonneg=True, sigma_min=0.002),
+                np.logspace(np.log10(np.exp(-5)), np.log10(np.exp(5.5)), 200), [('DRT', 'gamma')])
+    if fam in ('BimodalTP-DDT', 'BimodalBP-DDT'):
+        bc = 'transmissive' if 'TP' in fam else 'blocking'
+        inv = Inverter(distributions={'DDT': {'kernel': 'DDT', 'symmetry': 'planar', 'bc': bc, 'dist_type': 'parallel',
+                                              'basis_freq': np.logspace(6, -3, 91)}})
+        return inv, dict(sigma_min=sm), TAU_PLOT, [('DDT', 'gamma')]
+    inv = Inverter(distributions={'DRT': {'kernel': 'DRT', 'basis_freq': np.logspace(6, -2, 81)},
+                                  'TP-DDT': {'kernel': 'DDT', 'symmetry': 'planar', 'bc': 'transmissive', 'dist_type': 'parallel',
+                                             'basis_freq': np.logspace(6, -2, 81), 'x_scale': 0.8}})
+    return inv, dict(nonneg=True, sigma_min=sm), TAU_PLOT, [('DRT', 'gamma'), ('TP-DDT', 'ftp')]
+
+
+# (stem, expected model, bound on the posterior-mean rel-L2 per distribution): measured values in profiles/r03/hmc_suite2.txt,
+# bounds ~2 x them -- the reference's runs are 2 chains x 200 draws, and families whose OWN seed-to-seed scatter is tens of %
+# (trunc, BP-DDT noiseless, Series-2Parallel: profiles/r03/hmc_suite2_scatter.txt) are left to the record
+SUITE2 = [('RC-ZARC_noiseless', 'Series_pos', (0.02,)), ('RC-ZARC_Orazem_0.25', 'Series_pos', (0.03,)),
+          ('BimodalTP-DDT_Macdonald_0.25', 'Parallel', (0.10,)), ('BimodalTP-DDT_uniform_0.25', 'Parallel', (0.12,)),
+          ('BimodalTP-DDT_noiseless', 'Parallel', (0.10,)), ('BimodalBP-DDT_Macdonald_0.05', 'Parallel', (0.10,)),
+          ('DRT-2-TpDDT_uniform_0.25', 'Series-Parallel_pos', (0.06, 0.12)), ('DRT-4-TpDDT_uniform_0.25', 'Series-Parallel_pos', (0.05, 0.10))]
+
+
+@pytest.mark.parametrize('stem,model,bounds', SUITE2)
+def test_other_families_match_the_published_hmc_curves(stem, model, bounds):
+    """The published HMC results of the OTHER model families (tests/golden/hmc_suite2.npz): Series_pos on its own basis,
+    the single parallel diffusion distribution (`Parallel` model -- the family no stored Stan MAP covers: these curves pin it
+    end to end), Series-Parallel_pos.  Posterior means within the stated bounds of the stored curves; tree-depth saturation in
+    the reference's class (pystan's counts from the notebook; e.g. BimodalTP-DDT_uniform_0.25: 71 there, 67 here)."""
+    S = load('hmc_suite2')
+    key = stem.replace('-', '').replace('.', 'p')
+    Zd, G, cols, d = S['Z__' + key], S['G__' + key], [str(c) for c in S['Gcols__' + key]], S['diag__' + key]
+    f, Z = Zd[:, 0], Zd[:, 1] + 1j * Zd[:, 2]
+    inv, kw, tau_plot, dists = _suite2_setup(stem)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        inv.fit(f, Z, mode='sample', warmup=200, samples=200, chains=2, **kw)
+    assert inv.stan_model_name == model + '_StanModel.pkl'
+    fit = inv._sample_result
+    errs = []
+    for (name, col), b in zip(dists, bounds):
+        g = inv.predict_distribution(name, eval_tau=tau_plot)
+        errs.append(rel_l2(g, G[:, cols.index(col)]))
+        assert errs[-1] <= b, (name, errs[-1], b)
+    print('%s [%s]: posterior mean rel-L2 %s; saturated %d (reference %s), divergent %d (reference %s)'
+          % (stem, model, ' '.join('%.4f' % e for e in errs), fit.n_max_treedepth, d[0], fit.n_divergent, d[1]))
+    if not np.isnan(d[0]):
+        if d[0] <= 12:
+            assert fit.n_max_treedepth <= 40
+        elif d[0] >= 380:
+            assert fit.n_max_treedepth >= 190
+        else:
+            assert abs(fit.n_max_treedepth - d[0]) <= 100
+    assert fit.n_divergent <= 20

@@ -36,3 +36,17 @@ for B in (1, 4, 32, 512, 4096, 16384, 65536):
     ms = e0.elapsed_time(e1) / n
     print(json.dumps(dict(B=B, ms=ms, evals_per_s=B / ms * 1e3, tflops=B * FLOP_PER_EVAL / ms * 1e-9,
                           frac_mfma=B * FLOP_PER_EVAL / ms * 1e-9 / 78.6)))
+
+# the same evaluator through the HOST-pointer entry point (bdrt_logp_grad: theta and gradient cross PCIe, B x D x 8 bytes each
+# way, pageable numpy buffers): the rate a caller without device buffers sees; never the benchmark's `value`
+import time
+for B in (4096, 65536):
+    thh = np.random.default_rng(0).uniform(-2, 2, (B, prob.D))
+    sp = np.random.default_rng(1).integers(0, 64, B).astype(np.int32)
+    prob.logp_grad(thh, jacobian=True, spec=sp)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        prob.logp_grad(thh, jacobian=True, spec=sp)
+    dt = (time.perf_counter() - t0) / 5
+    print(json.dumps(dict(B=B, host_pointer_ms=dt * 1e3, evals_per_s_pcie_inclusive=B / dt,
+                          bytes_over_pcie=2 * B * prob.D * 8, pcie_GBps=2 * B * prob.D * 8 / dt / 1e9)))

@@ -36,6 +36,7 @@ fi
 if has map; then
   python tools/map_timing.py > $OUT/map_timing.txt 2>&1
   python tools/map_kat_table.py > $OUT/map_kats.txt 2>&1
+  python tools/map_suite_run.py > $OUT/map_suite.txt 2>&1
   python tools/map_batch_timing.py > $OUT/map_batch_timing.txt 2>&1
   python tools/ridge_timing.py > $OUT/ridge_timing.txt 2>&1
 fi
