@@ -872,6 +872,26 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 // One chain per workgroup (bdrt_solo.h): the same transition logic as nuts_kernel, element j of every vector in thread j,
 // all vectors in LDS.  Global state layout: vecs [n_units][SG_COUNT][ds]; states [n_units].
 // ---------------------------------------------------------------------------------------------------------------------------
+// The part of a chain's scalar state that a leapfrog touches: kept in registers by every thread (identical updates).  The
+// rest (adaptation windows, dual averaging, counters) stays in LDS and is visited when a transition ends or the step size is
+// searched; same member names as ChainState, so the statements of the three samplers read alike.
+struct SoloHot {
+    int phase, iter, depth, leaf, nleaves, dir, n_leap_iter, init_attempt, eps_dir, eps_trials;
+    double eps, H0, lsw, lsw_sub, lps, lpq, sum_metro;
+    __device__ __forceinline__ void from(const ChainState &c)
+    {
+        phase = c.phase; iter = c.iter; depth = c.depth; leaf = c.leaf; nleaves = c.nleaves; dir = c.dir; n_leap_iter = c.n_leap_iter;
+        init_attempt = c.init_attempt; eps_dir = c.eps_dir; eps_trials = c.eps_trials;
+        eps = c.eps; H0 = c.H0; lsw = c.lsw; lsw_sub = c.lsw_sub; lps = c.lps; lpq = c.lpq; sum_metro = c.sum_metro;
+    }
+    __device__ __forceinline__ void to(ChainState &c) const
+    {
+        c.phase = phase; c.iter = iter; c.depth = depth; c.leaf = leaf; c.nleaves = nleaves; c.dir = dir; c.n_leap_iter = n_leap_iter;
+        c.init_attempt = init_attempt; c.eps_dir = eps_dir; c.eps_trials = eps_trials;
+        c.eps = eps; c.H0 = H0; c.lsw = lsw; c.lsw_sub = lsw_sub; c.lps = lps; c.lpq = lpq; c.sum_metro = sum_metro;
+    }
+};
+
 template <int WPE>   // waves per SIMD the register budget allows: 2 = one workgroup per CU, 4 = two (when their LDS fits)
 __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, SoloGeom g)
 {
@@ -883,25 +903,47 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
     const bool own = j < D;                                // this thread owns element j of the D-vectors
     double *Vg = a.vecs + (size_t)blockIdx.x * SG_COUNT * DS;    // global rows
     double *V = smem + g.o_vec;                            // LDS rows
-    auto row = [&](int v) -> double * { return V + (size_t)v * g.DSS; };
+    // WPE 4 (two workgroups per CU): SOLO_NHOT rows in LDS, the others where they are in HBM (each thread touches its own element)
+    constexpr bool TRIM = WPE == 4;
+    auto row = [&](int v) -> double * {
+        if constexpr (!TRIM) return V + (size_t)v * g.DSS;
+        else { const int h = solo_hot_slot(v); return h >= 0 ? V + (size_t)h * g.DSS : Vg + (size_t)v * DS; }
+    };
     double *red = smem + g.o_red;
     double *zrow = smem + g.o_z;
     double *lps_l = smem + g.o_scv + 12;                   // lp of the last evaluation
     int slot = 0;
 
-    ChainState s = a.states[unit];                         // every thread keeps the whole scalar state (identical updates)
-    const Philox rng = {np.seed_lo, np.seed_hi, (uint32_t)s.chain_id};
+    // the chain's scalar state lives in LDS; every thread keeps its hot part in registers (identical updates)
+    ChainState *cold = reinterpret_cast<ChainState *>(smem + g.o_state);
+    if (tid == 0) *cold = a.states[unit];
 #pragma unroll 7
     for (int v = 0; v < SV_COUNT; ++v) {
+        if (TRIM && solo_hot_slot(v) < 0) continue;
         const double x = own ? Vg[(size_t)v * DS + j] : 0.0;
         if (j < g.DSS) row(v)[j] = x;
     }
     solo_eval_init(P, g, smem, tid);
-    const SoloEvalRegs er = solo_eval_setup(P, g, s.spec, tid);
-    double *TH = row(SV_TH), *Pm = row(SV_P), *G = row(SV_G), *MI = row(SV_MINV);
     __syncthreads();
+    SoloHot s;
+    s.from(*cold);
+    const Philox rng = {np.seed_lo, np.seed_hi, (uint32_t)cold->chain_id};
+    const SoloEvalRegs er = solo_eval_setup(P, g, cold->spec, tid);
+    double *TH = row(SV_TH), *Pm = row(SV_P), *G = row(SV_G), *MI = row(SV_MINV);
+    // a statement of the shared scalar logic that needs the whole state: assembled from LDS + registers, run identically by
+    // every thread, written back by one (all threads take this path together: the state is uniform)
+    auto with_full_state = [&](auto fn) {
+        ChainState full = *cold;
+        s.to(full);
+        const int r = fn(full);
+        s.from(full);
+        __syncthreads();
+        if (tid == 0) *cold = full;
+        __syncthreads();
+        return r;
+    };
 
-    if (!s.kicked) {
+    if (!cold->kicked) {
         const int ph = s.phase;
         const double e = ph == PH_EPS ? s.eps : (ph == PH_TREE ? s.dir * s.eps : 0.0);
         if ((ph == PH_INIT || ph == PH_EPS || ph == PH_TREE) && own) {
@@ -909,7 +951,8 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
             Pm[j] = p;
             TH[j] += e * MI[j] * p;
         }
-        s.kicked = 1;
+        __syncthreads();
+        if (tid == 0) cold->kicked = 1;
         __syncthreads();
     }
     unsigned long long my_leaps = 0;
@@ -929,7 +972,7 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
             const double u = rng_uniform(rng, (uint32_t)s.leaf, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
             if (lane == 0) lps_l[1] = u;
         }
-        solo_eval(P, g, smem, TH, G, lps_l, er, 1, tid, prof);
+        solo_eval<WPE == 2 ? 16 : 8>(P, g, smem, TH, G, lps_l, er, 1, tid, prof);
         long long tsp = (prof && tid == 0) ? clock64() : 0;
 #define BDRT_SOLO_NPROF(slot) do { if (prof && tid == 0) { const long long t_ = clock64(); prof[slot] += t_ - tsp; tsp = t_; } } while (0)
 
@@ -971,7 +1014,7 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
             } else if (ph0 == PH_EPS) {
                 // Stan base_hmc::init_stepsize
                 my_leaps += 1;
-                next = nuts_stepsize_trial(s, np, lp, kin);
+                next = with_full_state([&](ChainState &f) { return nuts_stepsize_trial(f, np, lp, kin); });
             } else {   // PH_TREE: one new leaf
                 my_leaps += 1;
                 s.n_leap_iter = s.n_leap_iter + 1;
@@ -1060,7 +1103,7 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
             }
         }
         if (endt) {
-            next = nuts_transition_end(s, np, endt, draw, welf, wend, wn);     // (bdrt_nuts_device.h)
+            next = with_full_state([&](ChainState &f) { return nuts_transition_end(f, np, endt, draw, welf, wend, wn); });     // (bdrt_nuts_device.h)
             if (draw >= 0 && a.lp_draws && tid == 0) a.lp_draws[(size_t)unit * np.n_draws + draw] = s.lps;
         }
 
@@ -1156,9 +1199,11 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
     // ---- write the chain back ---------------------------------------------------------------------------------------------------
     __syncthreads();
     for (int v = 0; v < SV_COUNT; ++v)
-        if (own) Vg[(size_t)v * DS + j] = row(v)[j];
+        if (own && !(TRIM && solo_hot_slot(v) < 0)) Vg[(size_t)v * DS + j] = row(v)[j];
     if (tid == 0) {
-        a.states[unit] = s;
+        ChainState full = *cold;
+        s.to(full);
+        a.states[unit] = full;
         if (my_leaps) atomicAdd(a.leap_counter, my_leaps);
         const int ph = s.phase;
         if (!(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)) atomicAdd(a.done_counter, 1);
@@ -1786,9 +1831,13 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
                                S.np, S.args, S.geom1, S.nhot1);
         else if (S.solo)
         {
-            static const int wpe = getenv("BDRT_SOLO_WPE") ? atoi(getenv("BDRT_SOLO_WPE")) : 2;
-            if (wpe == 4 && 2 * S.lds_bytes <= 160 * 1024)
-                hipLaunchKernelGGL(nuts_solo_kernel<4>, dim3(S.n_solo), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
+            // more chains than CUs: two workgroups per CU (128 VGPRs each, 16 of the chain's rows in LDS) overlap each other's
+            // latencies; with at most one chain per CU the full-LDS variant is the faster one.  BDRT_SOLO_DUO=0 / 1: never / always.
+            const size_t lds2 = ((size_t)S.geom.o_vec + (size_t)SOLO_NHOT * S.geom.DSS) * sizeof(double) + 64;
+            const char *e = getenv("BDRT_SOLO_DUO");
+            const bool duo = 2 * lds2 <= 160 * 1024 && (e ? atoi(e) != 0 : S.n_solo > S.n_cu);
+            if (duo)
+                hipLaunchKernelGGL(nuts_solo_kernel<4>, dim3(S.n_solo), dim3(SOLO_NT), lds2, S.stream, dp, S.np, S.args, S.geom);
             else
                 hipLaunchKernelGGL(nuts_solo_kernel<2>, dim3(S.n_solo), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
         }
