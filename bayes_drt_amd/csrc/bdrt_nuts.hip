@@ -925,22 +925,27 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
     }
     solo_eval_init(P, g, smem, tid);
     __syncthreads();
-    SoloHot s;
-    s.from(*cold);
+    // one workgroup per CU: the whole state in registers (256 VGPRs to spend); two per CU: the hot part only
+    typedef typename std::conditional<WPE == 2, ChainState, SoloHot>::type State;
+    State s;
+    if constexpr (WPE == 2) s = *cold; else s.from(*cold);
     const Philox rng = {np.seed_lo, np.seed_hi, (uint32_t)cold->chain_id};
     const SoloEvalRegs er = solo_eval_setup(P, g, cold->spec, tid);
     double *TH = row(SV_TH), *Pm = row(SV_P), *G = row(SV_G), *MI = row(SV_MINV);
     // a statement of the shared scalar logic that needs the whole state: assembled from LDS + registers, run identically by
     // every thread, written back by one (all threads take this path together: the state is uniform)
     auto with_full_state = [&](auto fn) {
-        ChainState full = *cold;
-        s.to(full);
-        const int r = fn(full);
-        s.from(full);
-        __syncthreads();
-        if (tid == 0) *cold = full;
-        __syncthreads();
-        return r;
+        if constexpr (WPE == 2) return fn(s);
+        else {
+            ChainState full = *cold;
+            s.to(full);
+            const int r = fn(full);
+            s.from(full);
+            __syncthreads();
+            if (tid == 0) *cold = full;
+            __syncthreads();
+            return r;
+        }
     };
 
     if (!cold->kicked) {
@@ -1202,7 +1207,7 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
         if (own && !(TRIM && solo_hot_slot(v) < 0)) Vg[(size_t)v * DS + j] = row(v)[j];
     if (tid == 0) {
         ChainState full = *cold;
-        s.to(full);
+        if constexpr (WPE == 2) { const int k = full.kicked; full = s; full.kicked = k; } else s.to(full);
         a.states[unit] = full;
         if (my_leaps) atomicAdd(a.leap_counter, my_leaps);
         const int ph = s.phase;
@@ -1398,6 +1403,14 @@ __global__ __launch_bounds__(256) void nuts_compact_kernel(const double *vold, c
             for (int j = threadIdx.x; j < ds; j += blockDim.x)
                 dst[((size_t)v * NC + col) * rowlen + j] = src[((size_t)v * NC + ocol) * rowlen + j];
     }
+}
+
+// can two workgroups of the one-chain kernel share a CU for this problem (LDS of the trimmed variant)?
+static bool solo_duo_fits(const DevProblem &P)
+{
+    if (const char *e = getenv("BDRT_SOLO_DUO")) { if (atoi(e) == 0) return false; }
+    const SoloGeom g = solo_geometry(P.nf, P.blk[0].K, P.D);
+    return 2 * (((size_t)g.o_vec + (size_t)SOLO_NHOT * g.DSS) * sizeof(double) + 64) <= 160 * 1024;
 }
 
 // liveness of every unit (1: the chain is still running), for the host's re-packing decision
@@ -1628,7 +1641,9 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, P.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
     }
-    S.solo = solo_capable(P.dev) && n_units <= 4 * n_cu;
+    // (measured at 81 x 161, profiles/r03/solo_duo.txt: one workgroup per CU 30.6 M evals/s, two per CU 42-45 M from 512 units on;
+    //  the 16-chain kernel passes that at ~1300 units)
+    S.solo = solo_capable(P.dev) && n_units <= (solo_duo_fits(P.dev) ? 5 * n_cu : 4 * n_cu);
     S.n_cu = n_cu;
     // a run that starts on the 16-chain kernel may hand its last live chains to the one-chain-per-workgroup kernel
     S.may_migrate = (solo_capable(P.dev) || wide1_capable(P.dev)) && !S.solo;
@@ -1947,10 +1962,10 @@ static int maybe_compact(Sampler &S, int active)
 // nuts_migrate_kernel).  Called between launches with the stream idle.
 static int maybe_migrate_tail(Sampler &S, int active)
 {
-    // the one-chain kernels run one chain per CU at a time, ~4x faster per leapfrog: the LDS-resident one wins below ~4 live
-    // chains per CU, the general one below ~2.5
+    // the one-chain kernels run one or two chains per CU at a time, ~4x faster per leapfrog: the LDS-resident one wins below ~4.75
+    // live chains per CU when two of its workgroups fit a CU (else ~3.5), the general one below ~2.75
     const bool to_solo = solo_capable(S.prob->dev);
-    if (active <= 0 || active > (to_solo ? (7 * S.n_cu) / 2 : (11 * S.n_cu) / 4)) return 0;
+    if (active <= 0 || active > (to_solo ? (solo_duo_fits(S.prob->dev) ? (19 * S.n_cu) / 4 : (7 * S.n_cu) / 2) : (11 * S.n_cu) / 4)) return 0;
     std::vector<ChainState> hs((size_t)S.n_units);
     BDRT_HIP(hipMemcpy(hs.data(), S.args.states, hs.size() * sizeof(ChainState), hipMemcpyDeviceToHost));
     std::vector<int> map;

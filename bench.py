@@ -337,7 +337,7 @@ def main():
     if args.phase_profile and rank == 0:
         cyc = (C.c_longlong * 32)()
         check(lib.bdrt_sampler_phase_profile(smp.handle, 0, cyc), 'phase_profile')
-        if n_units <= 1024:          # the one-chain-per-workgroup kernel (bdrt_solo.h) has its own slots
+        if smp.kind() == 1:          # the one-chain-per-workgroup kernel (bdrt_solo.h) has its own slots
             for k, nm in enumerate(['eval E0 constrain', 'eval E1 A.x + prior', 'eval E2 likelihood + L^T w', 'eval E3 A^T g',
                                     'eval E4 chain rule', 'nuts C kick + kinetic', 'nuts S1 scalar logic', 'nuts D tree / transition end',
                                     "nuts A'/E next point"]):
