@@ -73,6 +73,9 @@ struct Problem {
     int *d_spec = nullptr;
     size_t scratch_rows = 0;
     int ensure_scratch(size_t rows);
+    // launch_logp_grad_few: which one-workgroup-per-point evaluator the problem takes (-1 not looked at yet, 0 none, 1 the
+    // headline family's, 2 the general one), decided once -- the call is launch-latency-bound, host microseconds count
+    int few_kind = -1, few_ncu = 0;
 };
 
 // launch the batched evaluator on device buffers (theta/grad [B x D] row-major)

@@ -43,8 +43,17 @@ __device__ __forceinline__ cplx ctanh_d(cplx z)
         const double e = exp(-2.0 * fabs(z.re));
         return {copysign(1.0, z.re), 4.0 * sin(z.im) * cos(z.im) * e};
     }
-    const double d = cosh(2.0 * z.re) + cos(2.0 * z.im);
-    return {sinh(2.0 * z.re) / d, sin(2.0 * z.im) / d};
+    // Kahan's algorithm (what C's ctanh implements): with t = tan b, beta = 1 + t^2, s = sinh a, rho = sqrt(1 + s^2):
+    // tanh(a + ib) = (beta rho s + i t) / (1 + beta s^2).  sinh from expm1: the device library's sinh(a) is off by up to 2e-9
+    // relative for |a| ~ 1e-8 .. 1e-7 (tools/integrand_probe.hip: (tanh x - x) / x = 1.9e-9 at |x| = 1.4e-8, where it is 6e-17),
+    // which a randomised sweep caught as 6e-11 in a DDT matrix entry dominated by that stretch of the quadrature
+    // (profiles/r03/fuzz_parity.txt, case 3167)
+    const double em = expm1(fabs(z.re));
+    const double sh = copysign(0.5 * (em + em / (em + 1.0)), z.re);
+    const double t = tan(z.im), beta = 1.0 + t * t, rho = sqrt(1.0 + sh * sh);
+    if (isinf(t)) return {rho / sh, 1.0 / t};
+    const double den = 1.0 + beta * sh * sh;
+    return {beta * rho * sh / den, t / den};
 }
 
 // get_basis_func (matrices.py:8-24): gaussian (:12-13), Cole-Cole (:15-17), Zic (:19-21; epsilon unused)
@@ -73,7 +82,18 @@ __device__ __forceinline__ double integrand(double y, double w_n, double t_m, do
     cplx ZD;
     const cplx one = {1.0, 0.0};
     if (kernel == BDRT_KERNEL_DDT_BLOCK_PLANAR) ZD = cdivi(one, cmul(th, x));          // :62-70
-    else if (kernel == BDRT_KERNEL_DDT_BLOCK_SPHER) ZD = cdivi(th, cplx{x.re - th.re, x.im - th.im});  // :74-80
+    else if (kernel == BDRT_KERNEL_DDT_BLOCK_SPHER) {                                   // :74-80: tanh x / (x - tanh x)
+        const double u2 = x.re * x.re + x.im * x.im;
+        if (u2 < 1e-3) {
+            // x - tanh x = x^3/3 - ...: below |x| ~ 1e-5 the difference of the two rounded numbers is zero or noise (the
+            // reference's own values are noise there).  Laurent series 3/x^2 + 1/5 - x^2/175 (next term 2 x^4 / 7875)
+            const cplx xx = cmul(x, x);
+            const cplx inv = cdivi(cplx{3.0, 0.0}, xx);
+            ZD = {inv.re + 0.2 - xx.re * (1.0 / 175.0), inv.im - xx.im * (1.0 / 175.0)};
+        } else {
+            ZD = cdivi(th, cplx{x.re - th.re, x.im - th.im});
+        }
+    }
     else ZD = cdivi(th, x);                                                            // :86-92
     const cplx val = dist_series ? ZD : cdivi(one, ZD);                                 // :97-110
     return phi * (part == 0 ? val.re : val.im);

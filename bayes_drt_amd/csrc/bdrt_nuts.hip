@@ -1215,9 +1215,14 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
     }
 }
 
-// evaluator of the solo path on its own (parity tests): one workgroup per point, theta / grad [B x D] in global memory
-__global__ __launch_bounds__(SOLO_NT) void solo_eval_kernel(const DevProblem *__restrict__ Pp, SoloGeom g, const double *theta,
-                                                            const int *spec, int jacobian, double *lp, double *grad)
+// evaluator of the solo path on its own (few-point batches of bdrt_logp_grad, parity tests): a workgroup per point -- or, with
+// fewer workgroups than points, a grid-stride loop over the points --, theta / grad [B x D] in global memory.  Needs only the
+// evaluator's share of the LDS (solo_eval_lds_bytes), so that three workgroups fit a CU.
+__host__ __device__ inline size_t solo_eval_lds_bytes(const SoloGeom &g) { return ((size_t)g.o_vec + 2 * (size_t)g.DSS) * sizeof(double) + 64; }
+
+// one point per workgroup, nothing else: the form that measured 8.0 us per launch at B = 1 (the grid-stride form below: 9.5)
+__global__ __launch_bounds__(SOLO_NT) void solo_eval_one_kernel(const DevProblem *__restrict__ Pp, SoloGeom g, const double *theta,
+                                                                const int *spec, int jacobian, double *lp, double *grad)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevProblem &P = *Pp;
@@ -1230,6 +1235,27 @@ __global__ __launch_bounds__(SOLO_NT) void solo_eval_kernel(const DevProblem *__
     solo_eval(P, g, smem, TH, GR, lps, er, jacobian, tid);
     if (tid < g.D && grad) grad[(size_t)b * g.D + tid] = GR[tid];
     if (tid == 0 && lp) lp[b] = *lps;
+}
+
+// TIGHT: 80 VGPRs (six waves per SIMD: three workgroups share a CU) for batches of more points than CUs
+template <bool TIGHT>
+__global__ __launch_bounds__(SOLO_NT, TIGHT ? 6 : 2) void solo_eval_kernel(const DevProblem *__restrict__ Pp, SoloGeom g, const double *theta,
+                                                                          const int *spec, int B, int jacobian, double *lp, double *grad)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const DevProblem &P = *Pp;
+    const int tid = threadIdx.x;
+    double *TH = smem + g.o_vec, *GR = TH + g.DSS, *lps = smem + g.o_scv + 12;
+    solo_eval_init(P, g, smem, tid);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        if (tid < g.DSS) { TH[tid] = tid < g.D ? theta[(size_t)b * g.D + tid] : 0.0; GR[tid] = 0.0; }
+        const SoloEvalRegs er = solo_eval_setup(P, g, spec ? spec[b] : 0, tid);
+        __syncthreads();
+        solo_eval<TIGHT ? 8 : 16>(P, g, smem, TH, GR, lps, er, jacobian, tid);
+        if (tid < g.D && grad) grad[(size_t)b * g.D + tid] = GR[tid];
+        if (tid == 0 && lp) lp[b] = *lps;
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1324,15 +1350,17 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
 
 // the general one-chain evaluator (bdrt_solo_wide.h) on its own: one point per workgroup (tests)
 __global__ __launch_bounds__(SOLO_NT) void wide1_eval_kernel(const DevProblem *__restrict__ Pp, Wide1Geom G, const double *theta,
-                                                             const int *spec, int jacobian, double *lp, double *grad)
+                                                             const int *spec, int B, int jacobian, double *lp, double *grad)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevProblem &P = *Pp;
-    const int tid = threadIdx.x, b = blockIdx.x;
+    const int tid = threadIdx.x;
     wide1_init(P, G, smem, tid);
-    const Wide1Regs er = wide1_setup(P, G, spec ? spec[b] : 0, tid);
-    __syncthreads();
-    wide1_eval(P, G, smem, theta + (size_t)b * P.D, grad + (size_t)b * P.D, lp + b, er, jacobian, tid);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {          // (a workgroup per point, or a grid-stride loop over the points)
+        const Wide1Regs er = wide1_setup(P, G, spec ? spec[b] : 0, tid);
+        __syncthreads();
+        wide1_eval(P, G, smem, theta + (size_t)b * P.D, grad + (size_t)b * P.D, lp + b, er, jacobian, tid);
+    }
 }
 
 
@@ -1492,31 +1520,46 @@ int launch_logp_grad_few(Problem *p, const double *d_theta, const int *d_spec, i
     const char *sw = getenv("BDRT_FEW_POINTS");                     // diagnostics / tests: 0 = the tile evaluator whatever B is
     const bool off = sw && atoi(sw) == 0;
     if (off || B < 1 || !d_grad || !d_lp) return 1;
-    const bool solo = solo_capable(P.dev), w1 = !solo && wide1_capable(P.dev);
-    if (!solo && !w1) return 1;
-    BDRT_HIP(hipSetDevice(P.device));
-    static int n_cu[64] = {};
-    int &ncu = n_cu[P.device & 63];
-    if (ncu == 0) {
+    if (P.few_kind < 0) {
+        P.few_kind = solo_capable(P.dev) ? 1 : (wide1_capable(P.dev) ? 2 : 0);
         hipDeviceProp_t prop;
-        ncu = (hipGetDeviceProperties(&prop, P.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        P.few_ncu = (hipGetDeviceProperties(&prop, P.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    // up to one workgroup per CU: beyond that the 16-column tiles win (B = 512: 26 us)
-    if (B > ncu) return 1;
+    if (P.few_kind == 0) return 1;
+    const bool solo = P.few_kind == 1;
+    const int ncu = P.few_ncu;
+    BDRT_HIP(hipSetDevice(P.device));
+    // a few points per CU: beyond that the 16-column tiles win (26 us up to 16 points per CU).  BDRT_FEW_POINTS=n: n points per CU
+    // at most (default 5 for the LDS-light evaluator of the headline family, three workgroups of which share a CU; 1 otherwise)
+    const int per_cu = sw ? atoi(sw) : (solo ? 5 : 1);
+    if (B > per_cu * ncu) return 1;
     static LdsAttrCache attr_solo, attr_w1;
     if (solo) {
         const SoloGeom g = solo_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
-        const size_t lds = (size_t)g.total * sizeof(double) + 64;
-        BDRT_HIP(attr_solo.ensure(lds, [&]() {
-            return hipFuncSetAttribute((const void *)solo_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }));
-        hipLaunchKernelGGL(solo_eval_kernel, dim3(B), dim3(SOLO_NT), lds, stream, (const DevProblem *)P.d_dev, g, d_theta, d_spec,
-                           jacobian, d_lp, d_grad);
+        // The LDS request doubles as a placement hint: the dispatcher packs as many workgroups on a CU as their resources allow
+        // and leaves other CUs idle, so each workgroup asks for its share of a CU -- all of it while there are at most as many
+        // points as CUs (measured: 8.0 us at B = 1 against 9.5 us when three fit), half or a third beyond
+        const int wgs = B <= ncu ? B : std::min(B, 3 * ncu);
+        const int share = std::min(3, (wgs + ncu - 1) / ncu);
+        const size_t lds = std::max(solo_eval_lds_bytes(g), (size_t)(160 * 1024) / share - 2048);
+        const size_t lds_max = (size_t)160 * 1024 - 2048;
+        BDRT_HIP(attr_solo.ensure(lds_max, [&]() {
+            hipError_t e = hipFuncSetAttribute((const void *)solo_eval_one_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)solo_eval_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+            return e; }));
+        if (B <= ncu)
+            hipLaunchKernelGGL(solo_eval_one_kernel, dim3(wgs), dim3(SOLO_NT), (size_t)g.total * sizeof(double) + 64, stream, (const DevProblem *)P.d_dev, g,
+                               d_theta, d_spec, jacobian, d_lp, d_grad);
+        else
+            hipLaunchKernelGGL(solo_eval_kernel<true>, dim3(wgs), dim3(SOLO_NT), lds, stream, (const DevProblem *)P.d_dev, g,
+                               d_theta, d_spec, B, jacobian, d_lp, d_grad);
     } else {
         const Wide1Geom G = wide1_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D, P.dev.nblocks);
         const size_t lds = (size_t)G.total * sizeof(double) + 64;
         BDRT_HIP(attr_w1.ensure(lds, [&]() {
             return hipFuncSetAttribute((const void *)wide1_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }));
-        hipLaunchKernelGGL(wide1_eval_kernel, dim3(B), dim3(SOLO_NT), lds, stream, (const DevProblem *)P.d_dev, G, d_theta, d_spec,
+        const int wgs = std::min(B, 2 * ncu);
+        hipLaunchKernelGGL(wide1_eval_kernel, dim3(wgs), dim3(SOLO_NT), lds, stream, (const DevProblem *)P.d_dev, G, d_theta, d_spec, B,
                            jacobian, d_lp, d_grad);
     }
     BDRT_HIP(hipGetLastError());
@@ -2172,15 +2215,15 @@ int bdrt_debug_solo_logp_grad(bdrt_problem *p, const double *theta, const int *s
     if (!solo_capable(P.dev)) { set_error("problem does not take the solo path"); return -2; }
     BDRT_HIP(hipSetDevice(P.device));
     const SoloGeom g = solo_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
-    const size_t lds = (size_t)g.total * sizeof(double) + 64;
-    BDRT_HIP(hipFuncSetAttribute((const void *)solo_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = solo_eval_lds_bytes(g);
+    BDRT_HIP(hipFuncSetAttribute((const void *)solo_eval_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     double *dth = nullptr, *dlp = nullptr, *dg = nullptr;
     int *dsp = nullptr;
     const size_t nb = (size_t)B * P.dev.D * sizeof(double);
     BDRT_HIP(hipMalloc((void **)&dth, nb)); BDRT_HIP(hipMalloc((void **)&dg, nb)); BDRT_HIP(hipMalloc((void **)&dlp, B * sizeof(double)));
     BDRT_HIP(hipMemcpy(dth, theta, nb, hipMemcpyHostToDevice));
     if (spec) { BDRT_HIP(hipMalloc((void **)&dsp, B * sizeof(int))); BDRT_HIP(hipMemcpy(dsp, spec, B * sizeof(int), hipMemcpyHostToDevice)); }
-    hipLaunchKernelGGL(solo_eval_kernel, dim3(B), dim3(SOLO_NT), lds, 0, (const DevProblem *)P.d_dev, g, dth, dsp, jacobian, dlp, dg);
+    hipLaunchKernelGGL(solo_eval_kernel<false>, dim3(B), dim3(SOLO_NT), lds, 0, (const DevProblem *)P.d_dev, g, dth, dsp, B, jacobian, dlp, dg);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess && lp) e = hipMemcpy(lp, dlp, B * sizeof(double), hipMemcpyDeviceToHost);
@@ -2206,7 +2249,7 @@ int bdrt_debug_wide1_logp_grad(bdrt_problem *p, const double *theta, const int *
     BDRT_HIP(hipMemcpy(dth, theta, nbytes, hipMemcpyHostToDevice));
     BDRT_HIP(hipMemset(dg, 0, nbytes));
     if (spec) { BDRT_HIP(hipMalloc((void **)&dsp, B * sizeof(int))); BDRT_HIP(hipMemcpy(dsp, spec, B * sizeof(int), hipMemcpyHostToDevice)); }
-    hipLaunchKernelGGL(wide1_eval_kernel, dim3(B), dim3(SOLO_NT), lds, 0, (const DevProblem *)P.d_dev, G, dth, dsp, jacobian, dlp, dg);
+    hipLaunchKernelGGL(wide1_eval_kernel, dim3(B), dim3(SOLO_NT), lds, 0, (const DevProblem *)P.d_dev, G, dth, dsp, B, jacobian, dlp, dg);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess && lp) e = hipMemcpy(lp, dlp, B * sizeof(double), hipMemcpyDeviceToHost);
