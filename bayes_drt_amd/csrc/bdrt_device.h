@@ -69,6 +69,9 @@ struct DevProblem {
     int w3;                   // structured path: Lr holds all three w_i buffers (else one buffer, i after i: +4 barriers per block)
     int fast_s1;              // single series block, structured: bdrt_tile_s1.h evaluates it
     int fast_hw;              // any other family on log-uniform grids that fits: bdrt_tile_hw.h evaluates it
+    int toepA;                // fast_s1 and A_re, A_im exactly Toeplitz with nf % 16 <= 2, K % 16 <= 2: the S1 tile's two GEMMs take their
+                              // A operands from a [2][tlen] table in LDS instead of streaming packed fragments from L2 (bdrt_tile_s1.h)
+    int tlen;                 // length of one part of that table: 8 leading zeros, the nf + K - 1 generators, trailing zeros
     int XCR;                  // rows of the x cache (0: exp(theta_x) is recomputed where needed)
     int xc_off[MAXB];         // first cache row of each block
     int dbg;                  // timing ablation only (env BDRT_DEBUG_SKIP): 1 skip forward GEMMs, 2 skip backward GEMM

@@ -249,6 +249,16 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
         D.fast_s1 = (all && dat->nblocks == 1 && !D.blk[0].is_parallel && !D.use_x_sum &&
                      D.blk[0].x_scale == 1.0 && nf <= 128 && D.blk[0].K <= 32 * UK &&
                      s1_lds_doubles(D) <= lds_doubles(D) && !getenv("BDRT_GENERIC_TILE")) ? 1 : 0;
+        // ... and with A_re, A_im exactly Toeplitz (equal log spacing of frequencies and tau) on the shapes of the reference's
+        // default grids (ten points per decade over eight decades: nf = 80..82; K = 80..82 or 160..162), which tile as whole
+        // blocks of 80 plus at most two rows: GEMM operands from an LDS-resident generator table (bdrt_tile_s1.h::toep_gemm)
+        if (D.fast_s1 && D.blk[0].tg && nf / 16 == 5 && nf % 16 <= 2 && (D.blk[0].K / 16) % 5 == 0 && D.blk[0].K >= 80 && D.blk[0].K % 16 <= 2 &&
+            !getenv("BDRT_STREAM_A")) {
+            D.toepA = 1;
+            D.tlen = (8 + nf + D.blk[0].K - 1 + 8 + 1) & ~1;
+            const size_t nj = D.D <= 32 * 11 ? 11 : 16;      // (the sampler's theta rows, bdrt_nuts.hip::nuts_lds_bytes)
+            if ((s1_lds_doubles(D) + (size_t)NC * 32 * nj) * sizeof(double) + SAMPLER_LDS_RESERVE > 160 * 1024) { D.toepA = 0; D.tlen = 0; }
+        }
         // every other family (several distributions, parallel blocks, x_sum prior): the general half-wave evaluator
         bool hw = all && !D.fast_s1 && nf <= 128 && !getenv("BDRT_GENERIC_TILE") &&
                   (hw_lds_doubles(D) + 64) * sizeof(double) + 4096 <= 160 * 1024;
@@ -260,7 +270,7 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
                 nf, dat->nblocks, D.D, D.toep_all, toep_ok[0], dat->nblocks > 1 ? toep_ok[1] : -1, dat->nblocks > 2 ? toep_ok[2] : -1,
                 D.fast_s1, D.fast_hw, D.XR, D.ZR, 1 + D.npar, D.LR, D.XCR, lds_doubles(D) * sizeof(double));
     if (const char *e = getenv("BDRT_DEBUG_SKIP")) D.dbg = atoi(e);
-    P.lds_bytes = std::max(lds_doubles(D), D.fast_hw ? hw_lds_doubles(D) : (size_t)0) * sizeof(double);
+    P.lds_bytes = std::max(std::max(lds_doubles(D), D.fast_hw ? hw_lds_doubles(D) : (size_t)0), D.fast_s1 ? s1_lds_doubles(D) : (size_t)0) * sizeof(double);
     if (P.lds_bytes + SAMPLER_LDS_RESERVE > 160 * 1024) {
         set_error("bdrt_problem_create: problem needs %zu B of LDS per workgroup (+ %zu B of sampler state > 160 KiB): nf=%d, K too large",
                   P.lds_bytes, SAMPLER_LDS_RESERVE, nf);
@@ -289,7 +299,7 @@ static int set_Z(Problem &P, const double *Z, int n_spectra)
     return P.sync_dev();
 }
 
-// MODE 0: dense L path, 1: structured L path (generic tile), 2: fast S1 tile
+// MODE 0: dense L path, 1: structured L path (generic tile), 2: fast S1 tile, 3: general half-wave tile, 4: S1 tile with the A operands from the LDS table
 template <int MODE>
 __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restrict__ Pp, const double *theta, const int *spec, int B,
                                                        int jacobian, double *lp, double *grad, double *params,
@@ -311,7 +321,8 @@ __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restr
     io.sigma_tot = sig ? sig + (size_t)c0 * 2 * P.nf : nullptr;
     io.params = params ? params + (size_t)c0 * P.D : nullptr;
     io.prof = nullptr;
-    if (MODE == 3) logp_grad_tile_hw(P, io, smem);
+    if (MODE == 4) { s1_toep_init(P, smem); logp_grad_tile_s1<false, 32, NoHook, NoHook, true>(P, io, smem); }
+    else if (MODE == 3) logp_grad_tile_hw(P, io, smem);
     else if (MODE == 2) logp_grad_tile_s1<false>(P, io, smem);
     else if (MODE == 1) logp_grad_tile<true>(P, io, smem);
     else logp_grad_tile<false>(P, io, smem);
@@ -348,10 +359,10 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
     BDRT_HIP(hipSetDevice(p->device));
     static LdsAttrCache attr_cache;
     BDRT_HIP(attr_cache.ensure(p->lds_bytes, [&]() {
-        const void *fns[5] = {(const void *)logp_grad_kernel<0>, (const void *)logp_grad_kernel<1>, (const void *)logp_grad_kernel<2>,
-                              (const void *)logp_grad_kernel_wide, (const void *)logp_grad_kernel<3>};
+        const void *fns[6] = {(const void *)logp_grad_kernel<0>, (const void *)logp_grad_kernel<1>, (const void *)logp_grad_kernel<2>,
+                              (const void *)logp_grad_kernel_wide, (const void *)logp_grad_kernel<3>, (const void *)logp_grad_kernel<4>};
         hipError_t e = hipSuccess;
-        for (int i = 0; i < 5 && e == hipSuccess; ++i)
+        for (int i = 0; i < 6 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
         return e;
     }));
@@ -362,6 +373,9 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
                            d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
     else if (p->dev.fast_hw)
         hipLaunchKernelGGL(logp_grad_kernel<3>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
+                           d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
+    else if (p->dev.fast_s1 && p->dev.toepA)
+        hipLaunchKernelGGL(logp_grad_kernel<4>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
                            d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
     else if (p->dev.fast_s1)
         hipLaunchKernelGGL(logp_grad_kernel<2>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,

@@ -84,7 +84,8 @@ struct NutsArgs {
 // NJ = elements of a D-vector per lane (D <= 32*NJ): compile-time so that every pass over a chain's vectors is fully
 // unrolled into a batch of independent loads followed by the arithmetic (one memory round trip per stage instead of one
 // per element -- the state vectors of 2048+ chains live in HBM/MALL, not in L2).
-template <int NJ, int MODE>   // MODE 0: dense L, 1: structured L (generic tile), 2: S1 tile + theta rows in LDS, 3: S1 tile, state in HBM, 4: general half-wave tile
+// TA (MODE 2 only): DevProblem::toepA, the S1 tile's GEMMs take the A operands from the generator table in LDS
+template <int NJ, int MODE, bool TA = false>   // MODE 0: dense L, 1: structured L (generic tile), 2: S1 tile + theta rows in LDS, 3: S1 tile, state in HBM, 4: general half-wave tile
 __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -119,6 +120,8 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     double *V = a.vecs + (size_t)wg * V_COUNT * NC * DS;
     auto row = [&](int v) -> double * { return V + ((size_t)v * NC + c) * DS; };   // this chain's row of vector v
 
+    static_assert(!TA || MODE == 2, "the generator table belongs to the S1 tile");
+    if (TA) s1_toep_init(P, smem);
     if (tid < NC) {
         const int u = su[col_slot(tid)];
         if (u >= 0) sts[tid] = a.states[u];
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     any_next = v;
                 }
             };
-            logp_grad_tile_s1<true, 32, NoHook, decltype(read_flags)>(P, io, smem, NoHook(), read_flags);
+            logp_grad_tile_s1<true, 32, NoHook, decltype(read_flags), TA>(P, io, smem, NoHook(), read_flags);
             load_state();
         }
         else if (MODE == 3) { logp_grad_tile_s1<false>(P, io, smem); load_state(); }
@@ -1825,7 +1828,8 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     static LdsAttrCache attr_cache;
     const hipError_t ae = attr_cache.ensure(S.lds_bytes, [&]() {
-        const void *fns[13] = {(const void *)nuts_kernel<11, 1>, (const void *)nuts_kernel<11, 0>,
+        const void *fns[15] = {(const void *)nuts_kernel<11, 2, true>, (const void *)nuts_kernel<16, 2, true>,
+                               (const void *)nuts_kernel<11, 1>, (const void *)nuts_kernel<11, 0>,
                                (const void *)nuts_kernel<16, 1>, (const void *)nuts_kernel<16, 0>,
                                (const void *)nuts_kernel<27, 1>, (const void *)nuts_kernel<27, 0>,
                                (const void *)nuts_kernel<11, 2>, (const void *)nuts_kernel<16, 2>,
@@ -1836,7 +1840,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
             e = hipFuncSetAttribute((const void *)nuts_solo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)nuts_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
-        for (int i = 0; i < 13 && e == hipSuccess; ++i)
+        for (int i = 0; i < 15 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         return e;
     });
@@ -1899,6 +1903,10 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             else
                 hipLaunchKernelGGL(nuts_solo_kernel<2>, dim3(S.n_solo), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
         }
+        else if (S.use_s1 && S.prob->dev.toepA && S.D <= 32 * 11)
+            hipLaunchKernelGGL((nuts_kernel<11, 2, true>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
+        else if (S.use_s1 && S.prob->dev.toepA)
+            hipLaunchKernelGGL((nuts_kernel<16, 2, true>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
         else if (S.use_s1 && S.D <= 32 * 11)
             hipLaunchKernelGGL((nuts_kernel<11, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
         else if (S.use_s1)

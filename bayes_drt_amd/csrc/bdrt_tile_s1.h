@@ -15,6 +15,7 @@
 // tile by the GPU tests.
 #pragma once
 #include "bdrt_device.h"
+#include <type_traits>
 
 namespace bdrt {
 
@@ -139,18 +140,233 @@ __device__ __forceinline__ void gemm_sw(const double *__restrict__ Mp, int ntile
     }
 }
 
-// the chain's private row as seen by the sampler after a LDSIO evaluation: d lp / d theta in parameter order
-__device__ __forceinline__ double *s1_grad_row(const DevProblem &P, double *smem, int c);
-
 constexpr int RW = 32 * UK + 2 * MAXBW;   // length of a chain's private LDS row (k = 0..191 plus the convolution halo)
 constexpr int NTAP = 2 * MAXBW + 1;
 constexpr int WIN = UK + NTAP - 1;        // 22 values feed the 17-tap convolution of six consecutive k
 
-// LDS: Xs [XR rows][16] | Zh [16*tilesA rows][16] | private rows [16 chains][2 RW]
+// ---- GEMMs with the A operand from an LDS-resident generator table (DevProblem::toepA) -----------------------------------------
+// A_re and A_im are exactly Toeplitz (equal log spacing of the frequencies and of tau): A_part[n][k] = tg[part][n - k + K - 1].
+// The table Tt[part * tlen + 8 + d] = tg[part][d] (zeros in front and behind) replaces the packed fragment stream of gemm_sw:
+//   * nothing streams from L2 during the GEMMs (473 KB per GEMM and workgroup before; the stream ran the MFMA pipe at 70 %:
+//     126 MFMAs of a SIMD took 11.4 k cycles instead of 8.1 k, tools/tile_trace.py);
+//   * any wave can compute any (tile, k-range): the two parts tile separately (81 rows = 5 tiles + 1 row each, the odd rows are
+//     dot products on the VALU while their operands are in registers anyway), 161 = 10 tiles + 1 row likewise, and 10 tiles
+//     spread over the four SIMDs as 2.5 each -- eight whole tiles, two split in halves of the reduction range.  The two
+//     halves of a tile accumulate into zeroed cells with LDS atomics: two contributions commute exactly (0 + a + b = 0 + b + a),
+//     so the result does not depend on their order.
+// Lane l of a wave holds row i = l & 15, reduction index kq = l >> 4 of the A operand, column l & 15 of the B operand.
+__device__ __forceinline__ const double *s1_toep_table(const DevProblem &P, const double *smem)
+{
+    return smem + (size_t)NC * (P.XR + 16 * P.blk[0].tilesA) + (size_t)2 * NC * RW;
+}
+
+// FWD: Os = Zh, rows part * nf + n of (A_part x)[n], Bs = Xs (x, zero from row K on); else Os = Xs, rows k of A^T g, Bs = Zh (g).
+// (nf, K, tlen come from the caller's registers: read from the DevProblem here they are serial scalar-memory round trips right
+// behind the barrier, with every wave of the workgroup waiting and the MFMA pipe idle.)
+//
+// What shapes this routine (tools/ubench/f64_overlap.hip, toep_loop.hip, toep_gemm_probe): an fp64 MFMA occupies the SIMD's
+// VALU for its 64 cycles -- no VALU instruction of either wave issues meanwhile -- so every VALU instruction between two
+// MFMAs is serial time (a first version with 5 pointer increments per 8 MFMAs and ~60 address instructions per piece ran at
+// 82 cycles per MFMA for a wave alone and lost ~900 cycles per piece).  Hence:
+//   * blocks of five quads (1 quad = 16 reduction indices = 4 MFMAs; 80 rows of g / 80 columns of A = one block) with every
+//     operand address an immediate offset from five pointers that are set once per block;
+//   * the lane-dependent parts of all addresses are computed once per call, a block's pointers are those plus a scalar;
+//   * operands are read one quad ahead, behind the first MFMA of the quad before, so that they return in the shadow of the
+//     other three -- across blocks, across the real / imaginary rows of g, and across the pieces of a wave: one pipeline per call.
+// Requires nf / 16 == 5 and K / 16 a multiple of 5 (bdrt_problem_create sets toepA only then).
+#ifndef BDRT_TOEP_STAMP
+#define BDRT_TOEP_STAMP(slot)          // tools/ubench/toep_gemm_probe defines it: cycle stamps inside the routine
+#endif
+template <bool FWD>
+__device__ __forceinline__ void toep_gemm(int nf, int K, int tlen, const double *Tt, const double *Bs, double *Os, int wave, int lane)
+{
+    typedef const __attribute__((address_space(3))) double *lds_cptr;
+    const int i = lane & 15, kq = lane >> 4, col = i;
+    wave = __builtin_amdgcn_readfirstlane(wave);
+    constexpr int TPP = 5;
+    const int r4 = nf & 3;
+    const int T = FWD ? 2 * TPP : (K >> 4);
+    const int base = T & ~7, R = T - base;                 // whole rounds of eight tiles, the tiles beyond
+    const int nqt = FWD ? (K >> 4) : 2 * TPP;              // quads of a whole tile's reduction
+    const bool halves = R > 0 && R <= 4 && nqt % 10 == 0;  // the tiles beyond, each shared by two waves
+    const int npiece = base + (halves ? 2 * R : R);
+    if (wave >= npiece) return;
+    BDRT_TOEP_STAMP(0);
+
+    // ---- lane constants ----
+    // A operand: table position falls by 4 per chunk going forward (the pointer sits 76 below the block's first position, the
+    // lowest one its five quads reach), rises going backward
+    const lds_cptr aL = (lds_cptr)(Tt + (FWD ? i - kq - 76 : kq - i));
+    // B operand rows 4 j + kq (+ 16 per quad: the swizzle repeats); backward: what moves them to the imaginary rows nf + ...
+    lds_cptr bL0 = (lds_cptr)(Bs + swz(kq, col)), bL1 = (lds_cptr)(Bs + swz(4 + kq, col)), bL2 = (lds_cptr)(Bs + swz(8 + kq, col)),
+             bL3 = (lds_cptr)(Bs + swz(12 + kq, col));
+    const int dI0 = FWD ? 0 : swz(nf + kq, col) - swz(kq, col), dI1 = FWD ? 0 : swz(nf + 4 + kq, col) - swz(4 + kq, col),
+              dI2 = FWD ? 0 : swz(nf + 8 + kq, col) - swz(8 + kq, col), dI3 = FWD ? 0 : swz(nf + 12 + kq, col) - swz(12 + kq, col);
+    // backward: the chunk for the rows of g beyond the chunks of four (kq < r4 real, kq < 2 r4 imaginary, the other lanes a zero row)
+    const int mpart = kq >= r4 ? 1 : 0, mn = nf - r4 + kq - mpart * r4;
+    const lds_cptr mL = (lds_cptr)(Tt + mpart * tlen + 8 + mn - i + (K - 1));
+    double Bm = 0.0;
+    if (!FWD && r4) Bm = Bs[swz(kq < 2 * r4 ? mpart * nf + mn : 2 * nf + kq, col)];
+
+    // ---- the piece in flight (uniform) ----
+    int t = 0, half = -1, orow = 0, nblk = 0, nrem = 0, aoff = 0, boff = 0;
+    bool mixed = false;
+    lds_cptr a, b0, b1, b2, b3;
+    // operand buffers: (A2, B2) holds the first quad of a block, the other four alternate between (A0, B0) and (A1, B1) -- the same
+    // registers in every block, whatever follows it
+    double A0[4], B0[4], A1[4], B1[4], A2[4], B2[4], Am = 0.0;
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+
+    auto describe = [&](int sidx) {
+        t = sidx; half = -1;
+        if (sidx >= base && halves) { t = base + ((sidx - base) >> 1); half = (sidx - base) & 1; }
+        if (FWD) {
+            const int part = t >= TPP ? 1 : 0, n0 = 16 * (t - part * TPP);
+            orow = part * nf + n0;
+            const int nch = (K + 3) >> 2, nq = nch >> 2;
+            const int q0 = half == 1 ? nq / 2 : 0, q1 = half == 0 ? nq / 2 : nq;
+            nblk = (q1 - q0) / 5; nrem = half == 0 ? 0 : nch & 3;
+            aoff = part * tlen + 8 + n0 + (K - 1) - 16 * q0;      // position of (row i = 0, kq = 0) of the first chunk
+            boff = 16 * NC * q0;
+            mixed = false;
+        } else {
+            orow = 16 * t;
+            nblk = half < 0 ? 2 : 1; nrem = 0;
+            aoff = 8 - 16 * t + (K - 1); boff = 0;
+            mixed = r4 != 0 && half != 0;
+        }
+    };
+    // pointers of block blk of the piece
+    auto set_ptrs = [&](int blk) {
+        if (FWD) {
+            a = aL + (aoff - 80 * blk);
+            const int o = boff + 80 * NC * blk;
+            b0 = bL0 + o; b1 = bL1 + o; b2 = bL2 + o; b3 = bL3 + o;
+        } else {
+            const bool im = half == 1 || blk == 1;
+            a = aL + (aoff + (im ? tlen : 0));
+            b0 = bL0 + (im ? dI0 : 0); b1 = bL1 + (im ? dI1 : 0); b2 = bL2 + (im ? dI2 : 0); b3 = bL3 + (im ? dI3 : 0);
+        }
+    };
+    // quad r (0..4) of the block
+    auto ld = [&](double (&A)[4], double (&B)[4], auto Rr) {
+        constexpr int r = decltype(Rr)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A[j] = FWD ? a[76 - 16 * r - 4 * j] : a[16 * r + 4 * j];
+        B[0] = b0[16 * NC * r]; B[1] = b1[16 * NC * r]; B[2] = b2[16 * NC * r]; B[3] = b3[16 * NC * r];
+    };
+    typedef std::integral_constant<int, 0> R0;
+    typedef std::integral_constant<int, 1> R1;
+    typedef std::integral_constant<int, 2> R2;
+    typedef std::integral_constant<int, 3> R3;
+    typedef std::integral_constant<int, 4> R4;
+    auto mm = [&](const double (&A)[4], const double (&B)[4], auto &&next) {
+        acc0 = mfma_f64(A[0], B[0], acc0);
+        __builtin_amdgcn_sched_barrier(0);
+        next();
+        __builtin_amdgcn_sched_barrier(0);
+        acc1 = mfma_f64(A[1], B[1], acc1);
+        acc0 = mfma_f64(A[2], B[2], acc0);
+        acc1 = mfma_f64(A[3], B[3], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // five quads; `after` runs behind the first MFMA of the last quad and requests what follows into (A2, B2)
+    auto block = [&](auto &&after) {
+        mm(A2, B2, [&]() { ld(A0, B0, R1()); });
+        mm(A0, B0, [&]() { ld(A1, B1, R2()); });
+        mm(A1, B1, [&]() { ld(A0, B0, R3()); });
+        mm(A0, B0, [&]() { ld(A1, B1, R4()); });
+        mm(A1, B1, after);
+    };
+    // opens piece sidx: its first quad into (A2, B2), the odd chunk's A operand
+    auto open = [&](int sidx) {
+        describe(sidx);
+        set_ptrs(0);
+        ld(A2, B2, R0());
+        if (!FWD && mixed) Am = mL[-16 * t];
+    };
+
+    open(wave);
+    BDRT_TOEP_STAMP(1);
+    for (int sidx = wave; sidx < npiece; sidx += 8) {
+        const bool more = sidx + 8 < npiece;
+        const int o_row = orow, o_half = half, o_nrem = nrem;
+        const bool o_mixed = mixed;
+        const double o_Am = Am;
+        const int nb = nblk;
+        for (int blk = 0; blk < nb; ++blk) {
+            const bool last = blk + 1 == nb;
+            block([&]() {
+                if (!last) { set_ptrs(blk + 1); ld(A2, B2, R0()); }
+                else if (FWD && o_nrem) { set_ptrs(nb); ld(A2, B2, R0()); }      // the chunks beyond the last quad
+                else if (more) open(sidx + 8);
+            });
+        }
+        if (FWD && o_nrem) {
+            double ra[3] = {A2[0], A2[1], A2[2]}, rb[3] = {B2[0], B2[1], B2[2]};
+            acc0 = mfma_f64(ra[0], rb[0], acc0);
+            if (o_nrem > 1) acc1 = mfma_f64(ra[1], rb[1], acc1);
+            if (o_nrem > 2) acc0 = mfma_f64(ra[2], rb[2], acc0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) open(sidx + 8);               // (behind these MFMAs: a short bubble in front of the next piece)
+        }
+        if (!FWD && o_mixed) acc1 = mfma_f64(o_Am, Bm, acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        BDRT_TOEP_STAMP(2 + 3 * (sidx >> 3));
+        const d4 s = acc0 + acc1;
+        BDRT_TOEP_STAMP(3 + 3 * (sidx >> 3));
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            double *o = Os + swz(o_row + kq + 4 * rr, col);
+            if (o_half < 0) *o = s[rr];
+            else __hip_atomic_fetch_add(o, s[rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        acc0 = d4{0.0, 0.0, 0.0, 0.0}; acc1 = d4{0.0, 0.0, 0.0, 0.0};
+        BDRT_TOEP_STAMP(4 + 3 * (sidx >> 3));
+    }
+}
+
+// the output cells of the tiles that two waves share: zero before the GEMM (by all NT threads, any time after the previous
+// reader of those rows and before the barrier in front of the GEMM)
+template <bool FWD>
+__device__ __forceinline__ void toep_zero_split(int nf, int K, double *Os, int tid)
+{
+    const int TPP = nf >> 4, T = FWD ? 2 * TPP : (K >> 4);
+    const int base = T & ~7, R = T - base;
+    if (R == 0 || R > 4 || (FWD ? (K >> 4) : 2 * TPP) % 10 != 0) return;       // (toep_gemm's `halves`)
+    for (int e = tid; e < R * 256; e += NT) {
+        const int t = base + (e >> 8), r = (e >> 4) & 15;
+        const int part = (FWD && t >= TPP) ? 1 : 0;
+        const int row = FWD ? part * nf + 16 * (t - part * TPP) + r : 16 * t + r;
+        Os[row * NC + (e & 15)] = 0.0;
+    }
+}
+
+// once per kernel, all NT threads, ends with a barrier: the generator table, and zeros in the rows of Zh behind the 2 nf
+// rows of g that the backward GEMM's last chunk multiplies for its idle lanes
+__device__ __forceinline__ void s1_toep_init(const DevProblem &P, double *smem)
+{
+    const DevBlock &B = P.blk[0];
+    double *Tt = const_cast<double *>(s1_toep_table(P, smem));
+    double *Zh = smem + (size_t)P.XR * NC;
+    const int glen = P.nf + B.K - 1, tlen = P.tlen;
+    for (int e = threadIdx.x; e < 2 * tlen; e += NT) {
+        const int part = e >= tlen ? 1 : 0, j = e - part * tlen - 8;
+        Tt[e] = (j >= 0 && j < glen) ? B.tg[(size_t)part * glen + j] : 0.0;
+    }
+    for (int e = 2 * P.nf * NC + threadIdx.x; e < 16 * B.tilesA * NC; e += NT) Zh[e] = 0.0;
+    __syncthreads();
+}
+
+// the chain's private row as seen by the sampler after a LDSIO evaluation: d lp / d theta in parameter order
+__device__ __forceinline__ double *s1_grad_row(const DevProblem &P, double *smem, int c);
+
+
+// LDS: Xs [XR rows][16] | Zh [16*tilesA rows][16] | private rows [16 chains][2 RW] | (toepA) generator table [2][tlen]
 __host__ __device__ inline size_t s1_lds_doubles(const DevProblem &P)
 {
     const DevBlock &B = P.blk[0];
-    return (size_t)NC * (P.XR + 16 * B.tilesA) + (size_t)2 * NC * RW;
+    return (size_t)NC * (P.XR + 16 * B.tilesA) + (size_t)2 * NC * RW + (P.toepA ? (size_t)2 * P.tlen : 0);
 }
 
 // Two thread mappings of a chain's K-vectors inside its half-wave:
@@ -172,7 +388,8 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // issue the global loads of the state it needs next, so that their latency hides behind the MFMA work.
 // `after_x_ready` runs right after the first barrier (X of all 16 chains published): the sampler reads the chains' activity
 // flags there -- every wave has finished its previous round by then -- instead of voting at a barrier of its own.
-template <bool LDSIO, int LPC = 32, class Hook = NoHook, class Hook1 = NoHook>
+// TA: DevProblem::toepA -- the caller has run s1_toep_init once in this kernel.
+template <bool LDSIO, int LPC = 32, class Hook = NoHook, class Hook1 = NoHook, bool TA = false>
 __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, double *smem, Hook before_backward = Hook(),
                                          Hook1 after_x_ready = Hook1())
 {
@@ -190,6 +407,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     const int l32 = tid % LPC, hb = lane & (64 - LPC);     // lane within the group, first lane of the group in the wave
     const DevBlock &B = P.blk[0];
     const int nf = P.nf, N2 = 2 * nf, K = B.K, KP = 8 * B.kpairs;
+    const int dbg = P.dbg;                                  // (read once: a scalar load behind each barrier otherwise)
     const bool valid = c < io.nvalid;
     const int cc = valid ? c : 0;
     const double jac = io.jacobian ? 1.0 : 0.0;
@@ -257,6 +475,24 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             wrow[l32] = 0.0; wrow[MAXBW + LPC * UKV + l32] = 0.0;
         }
     }
+    static_assert(!TA || LPC == 32, "the Toeplitz-A GEMMs are written for 512 threads");
+    const double *Tt = TA ? s1_toep_table(P, smem) : nullptr;
+    const int tlen = TA ? P.tlen : 0;
+    if (TA) {
+        // the rows of A_re x and A_im x beyond the full tiles (nf % 16 <= 2 of each part): dot products while x is in registers
+        const int r16 = nf & 15, n0 = nf - r16;
+        for (int j = 0; j < r16; ++j) {
+            double sr = 0.0, si = 0.0;
+#pragma unroll
+            for (int u = 0; u < UKV; ++u) {
+                const int idx = max(8 + n0 + j + (K - 1) - (l32 + LPC * u), 0);     // (x_ is zero from K on)
+                sr = fma(Tt[idx], x_[u], sr); si = fma(Tt[tlen + idx], x_[u], si);
+            }
+            sr = hsum<LPC>(sr); si = hsum<LPC>(si);
+            if (l32 == 0) { Zh[swz(n0 + j, c)] = sr; Zh[swz(nf + n0 + j, c)] = si; }
+        }
+        toep_zero_split<true>(nf, K, Zh, tid);
+    }
     const double d0 = __shfl(sraw, hb | 6), d1 = __shfl(sraw, hb | 7), d2 = __shfl(sraw, hb | 8);
     // priors of the 9 scalars (std_normal on the six raws, inv_gamma(5,5) on the d's) + log-Jacobian: lane j owns scalar j
     if (l32 < 6) lp += -0.5 * sraw * sraw + jac * st;
@@ -270,13 +506,16 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
 #pragma unroll 1
     for (int step = 0; step < 2; ++step) {
     BDRT_S1_TRACE(3 + step);
-    if (step == 0) {   // (swapping the order between the two waves of a SIMD was measured: no gain -- MFMA f64 and VALU f64 share the pipe)
-        if (!(P.dbg & 1)) gemm_sw<NWV, GPFV>(B.Af, B.tilesA, B.kpairs, Xs, Zh, wave, lane);        // Zh = A x  (pad rows come out as exact zeros)
+    if (step == 0) {   // (the other order for the second wave of each SIMD was measured in rounds 2 and 3: B1 -> B2 25.1 k -> 26.1 k cycles -- MFMA f64 and VALU f64 share the pipe)
+        if (!(dbg & 1)) {
+            if (TA) toep_gemm<true>(nf, K, tlen, Tt, Xs, Zh, wave, lane);
+            else gemm_sw<NWV, GPFV>(B.Af, B.tilesA, B.kpairs, Xs, Zh, wave, lane);                // Zh = A x  (pad rows come out as exact zeros)
+        }
         continue;
     }
 
     // ---- P2 (M2): v_i = L_i x, q / ups / dups priors, w_i, sum_i L_i^T w_i -- all on this chain's private rows -------------
-    if (!(P.dbg & 4)) {
+    if (!(dbg & 4)) {
         const int kb = UKV * l32;                                        // first k of this lane
         double xw[WINV], tuc[UKV];
 #pragma unroll
@@ -402,10 +641,14 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     const double Rinf = 100.0 * __shfl(sraw, hb | 0), induc = __shfl(sraw, hb | 1) * P.induc_scale;
     const double s_res = 0.05 * __shfl(sraw, hb | 2), a_p = 0.05 * __shfl(sraw, hb | 3), a_r = 0.05 * __shfl(sraw, hb | 4),
                  a_i = 0.05 * __shfl(sraw, hb | 5);
-    if (!(P.dbg & 8)) {
+    if (!(dbg & 8)) {
         const double c0 = P.sigma_min * P.sigma_min + s_res * s_res;
         const double ap2 = a_p * a_p, ar2 = a_r * a_r, ai2 = a_i * a_i;
         double sR = 0, sL = 0, sH = 0, sHz2 = 0, sHzr2 = 0, sHzi2 = 0;
+        // TA: the rows k >= 16 (K / 16) of A^T g (K % 16 <= 2 of them) are dot products with g while it is in registers
+        const int rk = TA ? (K & 15) : 0;
+        double lk0 = 0.0, lk1 = 0.0;
+        if (TA) toep_zero_split<false>(nf, K, Xs, tid);
 #pragma unroll
         for (int v = 0; v < UNV; ++v) {
             const int n = l32 + LPC * v;
@@ -435,6 +678,10 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             const double gzi = e_im * w_im + 2.0 * zi * (h_im * (ap2 + ai2) + h_re * ai2);
             Zh[swz(n, c)] = gzr;
             Zh[swz(nf + n, c)] = gzi;
+            if (TA && rk > 0) {            // A_part[n][K - rk + j] = tg[part][n + rk - 1 - j]
+                lk0 = fma(Tt[8 + n + rk - 1], gzr, fma(Tt[tlen + 8 + n + rk - 1], gzi, lk0));
+                if (rk > 1) lk1 = fma(Tt[8 + n + rk - 2], gzr, fma(Tt[tlen + 8 + n + rk - 2], gzi, lk1));
+            }
             sR += gzr;
             sL += gzi * wn;
             sH += h_re + h_im;
@@ -459,6 +706,11 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             }
         }
         sR = hsum<LPC>(sR); sL = hsum<LPC>(sL); sH = hsum<LPC>(sH); sHz2 = hsum<LPC>(sHz2); sHzr2 = hsum<LPC>(sHzr2); sHzi2 = hsum<LPC>(sHzi2);
+        if (TA && rk > 0) {
+            lk0 = hsum<LPC>(lk0);
+            if (rk > 1) lk1 = hsum<LPC>(lk1);
+            if (l32 == 0) { Xs[swz(K - rk, c)] = lk0; if (rk > 1) Xs[swz(K - rk + 1, c)] = lk1; }
+        }
         if (l32 < 6) {
             // d lp / d(raw), likelihood part, of Rinf_raw, induc_raw, sigma_res_raw, alpha_prop/re/im_raw (lane j owns scalar j)
             double dl;
@@ -478,7 +730,10 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     BDRT_S1_TRACE(8);
     BDRT_S1_PROF(4);
     before_backward();
-    if (!(P.dbg & 2)) gemm_sw<NWV, GPFV>(B.BkA, B.tilesK, B.rpairsA, Zh, Xs, wave, lane);          // Xs = A^T g_Zhat
+    if (!(dbg & 2)) {
+        if (TA) toep_gemm<false>(nf, K, tlen, Tt, Zh, Xs, wave, lane);
+        else gemm_sw<NWV, GPFV>(B.BkA, B.tilesK, B.rpairsA, Zh, Xs, wave, lane);                    // Xs = A^T g_Zhat
+    }
     BDRT_S1_TRACE(9);
     __syncthreads();                                                   // B4
     BDRT_S1_TRACE(10);
