@@ -65,7 +65,7 @@ class ChainDiag(C.Structure):
 # every symbol include/bdrt.h declares (tests/test_abi.py checks the library exports each of them)
 SYMBOLS = [
     'bdrt_build_A', 'bdrt_build_A_basis', 'bdrt_build_L', 'bdrt_build_L_rect', 'bdrt_build_M',
-    'bdrt_problem_create', 'bdrt_problem_destroy', 'bdrt_num_params', 'bdrt_param_is_pos', 'bdrt_problem_set_Z',
+    'bdrt_problem_create', 'bdrt_problem_destroy', 'bdrt_num_params', 'bdrt_problem_evaluator', 'bdrt_param_is_pos', 'bdrt_problem_set_Z',
     'bdrt_logp_grad', 'bdrt_logp_grad_dev', 'bdrt_transformed',
     'bdrt_opt_defaults', 'bdrt_optimize',
     'bdrt_nuts_defaults', 'bdrt_sampler_create', 'bdrt_sampler_destroy', 'bdrt_sampler_advance', 'bdrt_sampler_sync',
@@ -126,6 +126,8 @@ def load_library():
     lib.bdrt_problem_destroy.argtypes = [vp]
     lib.bdrt_problem_destroy.restype = None
     lib.bdrt_num_params.argtypes = [vp]
+    lib.bdrt_problem_evaluator.argtypes = [vp]
+    lib.bdrt_problem_evaluator.restype = C.c_int
     lib.bdrt_param_is_pos.argtypes = [vp, vp]
     lib.bdrt_problem_set_Z.argtypes = [vp, vp, C.c_int]
     lib.bdrt_logp_grad.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]

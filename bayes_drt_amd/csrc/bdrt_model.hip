@@ -438,6 +438,12 @@ void bdrt_problem_destroy(bdrt_problem *p)
 }
 
 int bdrt_num_params(const bdrt_problem *p) { return p ? p->impl.dev.D : -1; }
+int bdrt_problem_evaluator(const bdrt_problem *p)
+{
+    if (!p) return -1;
+    const bdrt::DevProblem &D = p->impl.dev;
+    return D.fast_hw ? 3 : (D.fast_s1 ? (D.toepA ? 4 : 2) : (D.toep_all ? 1 : 0));
+}
 
 int bdrt_param_is_pos(const bdrt_problem *p, unsigned char *is_pos)
 {

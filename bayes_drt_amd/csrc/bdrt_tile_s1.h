@@ -497,16 +497,24 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     // priors of the 9 scalars (std_normal on the six raws, inv_gamma(5,5) on the d's) + log-Jacobian: lane j owns scalar j
     if (l32 < 6) lp += -0.5 * sraw * sraw + jac * st;
     else if (l32 < 9) lp += -6.0 * st - 5.0 / sraw + jac * st;
-    BDRT_S1_TRACE(1);
-    __syncthreads();                                                   // B1: X of all 16 chains in the operand tile
-    after_x_ready();
-    BDRT_S1_TRACE(2);
-    BDRT_S1_PROF(1);
-    // MFMA part, then the VALU part of this phase (the prior chain does not depend on A x, so no barrier in between).
+    // The prior chain x -> L x -> w -> L^T w (P2) needs neither A x nor the other chains: it runs BEFORE the first barrier.  In the
+    // sampler the waves reach this evaluation at different times (their chains close sub-trees of different depth); a wave
+    // that is early spends the wait on its P2 -- VALU work that fills the issue slots the late waves' memory-bound bookkeeping
+    // leaves -- instead of idling at B1 and then sharing the fp64 pipe with the forward GEMM (an fp64 MFMA occupies the SIMD's VALU
+    // for its 64 cycles: MFMA and VALU work add up, whatever the order; tools/ubench/f64_overlap.hip).
+#ifndef BDRT_EARLY_P2
+#define BDRT_EARLY_P2 1
+#endif
+    constexpr bool EARLY_P2 = BDRT_EARLY_P2 != 0;
 #pragma unroll 1
     for (int step = 0; step < 2; ++step) {
-    BDRT_S1_TRACE(3 + step);
-    if (step == 0) {   // (the other order for the second wave of each SIMD was measured in rounds 2 and 3: B1 -> B2 25.1 k -> 26.1 k cycles -- MFMA f64 and VALU f64 share the pipe)
+    if (EARLY_P2 ? step == 1 : step == 0) {
+        BDRT_S1_TRACE(1);
+        __syncthreads();                                               // B1: X of all 16 chains in the operand tile
+        after_x_ready();
+        BDRT_S1_TRACE(2);
+        BDRT_S1_PROF(1);
+        BDRT_S1_TRACE(3);
         if (!(dbg & 1)) {
             if (TA) toep_gemm<true>(nf, K, tlen, Tt, Xs, Zh, wave, lane);
             else gemm_sw<NWV, GPFV>(B.Af, B.tilesA, B.kpairs, Xs, Zh, wave, lane);                // Zh = A x  (pad rows come out as exact zeros)
@@ -515,6 +523,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     }
 
     // ---- P2 (M2): v_i = L_i x, q / ups / dups priors, w_i, sum_i L_i^T w_i -- all on this chain's private rows -------------
+    BDRT_S1_TRACE(4);
     if (!(dbg & 4)) {
         const int kb = UKV * l32;                                        // first k of this lane
         double xw[WINV], tuc[UKV];

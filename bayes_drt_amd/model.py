@@ -67,6 +67,11 @@ class Problem:
         check(lib.bdrt_param_is_pos(self.handle, ptr(pos)), 'bdrt_param_is_pos')
         self.is_pos = pos.astype(bool)
 
+    def evaluator(self):
+        """Which tile evaluator the problem was given (bdrt_problem_evaluator, include/bdrt.h): 0 dense L, 1 banded L, 2 one-block
+        fast tile, 3 general half-wave tile, 4 one-block fast tile with the A operands from the LDS-resident Toeplitz table."""
+        return check(self._lib.bdrt_problem_evaluator(self.handle), 'bdrt_problem_evaluator')
+
     # layout of the unconstrained vector (Stan declaration order, include/bdrt.h)
     def layout(self):
         o = 2

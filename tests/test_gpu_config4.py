@@ -12,8 +12,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_config4_full_size_draws_match_oracle_and_summaries_match_numpy():
+@pytest.mark.parametrize('operands', ['table', 'streamed'])
+def test_config4_full_size_draws_match_oracle_and_summaries_match_numpy(operands, monkeypatch):
+    """operands: the A operands of the evaluator's GEMMs from the Toeplitz generator table in LDS (the default for this shape) or
+    streamed as packed fragments from L2 (BDRT_STREAM_A=1, the path of every other shape)."""
     import bench
+    if operands == 'streamed': monkeypatch.setenv('BDRT_STREAM_A', '1')
+    else: monkeypatch.delenv('BDRT_STREAM_A', raising=False)
     from bayes_drt_amd import _lib
     from bayes_drt_amd.engine import Sampler
     from bayes_drt_amd.model import Problem
@@ -24,6 +29,7 @@ def test_config4_full_size_draws_match_oracle_and_summaries_match_numpy():
     blocks, Z, freq = kw.pop('blocks'), kw.pop('Z'), kw.pop('freq')
     prob = Problem(blocks, Z, freq, **kw)
     assert prob.D == 331 and Z.shape == (512, 162)
+    assert prob.evaluator() == (4 if operands == 'table' else 2)
     spec, chain = make_units(bench.N_SPECTRA, bench.CHAINS_PER_SPECTRUM)
     ctrl = _lib.NutsControl(); lib.bdrt_nuts_defaults(C.byref(ctrl))
     ctrl.adapt_delta, ctrl.adapt_t0, ctrl.max_treedepth = 0.9, 10.0, 5

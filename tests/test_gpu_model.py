@@ -60,6 +60,46 @@ def test_benchmark_shape_vs_oracle(mode, B):
     _compare(prob, om, thetas, mode != 'sample')
 
 
+@pytest.mark.parametrize('tag,K', [('K161', 161), ('K81', 81)])
+def test_both_operand_paths_of_the_one_block_tile(tag, K, monkeypatch):
+    """81 x 161 and 81 x 81 on log-uniform grids: the GEMMs take their A operands from the Toeplitz generator table in LDS
+    (evaluator 4); BDRT_STREAM_A=1 pins the streamed fragments (evaluator 2).  Both against the oracle, and against each other."""
+    Problem, orc = _mods()
+    d, blk, kw = _bench_blocks('sample', tag)
+    om = orc.OracleModel([blk], d['Z'], d['freq'], **kw)
+    rng = np.random.default_rng(K)
+    thetas = rng.uniform(-2, 2, (37, om.D))
+    out = {}
+    for stream in ('0', '1'):
+        if stream == '1': monkeypatch.setenv('BDRT_STREAM_A', '1')
+        else: monkeypatch.delenv('BDRT_STREAM_A', raising=False)
+        prob = Problem([blk], d['Z'], d['freq'], **kw)
+        assert prob.evaluator() == (2 if stream == '1' else 4)
+        for jac in (True, False):
+            _compare(prob, om, thetas, jac)
+        out[stream] = prob.logp_grad(thetas, jacobian=True)
+    assert np.max(np.abs(out['0'][0] - out['1'][0]) / np.maximum(1.0, np.abs(out['1'][0]))) < 1e-11
+    assert np.max(np.abs(out['0'][1] - out['1'][1])) <= 1e-11 * max(1.0, np.max(np.abs(out['1'][1])))
+    assert not np.array_equal(out['0'][1], out['1'][1])          # (another summation order: the switch did switch)
+
+
+def test_shapes_beside_the_table_path_keep_the_streamed_fragments():
+    """nf = 41 / K = 51 (not blocks of 80): one of the evaluators that stream the packed fragments, not 4."""
+    Problem, orc = _mods()
+    from bayes_drt_amd import matrices as gm
+    f = np.logspace(5, 1, 41)
+    bf = np.logspace(6, 1, 51); tau = 1 / (2 * np.pi * bf); eps = 1 / np.mean(np.diff(np.log(tau)))
+    A = np.vstack([gm.construct_A(f, 'real', tau=tau, epsilon=eps), gm.construct_A(f, 'imag', tau=tau, epsilon=eps)])
+    L = [gm.construct_L(bf, tau=tau, epsilon=eps, order=o) for o in (0, 1, 2)]
+    rng = np.random.default_rng(5)
+    Z = rng.standard_normal(82)
+    blk = dict(A=A, L0=L[0], L1=L[1], L2=L[2], nonneg=True)
+    prob = Problem([blk], Z, f, ups_alpha=1.0, ups_beta=0.1)
+    assert prob.evaluator() in (2, 3)
+    om = orc.OracleModel([blk], Z, f, ups_alpha=1.0, ups_beta=0.1)
+    _compare(prob, om, rng.uniform(-2, 2, (9, prob.D)), True)
+
+
 def test_signed_x_series():
     Problem, orc = _mods()
     d, blk, kw = _bench_blocks('sample', 'K81')
