@@ -94,6 +94,69 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// ---- lean elementary functions for the evaluators' inner loops -----------------------------------------------------------------------
+// On this machine every VALU instruction of the sampler's round is issue time on the SIMD's one fp64 pipe, and
+// the device library's exp / log / IEEE division spend a third of theirs on range and special-case handling that the evaluator's
+// arguments never need.  Accuracy (tests/test_gpu_lean_math.py, against numpy on 1e6 arguments per function): <= 1.5 ulp.
+// Arguments outside the stated domains give a non-finite or inaccurate value, never a trap; the evaluators' callers treat a
+// non-finite log-posterior the same way whatever produced it.
+
+// 1 / b for finite, normal b != 0 (|b| in [1e-300, 1e300]): hardware estimate + two Newton steps; 5 instructions against the 11
+// of the IEEE-exact quotient.  b = 0, inf: NaN (the quotient: inf, 0).
+__device__ __forceinline__ double lean_rcp(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+// exp(x) for finite x: n = rint(x / ln 2), r = x - n ln 2 in two steps (Cody-Waite), e^r by the degree-13 Taylor polynomial
+// (|r| <= 0.3466: truncation 6e-18 relative), 2^n by v_ldexp_f64, which overflows to inf and underflows towards 0 by itself.
+// 19 instructions against 28.  x = +-inf: NaN.
+__device__ __forceinline__ double lean_exp(double x)
+{
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821614599e-10;                 // 1/13!
+    p = __builtin_fma(p, r, 2.0876756987868098979e-09);   // 1/12!
+    p = __builtin_fma(p, r, 2.5052108385441718775e-08);   // 1/11!
+    p = __builtin_fma(p, r, 2.7557319223985890653e-07);   // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985892511e-06);   // 1/9!
+    p = __builtin_fma(p, r, 2.4801587301587301566e-05);   // 1/8!
+    p = __builtin_fma(p, r, 1.9841269841269841253e-04);   // 1/7!
+    p = __builtin_fma(p, r, 1.3888888888888889419e-03);   // 1/6!
+    p = __builtin_fma(p, r, 8.3333333333333332177e-03);   // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664354e-02);   // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666665741e-01);   // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+
+// log(x) for finite, normal x > 0: x = 2^e m with m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f),
+// log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with the classic degree-7 polynomial in s^2 (fdlibm's e_log.c coefficients, error
+// of the approximation < 2^-58.45), log x = e ln2_hi + (log(1 + f) + e ln2_lo).  ~33 instructions against 58.
+__device__ __forceinline__ double lean_log(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = f * lean_rcp(2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                                         2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t1 + t2, hfsq = 0.5 * f * f, de = (double)e;
+    return __builtin_fma(de, 6.93147180369123816490e-01, f - (hfsq - __builtin_fma(s, hfsq + R, de * 1.90821492927058770002e-10)));
+}
+
 // Sum over the 32 lanes of a half-wave, result in every lane.  Four of the five butterfly steps are DPP moves on the VALU
 // (quad xor 1, quad xor 2, row_half_mirror, row_mirror: any pairing of equal partial sums will do), only the step across
 // the two 16-lane rows needs the LDS crossbar (ds_swizzle, no address register).  The plain __shfl_xor butterfly is five

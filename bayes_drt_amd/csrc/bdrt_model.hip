@@ -390,6 +390,14 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
     return 0;
 }
 
+// debug / tests only: the lean elementary functions of bdrt_device.h on n values (out: [3][n] = exp, log, reciprocal)
+__global__ void lean_math_kernel(const double *x, int n, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = lean_exp(x[i]); out[n + i] = lean_log(x[i]); out[2 * (size_t)n + i] = lean_rcp(x[i]);
+}
+
 }  // namespace bdrt
 
 using namespace bdrt;
@@ -474,6 +482,20 @@ static int check_spec(Problem &P, const int *spec, int B)
 int bdrt_debug_set_tile_trace(void *d_buf)
 {
     BDRT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace), &d_buf, sizeof(void *)));
+    return 0;
+}
+
+int bdrt_debug_lean_math(const double *x, int n, double *out)
+{
+    if (!x || !out || n < 1) { set_error("bdrt_debug_lean_math: bad arguments"); return -1; }
+    bind_process_device();
+    double *dx = nullptr, *dout = nullptr;
+    BDRT_HIP(hipMalloc((void **)&dx, (size_t)n * sizeof(double)));
+    BDRT_HIP(hipMalloc((void **)&dout, (size_t)3 * n * sizeof(double)));
+    BDRT_HIP(hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(lean_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, dout);
+    BDRT_HIP(hipMemcpy(out, dout, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(dout);
     return 0;
 }
 

@@ -439,7 +439,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         if (l32 < 2) j = l32;
         else if (l32 < 6) j = P.o_err + (l32 - 2);
         else if (l32 < 9) j = B.o_d + (l32 - 6);
-        if (j >= 0) { st = TH(j); sraw = exp(st); PW(j, sraw); }
+        if (j >= 0) { st = TH(j); sraw = lean_exp(st); PW(j, sraw); }
     }
     double lp = 0.0;
     double x_[UKV];
@@ -455,7 +455,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         // materialised once for the six evaluations instead of once per predicated block
         double ex_[UKV];
 #pragma unroll
-        for (int u = 0; u < UKV; ++u) ex_[u] = exp(tx_[u]);
+        for (int u = 0; u < UKV; ++u) ex_[u] = lean_exp(tx_[u]);
 #pragma unroll
         for (int u = 0; u < UKV; ++u) {
             const int k = l32 + LPC * u;
@@ -495,8 +495,9 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     }
     const double d0 = __shfl(sraw, hb | 6), d1 = __shfl(sraw, hb | 7), d2 = __shfl(sraw, hb | 8);
     // priors of the 9 scalars (std_normal on the six raws, inv_gamma(5,5) on the d's) + log-Jacobian: lane j owns scalar j
+    const double israw5 = 5.0 * lean_rcp(sraw);                        // (meaningful in lanes 6..8: 5 / d_i)
     if (l32 < 6) lp += -0.5 * sraw * sraw + jac * st;
-    else if (l32 < 9) lp += -6.0 * st - 5.0 / sraw + jac * st;
+    else if (l32 < 9) lp += -6.0 * st - israw5 + jac * st;
     // The prior chain x -> L x -> w -> L^T w (P2) needs neither A x nor the other chains: it runs BEFORE the first barrier.  In the
     // sampler the waves reach this evaluation at different times (their chains close sub-trees of different depth); a wave
     // that is early spends the wait on its P2 -- VALU work that fills the issue slots the late waves' memory-bound bookkeeping
@@ -549,7 +550,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         // ups of k-2 .. k+7 around the lane's six k: own registers plus two values from each neighbouring lane
         double ue[UKV + 4], ie[UKV + 2];                                 // ups of k-2..k+7, 1/ups of k-1..k+6
 #pragma unroll
-        for (int u = 0; u < UKV; ++u) { ue[u + 2] = 0.15 * exp(tuc[u]); ie[u + 1] = 1.0 / ue[u + 2]; }
+        for (int u = 0; u < UKV; ++u) { ue[u + 2] = 0.15 * lean_exp(tuc[u]); ie[u + 1] = lean_rcp(ue[u + 2]); }
         {
             const int lo = hb | ((l32 + LPC - 1) & (LPC - 1)), hi = hb | ((l32 + 1) & (LPC - 1));
             ue[0] = __shfl(ue[UKV], lo); ue[1] = __shfl(ue[UKV + 1], lo);
@@ -624,7 +625,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         sv0 = hsum<LPC>(sv0); sv1 = hsum<LPC>(sv1); sv2 = hsum<LPC>(sv2);
         if (l32 >= 6 && l32 < 9) {                                       // d_i gradients: lane 6+i
             const double sv = l32 == 6 ? sv0 : (l32 == 7 ? sv1 : sv2);
-            gsc = -0.5 * sraw * sv - 6.0 + 5.0 / sraw + jac;
+            gsc = -0.5 * sraw * sv - 6.0 + israw5 + jac;
             GW(B.o_d + (l32 - 6), gsc);
         }
     }
@@ -669,7 +670,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             double so_re = 0.0, so_im = 0.0, r0 = 0.0, r1 = 0.0, t0 = 0.0, t1 = 0.0;
             if (P.outlier_mode) {
                 t0 = TH(P.o_so + n); t1 = TH(P.o_so + nf + n);
-                r0 = exp(t0); r1 = exp(t1);
+                r0 = lean_exp(t0); r1 = lean_exp(t1);
                 PW(P.o_so + n, r0); PW(P.o_so + nf + n, r1);
                 if (P.outlier_mode == 1) so_re = so_im = 0.05 * r0 * r1;
                 else { so_re = 0.05 * r0; so_im = 0.05 * r1; }
@@ -678,9 +679,9 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             const double s2_re = c0 + ap2 * zr * zr + common + so_re * so_re;
             const double s2_im = c0 + ap2 * zi * zi + common + so_im * so_im;
             const double e_re = zre_[v] - zr, e_im = zim_[v] - zi;
-            const double prod = s2_re * s2_im, ip = 1.0 / prod;       // one reciprocal and one logarithm per (re, im) pair
+            const double prod = s2_re * s2_im, ip = lean_rcp(prod);       // one reciprocal and one logarithm per (re, im) pair
             const double w_re = s2_im * ip, w_im = s2_re * ip;
-            lp += -0.5 * log(prod) - 0.5 * e_re * e_re * w_re - 0.5 * e_im * e_im * w_im;
+            lp += -0.5 * lean_log(prod) - 0.5 * e_re * e_re * w_re - 0.5 * e_im * e_im * w_im;
             const double h_re = -0.5 * w_re + 0.5 * e_re * e_re * w_re * w_re;
             const double h_im = -0.5 * w_im + 0.5 * e_im * e_im * w_im * w_im;
             const double gzr = e_re * w_re + 2.0 * zr * (h_re * (ap2 + ar2) + h_im * ar2);
