@@ -148,9 +148,9 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
     if (sidx >= 0 && sidx < nsc) {
         sj = sidx < 2 ? sidx : (sidx < 6 ? P.o_err + (sidx - 2) : P.blk[(sidx - 6) / 3].o_d + (sidx - 6) % 3);
         const double st = TH[sj];
-        sraw = exp(st);
+        sraw = lean_exp(st);
         scv[sidx] = sraw;
-        lp += (sidx < 6 ? -0.5 * sraw * sraw : -6.0 * st - 5.0 / sraw) + jac * st;
+        lp += (sidx < 6 ? -0.5 * sraw * sraw : -6.0 * st - 5.0 * lean_rcp(sraw)) + jac * st;
     }
     double xv[W1_MAXB], gupv[W1_MAXB];                     // x_k and d lp / d theta_ups_k of this thread's k, per block
     double xsum_p = 0.0;
@@ -166,9 +166,9 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
         if (tid < K) {
             const double tx = TH[B.o_x + tid];
             tu = TH[B.o_ups + tid];
-            const double x = B.is_pos ? exp(tx) : tx;
+            const double x = B.is_pos ? lean_exp(tx) : tx;
             if (B.is_pos) lp += jac * tx;
-            uu = 0.15 * exp(tu);
+            uu = 0.15 * lean_exp(tu);
             xv[b] = x;
             xsum_p += x;
             xr[MAXBW + tid] = x;
@@ -234,7 +234,7 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             }
             const double d0 = scv[6 + 3 * b], d1 = scv[7 + 3 * b], d2 = scv[8 + 3 * b];
             const double um2 = us[k], um1 = us[k + 1], up1 = us[k + 3], up2 = us[k + 4];
-            const double iu = 1.0 / uu, iu2 = iu * iu;
+            const double iu = lean_rcp(uu), iu2 = iu * iu;
             const double q2 = d0 * v0 * v0 + d1 * v1 * v1 + d2 * v2 * v2;
             const double ir = 0.15 * iu;                   // 1 / ups_raw
             lp += -(tu + LOG_015) - 0.5 * q2 * iu2 - (P.ups_alpha + 1.0) * tu - P.ups_beta * ir + jac * tu;
@@ -246,12 +246,12 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
                 gu += -du * 0.25 * (um1 + up1) * iu2;
             }
             if (k >= 2) {
-                const double i0 = 1.0 / um1;
+                const double i0 = lean_rcp(um1);
                 const double du = 0.5 * (um1 - 0.5 * (um2 + uu)) * i0;
                 gu += du * 0.25 * i0;
             }
             if (k + 2 < K) {
-                const double i0 = 1.0 / up1;
+                const double i0 = lean_rcp(up1);
                 const double du = 0.5 * (up1 - 0.5 * (uu + up2)) * i0;
                 gu += du * 0.25 * i0;
             }
@@ -302,7 +302,7 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
                 const double yr = yb[b * 2 * g.NFP + n], yi = yb[b * 2 * g.NFP + g.NFP + n];
                 if (!P.blk[b].is_parallel) { zr += yr; zi += yi; }
                 else {
-                    const double idn = 1.0 / (yr * yr + yi * yi);
+                    const double idn = lean_rcp(yr * yr + yi * yi);
                     zr += yr * idn;                        // Z_hat_p = conj(Y) / |Y|^2 (Parallel_modelcode.txt:47)
                     zi += -yi * idn;
                 }
@@ -313,7 +313,7 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             double so_re = 0.0, so_im = 0.0, r0 = 0.0, r1 = 0.0, t0 = 0.0, t1 = 0.0;
             if (P.outlier_mode) {
                 t0 = TH[P.o_so + n]; t1 = TH[P.o_so + nf + n];
-                r0 = exp(t0); r1 = exp(t1);
+                r0 = lean_exp(t0); r1 = lean_exp(t1);
                 if (P.outlier_mode == 1) so_re = so_im = 0.05 * r0 * r1;
                 else { so_re = 0.05 * r0; so_im = 0.05 * r1; }
             }
@@ -323,9 +323,9 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             const double s2_re = c0 + ap2 * zr * zr + common + so_re * so_re;
             const double s2_im = c0 + ap2 * zi * zi + common + so_im * so_im;
             const double e_re = er.zre - zr, e_im = er.zim - zi;
-            const double prod = s2_re * s2_im, ip = 1.0 / prod;
+            const double prod = s2_re * s2_im, ip = lean_rcp(prod);
             const double w_re = s2_im * ip, w_im = s2_re * ip;
-            lp += -0.5 * log(prod) - 0.5 * e_re * e_re * w_re - 0.5 * e_im * e_im * w_im;
+            lp += -0.5 * lean_log(prod) - 0.5 * e_re * e_re * w_re - 0.5 * e_im * e_im * w_im;
             const double h_re = -0.5 * w_re + 0.5 * e_re * e_re * w_re * w_re;
             const double h_im = -0.5 * w_im + 0.5 * e_im * e_im * w_im * w_im;
             const double gzr = e_re * w_re + 2.0 * zr * (h_re * (ap2 + ar2) + h_im * ar2);
@@ -336,8 +336,8 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             if (P.outlier_mode == 1) {
                 const double dso = 2.0 * so_re * (h_re + h_im);
                 GR[P.o_so + n] = r0 * (0.05 * r1 * dso - P.so_lambda) + jac;
-                GR[P.o_so + nf + n] = 0.05 * r0 * r1 * dso - (P.so_alpha + 1.0) + P.so_beta / r1 + jac;
-                lp += -P.so_lambda * r0 - (P.so_alpha + 1.0) * t1 - P.so_beta / r1 + jac * (t0 + t1);
+                GR[P.o_so + nf + n] = 0.05 * r0 * r1 * dso - (P.so_alpha + 1.0) + P.so_beta * lean_rcp(r1) + jac;
+                lp += -P.so_lambda * r0 - (P.so_alpha + 1.0) * t1 - P.so_beta * lean_rcp(r1) + jac * (t0 + t1);
             } else if (P.outlier_mode == 2) {
                 GR[P.o_so + n] = r0 * (0.05 * 2.0 * so_re * h_re - P.so_lambda) + jac;
                 GR[P.o_so + nf + n] = r1 * (0.05 * 2.0 * so_im * h_im - P.so_lambda) + jac;
@@ -381,7 +381,7 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             double rr = gz[n], ri = gz[g.NFP + n];
             if (B.is_parallel) {
                 const double yr = yb[b * 2 * g.NFP + n], yi = yb[b * 2 * g.NFP + g.NFP + n];
-                const double dn = yr * yr + yi * yi, id2 = 1.0 / (dn * dn);
+                const double dn = yr * yr + yi * yi, id2 = lean_rcp(dn * dn);
                 const double dd = (yi * yi - yr * yr) * id2, doff = 2.0 * yr * yi * id2;
                 const double gr_ = rr, gi_ = ri;
                 rr = (gr_ * dd + gi_ * doff) * B.x_scale;
@@ -428,7 +428,7 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
         } else {
             const int q = 8 + (sidx - 6);                  // slot 8 + 3 b + i
             const double sv = ered[q] + ered[32 + q] + ered[64 + q];
-            gsc = -0.5 * sraw * sv - 6.0 + 5.0 / sraw + jac;
+            gsc = -0.5 * sraw * sv - 6.0 + 5.0 * lean_rcp(sraw) + jac;
         }
         GR[sj] = gsc;
     }

@@ -57,11 +57,11 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
         if (l32 < 2) j = l32;
         else if (l32 < 6) j = P.o_err + (l32 - 2);
         else if (l32 < 6 + 3 * nblocks) j = P.blk[(l32 - 6) / 3].o_d + (l32 - 6) % 3;
-        if (j >= 0) { st = TH(j); sraw = exp(st); PW(j, sraw); }
+        if (j >= 0) { st = TH(j); sraw = lean_exp(st); PW(j, sraw); }
     }
     double lp = 0.0;
     if (l32 < 6) lp += -0.5 * sraw * sraw + jac * st;                      // std_normal on the raws, log transform
-    else if (l32 < 6 + 3 * nblocks) lp += -6.0 * st - 5.0 / sraw + jac * st;   // d ~ inv_gamma(5, 5)
+    else if (l32 < 6 + 3 * nblocks) lp += -6.0 * st - 5.0 * lean_rcp(sraw) + jac * st;   // d ~ inv_gamma(5, 5)
     double gsc = 0.0;
 
     double zre_a[UNV], zim_a[UNV];                                         // Z_hat without the offsets, n = l32 + 32 v
@@ -84,7 +84,7 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
                 tu_[u] = k < K ? TH(B.o_ups + k) : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < UKV; ++u) ex_[u] = exp(tx_[u]);
+            for (int u = 0; u < UKV; ++u) ex_[u] = lean_exp(tx_[u]);
 #pragma unroll
             for (int u = 0; u < UKV; ++u) {
                 const int k = l32 + LPC * u;
@@ -131,7 +131,7 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
             }
             double ue[UKV + 4], ie[UKV + 2];
 #pragma unroll
-            for (int u = 0; u < UKV; ++u) { ue[u + 2] = 0.15 * exp(tuc[u]); ie[u + 1] = 1.0 / ue[u + 2]; }
+            for (int u = 0; u < UKV; ++u) { ue[u + 2] = 0.15 * lean_exp(tuc[u]); ie[u + 1] = lean_rcp(ue[u + 2]); }
             {
                 const int lo = hb | ((l32 + LPC - 1) & (LPC - 1)), hi = hb | ((l32 + 1) & (LPC - 1));
                 ue[0] = __shfl(ue[UKV], lo); ue[1] = __shfl(ue[UKV + 1], lo);
@@ -211,7 +211,7 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
             if (l32 >= 6 + 3 * b && l32 < 9 + 3 * b) {                     // d_i gradients of this block: lane 6 + 3 b + i
                 const int i = l32 - 6 - 3 * b;
                 const double sv = i == 0 ? sv0 : (i == 1 ? sv1 : sv2);
-                GW(B.o_d + i, -0.5 * sraw * sv - 6.0 + 5.0 / sraw + jac);
+                GW(B.o_d + i, -0.5 * sraw * sv - 6.0 + 5.0 * lean_rcp(sraw) + jac);
             }
         }
         __syncthreads();                                                   // B2: A_b x_b of all chains in Zh
@@ -225,7 +225,7 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
             if (!B.is_parallel) { zre_a[v] += yr; zim_a[v] += yi; }
             else {
                 Y[swz(n, c)] = yr; Y[swz(nf + n, c)] = yi;
-                const double idn = 1.0 / (yr * yr + yi * yi);
+                const double idn = lean_rcp(yr * yr + yi * yi);
                 zre_a[v] += yr * idn;                                      // Z_hat_p (Parallel_modelcode.txt:47)
                 zim_a[v] += -yi * idn;
             }
@@ -264,7 +264,7 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
             double so_re = 0.0, so_im = 0.0, r0 = 0.0, r1 = 0.0, t0 = 0.0, t1 = 0.0;
             if (P.outlier_mode) {
                 t0 = TH(P.o_so + n); t1 = TH(P.o_so + nf + n);
-                r0 = exp(t0); r1 = exp(t1);
+                r0 = lean_exp(t0); r1 = lean_exp(t1);
                 PW(P.o_so + n, r0); PW(P.o_so + nf + n, r1);
                 if (P.outlier_mode == 1) so_re = so_im = 0.05 * r0 * r1;
                 else { so_re = 0.05 * r0; so_im = 0.05 * r1; }
@@ -273,9 +273,9 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
             const double s2_re = c0 + ap2 * zr * zr + common + so_re * so_re;
             const double s2_im = c0 + ap2 * zi * zi + common + so_im * so_im;
             const double e_re = Zm[n] - zr, e_im = Zm[nf + n] - zi;
-            const double prod = s2_re * s2_im, ip = 1.0 / prod;
+            const double prod = s2_re * s2_im, ip = lean_rcp(prod);
             const double w_re = s2_im * ip, w_im = s2_re * ip;
-            lp += -0.5 * log(prod) - 0.5 * e_re * e_re * w_re - 0.5 * e_im * e_im * w_im;
+            lp += -0.5 * lean_log(prod) - 0.5 * e_re * e_re * w_re - 0.5 * e_im * e_im * w_im;
             const double h_re = -0.5 * w_re + 0.5 * e_re * e_re * w_re * w_re;
             const double h_im = -0.5 * w_im + 0.5 * e_im * e_im * w_im * w_im;
             const double gzr = e_re * w_re + 2.0 * zr * (h_re * (ap2 + ar2) + h_im * ar2);
@@ -290,8 +290,8 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
             if (P.outlier_mode == 1) {
                 const double dso = 2.0 * so_re * (h_re + h_im);
                 GW(P.o_so + n, r0 * (0.05 * r1 * dso - P.so_lambda) + jac);
-                GW(P.o_so + nf + n, 0.05 * r0 * r1 * dso - (P.so_alpha + 1.0) + P.so_beta / r1 + jac);
-                lp += -P.so_lambda * r0 - (P.so_alpha + 1.0) * t1 - P.so_beta / r1 + jac * (t0 + t1);
+                GW(P.o_so + nf + n, 0.05 * r0 * r1 * dso - (P.so_alpha + 1.0) + P.so_beta * lean_rcp(r1) + jac);
+                lp += -P.so_lambda * r0 - (P.so_alpha + 1.0) * t1 - P.so_beta * lean_rcp(r1) + jac * (t0 + t1);
             } else if (P.outlier_mode == 2) {
                 GW(P.o_so + n, r0 * (0.05 * 2.0 * so_re * h_re - P.so_lambda) + jac);
                 GW(P.o_so + nf + n, r1 * (0.05 * 2.0 * so_im * h_im - P.so_lambda) + jac);
@@ -332,7 +332,7 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
             double rr = gzr_[v], ri = gzi_[v];
             if (B.is_parallel) {
                 const double yr = Y[swz(n, c)], yi = Y[swz(nf + n, c)];
-                const double dn = yr * yr + yi * yi, id2 = 1.0 / (dn * dn);
+                const double dn = yr * yr + yi * yi, id2 = lean_rcp(dn * dn);
                 const double dd = (yi * yi - yr * yr) * id2, doff = 2.0 * yr * yi * id2;
                 rr = (gzr_[v] * dd + gzi_[v] * doff) * B.x_scale;
                 ri = (-gzr_[v] * doff + gzi_[v] * dd) * B.x_scale;
@@ -352,7 +352,7 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
                 gl_[u] = k < K ? GR(B.o_x + k) : 0.0;                      // L^T w of this block, parked by the prior phase
             }
 #pragma unroll
-            for (int u = 0; u < UKV; ++u) ex_[u] = exp(tx_[u]);
+            for (int u = 0; u < UKV; ++u) ex_[u] = lean_exp(tx_[u]);
 #pragma unroll
             for (int u = 0; u < UKV; ++u) {
                 const int k = l32 + LPC * u;
