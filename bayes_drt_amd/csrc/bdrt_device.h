@@ -174,6 +174,40 @@ __device__ __forceinline__ double swizzle_xor16(double x)
     const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), 0x401F);
     return __hiloint2double(hi, lo);
 }
+// the value of lane (l ^ 4) of the same row of 16: two DPP moves per half (shift left by 4 into the banks whose lanes have bit 2
+// clear, shift right into the others)
+__device__ __forceinline__ double dpp_xor4(double x)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x104, 0xF, 0x5, false);       // row_shl:4 -> banks 0, 2
+    lo = __builtin_amdgcn_update_dpp(lo, __double2loint(x), 0x114, 0xF, 0xA, false);          // row_shr:4 -> banks 1, 3
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x104, 0xF, 0x5, false);
+    hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(x), 0x114, 0xF, 0xA, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Sums of N = 4 or 8 quantities over the 32 lanes of a half-wave in ONE butterfly: at the step across lane bit b every lane
+// keeps the half of its quantities whose index has bit b equal to its own lane bit and receives the partner's partial sums
+// of those -- 4 + 2 + 1 exchanges for eight quantities instead of 8 x 5.  Lane l ends with the total of quantity (l & (N - 1)),
+// the same value in all lanes that share it.  (57 instructions for eight sums against 8 x 17.)
+template <int N>
+__device__ __forceinline__ double sum32_by_lane(const double (&v)[N], int lane)
+{
+    static_assert(N == 4 || N == 8, "four or eight quantities");
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    double a[N / 2];
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) a[i] = (b0 ? v[2 * i + 1] : v[2 * i]) + dpp_perm<0xB1>(b0 ? v[2 * i] : v[2 * i + 1]);      // index bit 0 = lane bit 0
+    double b[N / 4];
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) b[i] = (b1 ? a[2 * i + 1] : a[2 * i]) + dpp_perm<0x4E>(b1 ? a[2 * i] : a[2 * i + 1]);      // index bit 1 = lane bit 1
+    double c;
+    if (N == 8) c = (b2 ? b[N / 4 - 1] : b[0]) + dpp_xor4(b2 ? b[0] : b[N / 4 - 1]);                                           // index bit 2 = lane bit 2
+    else c = b[0] + dpp_xor4(b[0]);
+    c += dpp_perm<0x128>(c);       // row_ror:8 = lane ^ 8
+    c += swizzle_xor16(c);
+    return c;
+}
+
 __device__ __forceinline__ double sum32(double x)
 {
     x += dpp_perm<0xB1>(x);        // quad_perm [1,0,3,2]

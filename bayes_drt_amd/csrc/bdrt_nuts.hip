@@ -379,11 +379,11 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                         if (l32 == 0) my_leaps += 1;
                         s.n_leap_iter = s.n_leap_iter + 1;
                         const double w = H0 - h;
-                        s.sum_metro = s.sum_metro + (w > 0.0 ? 1.0 : exp(w));
+                        s.sum_metro = s.sum_metro + (w > 0.0 ? 1.0 : BDRT_NUTS_EXP(w));
                         const double lsw_new = log_sum_exp2(s.lsw_sub, w);
                         // uniform sampling inside the new subtree: keep leaf i with probability w_i / W_i
                         const double u = rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
-                        const bool copyq = leaf_now == 0 || u < exp(w - lsw_new);
+                        const bool copyq = leaf_now == 0 || u < BDRT_NUTS_EXP(w - lsw_new);
                         s.lsw_sub = lsw_new;
                         s.leaf = leaf_now + 1;
                         if (copyq) {
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 const double lsw = s.lsw, lsw_sub = s.lsw_sub;
                 bool take;
                 if (lsw_sub > lsw) take = true;
-                else take = rng_uniform(rng, 0, RNG_TOP, (uint32_t)depth, 0, (uint32_t)s.iter) < exp(lsw_sub - lsw);
+                else take = rng_uniform(rng, 0, RNG_TOP, (uint32_t)depth, 0, (uint32_t)s.iter) < BDRT_NUTS_EXP(lsw_sub - lsw);
                 if (take) { upds = true; s.lps = s.lpq; }
                 s.lsw = log_sum_exp2(lsw, lsw_sub);
                 const bool keep_going = (t0 > 0.0) && (t1 > 0.0);
@@ -1031,13 +1031,13 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
                 const double H0 = s.H0;
                 const bool divergent = (h - H0) > np.max_deltaH;
                 const double w = H0 - h;
-                s.sum_metro = s.sum_metro + (w > 0.0 ? 1.0 : exp(w));
+                s.sum_metro = s.sum_metro + (w > 0.0 ? 1.0 : BDRT_NUTS_EXP(fmax(w, -746.0)));       // (w = -inf on a non-finite energy)
                 if (divergent) {
                     endt = 2;
                 } else {
                     const double lsw_new = log_sum_exp2(s.lsw_sub, w);
                     const double u = lps_l[1];                          // drawn by wave 7 before the evaluation
-                    if (leaf_now == 0 || u < exp(w - lsw_new)) { copyq = true; s.lpq = lp; }
+                    if (leaf_now == 0 || u < BDRT_NUTS_EXP(w - lsw_new)) { copyq = true; s.lpq = lp; }
                     s.lsw_sub = lsw_new;
                     tree = true;
                     while ((leaf_now >> nm) & 1) ++nm;
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
                 const double lsw = s.lsw, lsw_sub = s.lsw_sub;
                 bool take;
                 if (lsw_sub > lsw) take = true;
-                else take = rng_uniform(rng, 0, RNG_TOP, (uint32_t)depth, 0, (uint32_t)s.iter) < exp(lsw_sub - lsw);
+                else take = rng_uniform(rng, 0, RNG_TOP, (uint32_t)depth, 0, (uint32_t)s.iter) < BDRT_NUTS_EXP(lsw_sub - lsw);
                 if (take) { upds = true; s.lps = s.lpq; }
                 s.lsw = log_sum_exp2(lsw, lsw_sub);
                 const bool keep_going = (t0 > 0.0) && (t1 > 0.0);

@@ -80,11 +80,21 @@ __device__ inline void rng_normal_pair(const Philox &g, uint32_t i, uint32_t pur
 }
 #endif
 
+// The per-leaf weights of the device kernels go through the lean exp / log of bdrt_device.h (their arguments are finite and <= 0, or the
+// comparison they feed is false either way); host code -- the window logic's unit test -- keeps the C library.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BDRT_NUTS_EXP(x) ::bdrt::lean_exp(x)
+#define BDRT_NUTS_LOG1P_EXP(d) ::bdrt::lean_log(1.0 + ::bdrt::lean_exp(d))
+#else
+#define BDRT_NUTS_EXP(x) exp(x)
+#define BDRT_NUTS_LOG1P_EXP(d) log1p(exp(d))
+#endif
+
 __host__ __device__ inline double log_sum_exp2(double a, double b)
 {
     if (a == -INFINITY) return b;
     if (b == -INFINITY) return a;
-    return a > b ? a + log1p(exp(b - a)) : b + log1p(exp(a - b));
+    return a > b ? a + BDRT_NUTS_LOG1P_EXP(b - a) : b + BDRT_NUTS_LOG1P_EXP(a - b);
 }
 
 // chain phases
@@ -226,14 +236,14 @@ __host__ __device__ inline void nuts_tree_leaf(S &s, const NutsParams &np, const
     const double H0 = s.H0;
     const bool divergent = (h - H0) > np.max_deltaH;
     const double w = H0 - h;
-    s.sum_metro = s.sum_metro + (w > 0.0 ? 1.0 : exp(w));
+    s.sum_metro = s.sum_metro + (w > 0.0 ? 1.0 : BDRT_NUTS_EXP(fmax(w, -746.0)));
     if (divergent) {
         endt = 2;               // transition ends, subtree discarded, divergent
         return;
     }
     const double lsw_new = log_sum_exp2(s.lsw_sub, w);
     const double u = rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
-    if (leaf_now == 0 || u < exp(w - lsw_new)) { copyq = true; s.lpq = lp; }
+    if (leaf_now == 0 || u < BDRT_NUTS_EXP(w - lsw_new)) { copyq = true; s.lpq = lp; }
     s.lsw_sub = lsw_new;
     tree = true;
     while ((leaf_now >> nm) & 1) ++nm;              // trailing ones = sub-subtrees ending here

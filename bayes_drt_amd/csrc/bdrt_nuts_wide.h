@@ -247,7 +247,7 @@ __device__ inline void wide_coop_tail(const WideCtx &x, int hc, bool c_done, uns
             const double lsw = s.lsw, lsw_sub = s.lsw_sub;
             bool take;
             if (lsw_sub > lsw) take = true;
-            else take = rng_uniform(rng, 0, RNG_TOP, (uint32_t)depth, 0, (uint32_t)s.iter) < exp(lsw_sub - lsw);
+            else take = rng_uniform(rng, 0, RNG_TOP, (uint32_t)depth, 0, (uint32_t)s.iter) < BDRT_NUTS_EXP(lsw_sub - lsw);
             if (take) { upds = true; s.lps = s.lpq; }
             s.lsw = log_sum_exp2(lsw, lsw_sub);
             const bool keep_going = (red[2] > 0.0) && (red[3] > 0.0);

@@ -407,6 +407,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     const int l32 = tid % LPC, hb = lane & (64 - LPC);     // lane within the group, first lane of the group in the wave
     const DevBlock &B = P.blk[0];
     const int nf = P.nf, N2 = 2 * nf, K = B.K, KP = 8 * B.kpairs;
+    const int omode = LDSIO ? 0 : P.outlier_mode;           // (the sampler keeps its state in LDS only without outlier parameters: bdrt_nuts.hip use_s1)
     const int dbg = P.dbg;                                  // (read once: a scalar load behind each barrier otherwise)
     const bool valid = c < io.nvalid;
     const int cc = valid ? c : 0;
@@ -423,8 +424,9 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     double *gr = (io.grad && valid) ? io.grad + (long)cc * io.g_sc : nullptr;
     auto GW = [&](int j, double v) { if (!LDSIO && gr) gr[(long)j * io.g_sj] = v; };
     double gsc = 0.0;                                      // LDSIO: gradient of the scalar this lane owns (lanes 0..8)
-    double *pr = (io.params && valid) ? io.params + (size_t)cc * P.D : nullptr;
-    auto PW = [&](int j, double v) { if (pr) pr[j] = v; };
+    // (LDSIO = the sampler: it never asks for the constrained parameters, the model spectrum or sigma_tot)
+    double *pr = (!LDSIO && io.params && valid) ? io.params + (size_t)cc * P.D : nullptr;
+    auto PW = [&](int j, double v) { if (!LDSIO && pr) pr[j] = v; };
 
     long long tprev = (io.prof && tid == 0) ? clock64() : 0;
     long long *trc = g_tile_trace ? g_tile_trace + ((size_t)blockIdx.x * NWV + wave) * 16 : nullptr;
@@ -442,6 +444,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         if (j >= 0) { st = TH(j); sraw = lean_exp(st); PW(j, sraw); }
     }
     double lp = 0.0;
+    int lp_lane = -1;                                      // the lane that ends up with the chain's total (-1: not summed yet)
     double x_[UKV];
     {
         double tx_[UKV], tu_[UKV];
@@ -622,9 +625,15 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         }
 #pragma unroll
         for (int u = 0; u < UKV; ++u) { xrow[MAXBW + kb + u] = gup[u]; wrow[MAXBW + kb + u] = gl_[u]; }   // back to M1 for the epilogue
-        sv0 = hsum<LPC>(sv0); sv1 = hsum<LPC>(sv1); sv2 = hsum<LPC>(sv2);
+        double sv;                                                       // lane 6 + i: the total of sv_i
+        if constexpr (LPC == 32) {
+            const double q[4] = {sv2, 0.0, sv0, sv1};                    // (lane & 3 of the lanes 6, 7, 8 = 2, 3, 0)
+            sv = sum32_by_lane<4>(q, l32);
+        } else {
+            sv0 = hsum<LPC>(sv0); sv1 = hsum<LPC>(sv1); sv2 = hsum<LPC>(sv2);
+            sv = l32 == 6 ? sv0 : (l32 == 7 ? sv1 : sv2);
+        }
         if (l32 >= 6 && l32 < 9) {                                       // d_i gradients: lane 6+i
-            const double sv = l32 == 6 ? sv0 : (l32 == 7 ? sv1 : sv2);
             gsc = -0.5 * sraw * sv - 6.0 + israw5 + jac;
             GW(B.o_d + (l32 - 6), gsc);
         }
@@ -668,11 +677,11 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             const double zi = Zh[swz(nf + n, c)] + induc * wn;
             // outlier error model (Series_*_outliers_modelcode.txt): 2 Nf extra parameters, read where they are needed
             double so_re = 0.0, so_im = 0.0, r0 = 0.0, r1 = 0.0, t0 = 0.0, t1 = 0.0;
-            if (P.outlier_mode) {
+            if (omode) {
                 t0 = TH(P.o_so + n); t1 = TH(P.o_so + nf + n);
                 r0 = lean_exp(t0); r1 = lean_exp(t1);
                 PW(P.o_so + n, r0); PW(P.o_so + nf + n, r1);
-                if (P.outlier_mode == 1) so_re = so_im = 0.05 * r0 * r1;
+                if (omode == 1) so_re = so_im = 0.05 * r0 * r1;
                 else { so_re = 0.05 * r0; so_im = 0.05 * r1; }
             }
             const double common = ar2 * zr * zr + ai2 * zi * zi;
@@ -698,38 +707,48 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             sHz2 += h_re * zr * zr + h_im * zi * zi;
             sHzr2 += (h_re + h_im) * zr * zr;
             sHzi2 += (h_re + h_im) * zi * zi;
-            if (P.outlier_mode == 1) {
+            if (omode == 1) {
                 // sigma_out = raw .* scale * 0.05 ; raw ~ exponential(lambda) ; scale ~ inv_gamma(alpha, beta)
                 const double dso = 2.0 * so_re * (h_re + h_im);
                 GW(P.o_so + n, r0 * (0.05 * r1 * dso - P.so_lambda) + jac);
                 GW(P.o_so + nf + n, 0.05 * r0 * r1 * dso - (P.so_alpha + 1.0) + P.so_beta / r1 + jac);
                 lp += -P.so_lambda * r0 - (P.so_alpha + 1.0) * t1 - P.so_beta / r1 + jac * (t0 + t1);
-            } else if (P.outlier_mode == 2) {
+            } else if (omode == 2) {
                 GW(P.o_so + n, r0 * (0.05 * 2.0 * so_re * h_re - P.so_lambda) + jac);
                 GW(P.o_so + nf + n, r1 * (0.05 * 2.0 * so_im * h_im - P.so_lambda) + jac);
                 lp += -P.so_lambda * (r0 + r1) + jac * (t0 + t1);
             }
-            if (io.Z_hat && valid) { io.Z_hat[(size_t)c * N2 + n] = zr; io.Z_hat[(size_t)c * N2 + nf + n] = zi; }
-            if (io.sigma_tot && valid) {
+            if (!LDSIO && io.Z_hat && valid) { io.Z_hat[(size_t)c * N2 + n] = zr; io.Z_hat[(size_t)c * N2 + nf + n] = zi; }
+            if (!LDSIO && io.sigma_tot && valid) {
                 io.sigma_tot[(size_t)c * N2 + n] = sqrt(s2_re);
                 io.sigma_tot[(size_t)c * N2 + nf + n] = sqrt(s2_im);
             }
         }
-        sR = hsum<LPC>(sR); sL = hsum<LPC>(sL); sH = hsum<LPC>(sH); sHz2 = hsum<LPC>(sHz2); sHzr2 = hsum<LPC>(sHzr2); sHzi2 = hsum<LPC>(sHzi2);
-        if (TA && rk > 0) {
-            lk0 = hsum<LPC>(lk0);
-            if (rk > 1) lk1 = hsum<LPC>(lk1);
-            if (l32 == 0) { Xs[swz(K - rk, c)] = lk0; if (rk > 1) Xs[swz(K - rk + 1, c)] = lk1; }
-        }
-        if (l32 < 6) {
-            // d lp / d(raw), likelihood part, of Rinf_raw, induc_raw, sigma_res_raw, alpha_prop/re/im_raw (lane j owns scalar j)
-            double dl;
+        // the six sums, the odd row of A^T g and the chain's log-posterior (complete by now) in one butterfly: lane j gets sum j
+        double dl = 0.0;
+        if constexpr (LPC == 32) {
+            const double q[8] = {sR, sL, sH, sHz2, sHzr2, sHzi2, lk0, lp};
+            const double tot = sum32_by_lane<8>(q, l32);
+            // d lp / d(raw), likelihood part: 100 sR, induc_scale sL, 0.05 * 2 s_res sH, 0.05 * 2 alpha_prop sHz2, ... with
+            // s_res = 0.05 raw_2, alpha_* = 0.05 raw_3..5 -- the lane's own raw value
+            dl = (l32 == 0 ? 100.0 : (l32 == 1 ? P.induc_scale : 0.005 * sraw)) * tot;
+            if (TA && rk > 0) {
+                if (l32 == 6) Xs[swz(K - rk, c)] = tot;
+                if (rk > 1) { lk1 = hsum<LPC>(lk1); if (l32 == 0) Xs[swz(K - rk + 1, c)] = lk1; }
+            }
+            lp = tot;                                                    // (lane 7: the log-posterior)
+            lp_lane = 7;
+        } else {
+            sR = hsum<LPC>(sR); sL = hsum<LPC>(sL); sH = hsum<LPC>(sH); sHz2 = hsum<LPC>(sHz2); sHzr2 = hsum<LPC>(sHzr2); sHzi2 = hsum<LPC>(sHzi2);
             if (l32 == 0) dl = 100.0 * sR;
             else if (l32 == 1) dl = P.induc_scale * sL;
             else if (l32 == 2) dl = 0.05 * 2.0 * s_res * sH;
             else if (l32 == 3) dl = 0.05 * 2.0 * a_p * sHz2;
             else if (l32 == 4) dl = 0.05 * 2.0 * a_r * sHzr2;
             else dl = 0.05 * 2.0 * a_i * sHzi2;
+        }
+        if (l32 < 6) {
+            // d lp / d(raw) of Rinf_raw, induc_raw, sigma_res_raw, alpha_prop/re/im_raw (lane j owns scalar j)
             const int j = l32 < 2 ? l32 : P.o_err + (l32 - 2);
             gsc = sraw * (dl - sraw) + jac;
             GW(j, gsc);
@@ -772,8 +791,8 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         }
         if (l32 < 9) xrow[l32 < 2 ? l32 : (l32 < 6 ? P.o_err + (l32 - 2) : B.o_d + (l32 - 6))] = gsc;
     }
-    lp = hsum<LPC>(lp);
-    if (l32 == 0 && io.lp && valid) io.lp[c] = lp;
+    if (lp_lane < 0) { lp = hsum<LPC>(lp); lp_lane = 0; }
+    if (l32 == lp_lane && io.lp && valid) io.lp[c] = lp;
     BDRT_S1_PROF(9);
     BDRT_S1_TRACE(11);
     // LDSIO: what follows in the sampler only touches this chain's own rows; its end-of-round barrier closes the round
