@@ -451,6 +451,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         // ---- C: second half kick, kinetic energy, finiteness of the gradient -----------------------------
         // (p, g, Minv of this chain stay in registers from here to the end of stage D)
         double kin = 0.0, nonfin = 0.0;
+        bool bad_g = false;
         const int dir_now = s.dir;
         const int leaf_now = s.leaf;
         // An odd leaf merges with the single leaf waiting at level 0 (known from the index alone): its momentum is requested
@@ -473,12 +474,13 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     const double p = p_[m] + 0.5 * e * g_[m];
                     p_[m] = p;                            // written to memory by stage A' / E at the end of the body
                     kin += mi_[m] * p * p;
-                    nonfin += isfinite(g_[m]) ? 0.0 : 1.0;
+                    bad_g = bad_g || !isfinite(g_[m]);
                 }
             }
         }
         kin = 0.5 * half_sum(kin);
-        nonfin = half_sum(nonfin);
+        // a non-finite gradient entry anywhere in the chain's half-wave: one ballot instead of a second butterfly
+        nonfin = ((__builtin_amdgcn_ballot_w64(bad_g) >> (lane & 32)) & 0xffffffffull) ? 1.0 : 0.0;
         BDRT_NUTS_PROF(11);
         BDRT_WAVE_PROF(18);
 
