@@ -85,6 +85,9 @@ struct NutsArgs {
 // unrolled into a batch of independent loads followed by the arithmetic (one memory round trip per stage instead of one
 // per element -- the state vectors of 2048+ chains live in HBM/MALL, not in L2).
 // TA (MODE 2 only): DevProblem::toepA, the S1 tile's GEMMs take the A operands from the generator table in LDS
+#ifndef BDRT_NUTS_EARLY_STATE
+#define BDRT_NUTS_EARLY_STATE 1
+#endif
 template <int NJ, int MODE, bool TA = false>   // MODE 0: dense L, 1: structured L (generic tile), 2: S1 tile + theta rows in LDS, 3: S1 tile, state in HBM, 4: general half-wave tile
 __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a)
 {
@@ -236,8 +239,14 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     any_next = v;
                 }
             };
-            logp_grad_tile_s1<true, 32, NoHook, decltype(read_flags), TA>(P, io, smem, NoHook(), read_flags);
-            load_state();
+            // (momentum and inverse metric are requested right before the backward GEMM: their HBM round trip runs under its MFMAs
+            // instead of in front of stage C)
+            constexpr bool EARLY = BDRT_NUTS_EARLY_STATE && NJ <= 11;      // (16 elements per lane: the rows would be spilled)
+            // (Measured and dropped: touching one dword per line of the checkpoint rows that this leaf's merges of levels 1..3 will read,
+            // so that they wait in L2 by stage D: 0.767 -> 0.751, conditional or not.)
+            auto early_state = [&]() { if constexpr (EARLY) load_state(); };
+            logp_grad_tile_s1<true, 32, decltype(early_state), decltype(read_flags), TA>(P, io, smem, early_state, read_flags);
+            if constexpr (!EARLY) load_state();
         }
         else if (MODE == 3) { logp_grad_tile_s1<false>(P, io, smem); load_state(); }
         else if (MODE == 4) { logp_grad_tile_hw(P, io, smem); load_state(); }
