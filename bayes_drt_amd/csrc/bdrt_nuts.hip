@@ -475,6 +475,9 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         }
         // (Measured and dropped: the two rows of level 1 requested here as well for leaves that end in two one bits -- 44 more live
         // registers, 31 spilled: 0.766 -> 0.692.)
+        // (Measured and dropped: the two rows of level 1 requested here as well for leaves that end in two one bits -- 44 more live
+        // registers: 31 spilled, 0.766 -> 0.692; with the gradient re-read from its LDS row after stage C instead of held in registers
+        // (alone: 0.761) still 15 spilled, 0.698.  Any scratch access in this loop costs more than a memory round trip saved.)
         if (act) {
 #pragma unroll
             for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; g_[m] = G[j]; }
