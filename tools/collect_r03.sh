@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-3 measurement batch on the GPU box: everything DESIGN.md section 7 (round 3) quotes.  Writes gpurun_out/r03/.
-# Usage: tools/collect_r03.sh [part ...]   parts: bench trace sq soak hmc map config5 fuzz   (default: all but fuzz)
+# Usage: tools/collect_r03.sh [part ...]   parts: bench trace sq soak hmc map config5 extra fuzz   (default: all but extra and fuzz)
+# (extra: the sweeps / probes of the second half of the round; the tools/ubench binaries are built with the hipcc lines in their sources)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r03
@@ -44,6 +45,14 @@ if has config5; then
   python tools/bench_config5.py 4096 --phase-profile > $OUT/config5.txt 2>&1
   python tools/bench_config5.py 4096 --series-outliers >> $OUT/config5.txt 2>&1
   python tools/config5_run.py > $OUT/config5_run.txt 2>&1
+fi
+if has extra; then
+  python tools/few_points_sweep.py > $OUT/few_points_sweep.txt 2>&1
+  python tools/hmc_suite2_run.py > $OUT/hmc_suite2.txt 2>&1
+  python tools/solo_duo_probe.py > $OUT/solo_duo.txt 2>&1
+  python tools/soak_sampling.py 128 8 500 500 > $OUT/soak_128x8.txt 2>&1
+  python tools/scatter_2rc.py > $OUT/scatter_2rc.txt 2>&1
+  (for b in f64_overlap toep_loop toep_gemm_probe; do echo "== tools/ubench/$b"; ./tools/ubench/$b; echo; done) > $OUT/ubench.txt 2>&1
 fi
 if has fuzz; then
   python -m tests.fuzz_parity --first 3000 --count 400 > $OUT/fuzz_parity.txt 2>&1
