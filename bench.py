@@ -36,9 +36,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_EVAL = 4.27e5      # 4*(2Nf*K + 3K^2) + ~12k element-wise, Nf=81, K=161
-# what the structured path really executes per evaluation on a log-uniform grid: A GEMMs on padded 176 x 168 tiles
-# (2 * 462 MFMA * 2048 flop / 16 chains = 1.18e5) + six banded convolutions + ~1.5e4 element-wise
-FLOP_PER_EVAL_EXECUTED = 1.66e5
+# what the structured path really executes per evaluation on a log-uniform grid: the A GEMMs (820 MFMA * 2048 flop / 16 chains =
+# 1.05e5 with the operands from the LDS table, 1.18e5 on padded 176 x 168 tiles with streamed fragments) + six banded convolutions
+# + ~1.5e4 element-wise; main() picks the figure of the evaluator the problem was given
+FLOP_PER_EVAL_EXECUTED = 1.66e5 - (924 - 820) * 2048 / 16.0 + 1.3e3
 PEAK_F64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix peak; measured 78.05 by tools/mfma_probe (profiles/)
 NF, K = 81, 161
 N_SPECTRA, CHAINS_PER_SPECTRUM = 512, 8
@@ -56,9 +57,12 @@ PYSTAN_DERIVED = {'value': 2250.0, 'unit': 'evals/s', 'processes': 4,
 # ratio is context, not a quality measure -- roofline.frac is.
 CPU_PORT_NOTE = ('untuned checker: oracle/bdrt_oracle.c is the plain-C parity oracle (scalar dense mat-vecs, per-evaluation '
                  'malloc, no Toeplitz/band shortcuts), one chain per physical core')
-# MFMA instructions the structured path issues per evaluation of a 16-chain tile: forward A (11 row tiles x 42 k-steps) +
-# backward A^T (11 x 42) = 924 v_mfma_f64_16x16x4_f64 of 2048 flop each (SQ_INSTS_MFMA in profiles/ agrees)
-MFMA_FLOP_PER_EVAL = 924 * 2048 / 16.0
+# MFMA instructions the structured path issues per evaluation of a 16-chain tile (v_mfma_f64_16x16x4_f64, 2048 flop each; DESIGN
+# 3.1b; SQ_INSTS_MFMA in profiles/ agrees): with the packed A fragments streamed from L2 (evaluator 2) forward A (11 row tiles x 42
+# k-steps) + backward A^T (11 x 42) = 924; with the operands from the LDS-resident Toeplitz table (evaluator 4: this workload) ten
+# tiles x 41 chunks each way = 820, the odd rows being ~1.3e3 flop of VALU dot products
+MFMA_PER_TILE = {2: 924, 4: 820}
+MFMA_FLOP_PER_EVAL = MFMA_PER_TILE[4] * 2048 / 16.0
 
 
 def synth_spectra(n, seed=20260101):
@@ -301,6 +305,9 @@ def main():
     local_kw = dict(kw); blocks = local_kw.pop('blocks'); Zall = local_kw.pop('Z'); freq = local_kw.pop('freq')
     prob = Problem(blocks, np.atleast_2d(Zall)[s0:s1], freq, **local_kw)
     assert prob.D == 2 * K + 9
+    evaluator = prob.evaluator()                          # 4: GEMM operands from the LDS-resident Toeplitz table, 2: streamed fragments
+    mfma_flop = MFMA_PER_TILE.get(evaluator, 924) * 2048 / 16.0
+    flop_executed = 1.66e5 - (924 - MFMA_PER_TILE.get(evaluator, 924)) * 2048 / 16.0 + (1.3e3 if evaluator == 4 else 0.0)
     n_units = u1 - u0
     ctrl = NutsControl()
     lib.bdrt_nuts_defaults(C.byref(ctrl))
@@ -452,7 +459,7 @@ def main():
                                 'launched_by': 'bench.py itself (child torch.distributed.run)'
                                 if os.environ.get('BDRT_BENCH_SELF_LAUNCHED') else
                                 ('torch.distributed.run' if 'RANK' in os.environ else 'plain python, one process')},
-                       'units_per_gpu': n_units, 'rounds_per_launch': args.rounds,
+                       'units_per_gpu': n_units, 'rounds_per_launch': args.rounds, 'evaluator': evaluator,
                        'evals_in_timed_region': evals, 'timed_region_s': elapsed, 'setup_ms': setup_ms},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F64_MFMA_TFLOPS, 'traffic': traffic,
@@ -460,12 +467,12 @@ def main():
                          'flop_per_eval_algorithmic': FLOP_PER_EVAL,
                          # the same launch priced on what the structured path executes (band convolutions instead of dense
                          # L products) and on the MFMA pipe alone (A and A^T tiles)
-                         'flop_per_eval_executed': FLOP_PER_EVAL_EXECUTED,
-                         'frac_executed': achieved * FLOP_PER_EVAL_EXECUTED / FLOP_PER_EVAL / PEAK_F64_MFMA_TFLOPS,
-                         'mfma_flop_per_eval': MFMA_FLOP_PER_EVAL,
-                         'mfma_pipe_frac': achieved * MFMA_FLOP_PER_EVAL / FLOP_PER_EVAL / PEAK_F64_MFMA_TFLOPS,
+                         'flop_per_eval_executed': flop_executed,
+                         'frac_executed': achieved * flop_executed / FLOP_PER_EVAL / PEAK_F64_MFMA_TFLOPS,
+                         'mfma_flop_per_eval': mfma_flop,
+                         'mfma_pipe_frac': achieved * mfma_flop / FLOP_PER_EVAL / PEAK_F64_MFMA_TFLOPS,
                          'traffic_source': traffic_src,
-                         'executed_tflops_structured_path': achieved * FLOP_PER_EVAL_EXECUTED / FLOP_PER_EVAL},
+                         'executed_tflops_structured_path': achieved * flop_executed / FLOP_PER_EVAL},
         }
         if one_device:
             line['config']['test_mode'] = 'all %d ranks on ONE device over gloo (BDRT_BENCH_ONE_DEVICE): not a scaling measurement' % world
