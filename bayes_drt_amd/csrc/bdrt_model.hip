@@ -398,6 +398,17 @@ __global__ void lean_math_kernel(const double *x, int n, double *out)
     out[i] = lean_exp(x[i]); out[n + i] = lean_log(x[i]); out[2 * (size_t)n + i] = lean_rcp(x[i]);
 }
 
+// debug / tests only: sum32_by_lane<8> and <4> on one wavefront: in [64][8], out [2][64] (lane l of each half: the total of quantity l & 7 / l & 3)
+__global__ void sum_by_lane_kernel(const double *in, double *out)
+{
+    const int l = threadIdx.x;
+    double q8[8], q4[4];
+    for (int j = 0; j < 8; ++j) q8[j] = in[l * 8 + j];
+    for (int j = 0; j < 4; ++j) q4[j] = in[l * 8 + j];
+    out[l] = sum32_by_lane<8>(q8, l & 31);
+    out[64 + l] = sum32_by_lane<4>(q4, l & 31);
+}
+
 }  // namespace bdrt
 
 using namespace bdrt;
@@ -482,6 +493,20 @@ static int check_spec(Problem &P, const int *spec, int B)
 int bdrt_debug_set_tile_trace(void *d_buf)
 {
     BDRT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace), &d_buf, sizeof(void *)));
+    return 0;
+}
+
+int bdrt_debug_sum_by_lane(const double *in, double *out)
+{
+    if (!in || !out) { set_error("bdrt_debug_sum_by_lane: bad arguments"); return -1; }
+    bind_process_device();
+    double *di = nullptr, *dout = nullptr;
+    BDRT_HIP(hipMalloc((void **)&di, 512 * sizeof(double)));
+    BDRT_HIP(hipMalloc((void **)&dout, 128 * sizeof(double)));
+    BDRT_HIP(hipMemcpy(di, in, 512 * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sum_by_lane_kernel, dim3(1), dim3(64), 0, 0, di, dout);
+    BDRT_HIP(hipMemcpy(out, dout, 128 * sizeof(double), hipMemcpyDeviceToHost));
+    hipFree(di); hipFree(dout);
     return 0;
 }
 

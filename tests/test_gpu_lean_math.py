@@ -56,3 +56,25 @@ def test_lean_rcp():
     ref = (np.longdouble(1.0) / x.astype(np.longdouble)).astype(np.float64)
     u = _ulps(got, ref)
     assert u.max() <= 1.0, (u.max(), x[np.argmax(u)])
+
+
+def test_one_butterfly_for_eight_sums():
+    """sum32_by_lane (bdrt_device.h): lane l of a half-wave ends with the total of quantity l & 7 (l & 3) over the 32 lanes -- against
+    numpy, to rounding (another pairing than a sequential sum), on values of mixed sign and magnitude; the two halves are independent."""
+    from bayes_drt_amd import _lib
+    lib = _lib.require_gpu()
+    fn = lib.bdrt_debug_sum_by_lane
+    fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((64, 8)) * 10.0 ** rng.integers(-6, 7, (64, 8))
+    out = np.empty((2, 64))
+    assert fn(np.ascontiguousarray(x).ctypes.data, out.ctypes.data) == 0
+    for half in (0, 1):
+        rows = x[32 * half:32 * half + 32]
+        tot, mag = rows.sum(axis=0), np.abs(rows).sum(axis=0)
+        for l in range(32):
+            assert abs(out[0, 32 * half + l] - tot[l & 7]) <= 1e-15 * 32 * mag[l & 7]
+            assert abs(out[1, 32 * half + l] - tot[l & 3]) <= 1e-15 * 32 * mag[l & 3]
+        # every lane that shares a quantity holds the same bits
+        for j in range(8):
+            assert len({out[0, 32 * half + l] for l in range(32) if l & 7 == j}) == 1
