@@ -166,3 +166,35 @@ def test_compaction_of_an_oversubscribed_run_is_bit_identical(monkeypatch):
         da, lpa, _ = smp.results()
     assert np.array_equal(da, d1[pick]) and np.array_equal(lpa, lp1[pick])
     prob.close()
+
+
+@pytest.mark.parametrize('nf,K', [(80, 160), (82, 162), (82, 80), (80, 81)])
+def test_sixteen_chain_kernel_on_the_other_shapes_of_the_table_path_vs_oracle(nf, K, monkeypatch):
+    """The sampler's fast path with the Toeplitz-table GEMMs at the shapes beside 81 x 161 (no / two odd rows per part, no / two odd
+    rows of A^T): a few chains forced onto the 16-chain kernel, draw by draw against the recursive CPU oracle."""
+    from tests.test_gpu_model import _log_uniform_problem
+    from bayes_drt_amd import _lib
+    from bayes_drt_amd.engine import Sampler
+    from bayes_drt_amd.model import Problem
+    from oracle import oracle as orc
+    lib = _lib.require_gpu()
+    monkeypatch.setenv('BDRT_SOLO', '0'); monkeypatch.setenv('BDRT_WIDE1', '0')
+    blk, Z, f, kw = _log_uniform_problem(nf, K)
+    prob = Problem([blk], Z, f, **kw)
+    assert prob.evaluator() == 4
+    ctrl = _lib.NutsControl(); lib.bdrt_nuts_defaults(C.byref(ctrl))
+    ctrl.max_treedepth = 5
+    warm, nd, n_units = 6, 4, 5
+    spec = np.zeros(n_units, dtype=np.int32); cid = np.arange(n_units, dtype=np.int32)
+    with Sampler(prob, n_units, warm, nd, 4321, ctrl, spec=spec, chain_ids=cid) as smp:
+        assert smp.kind() == 0
+        smp.run()
+        draws, lp, diag = smp.results()
+    om = orc.OracleModel([blk], Z, f, **kw)
+    octrl = orc.nuts_control(max_treedepth=5)
+    for c in range(n_units):
+        ref, lpr, dr = orc.nuts_sample(om, c, 4321, warm, nd, control=octrl)
+        assert dr['n_leapfrog'] == diag[c]['n_leapfrog'], (c, dr, diag[c])
+        assert np.max(np.abs(draws[c] - ref)) < 1e-6 * np.max(np.abs(ref)), c
+        assert np.allclose(lp[c], lpr, rtol=1e-8, atol=1e-6)
+    prob.close()

@@ -83,6 +83,43 @@ def test_both_operand_paths_of_the_one_block_tile(tag, K, monkeypatch):
     assert not np.array_equal(out['0'][1], out['1'][1])          # (another summation order: the switch did switch)
 
 
+def _log_uniform_problem(nf, K, nonneg=True, **kw):
+    """A synthetic single-DRT problem on log-uniform grids of equal spacing (A_re, A_im exactly Toeplitz), nf frequencies, K basis points."""
+    from bayes_drt_amd import matrices as gm
+    ppd = 10.0
+    f = 10.0 ** (6.0 - np.arange(nf) / ppd)
+    bf = 10.0 ** (6.0 + ((K - nf) // 2) / ppd - np.arange(K) / ppd)         # the basis brackets the measured range, on the same grid
+    tau = 1 / (2 * np.pi * bf); eps = 1 / np.mean(np.diff(np.log(tau)))
+    A = np.vstack([gm.construct_A(f, 'real', tau=tau, epsilon=eps), gm.construct_A(f, 'imag', tau=tau, epsilon=eps)])
+    L = [gm.construct_L(bf, tau=tau, epsilon=eps, order=o) for o in (0, 1, 2)]
+    rng = np.random.default_rng(nf * 1000 + K)
+    Z = np.concatenate([1.0 + rng.random(nf), -rng.random(nf)]) + 0.01 * rng.standard_normal(2 * nf)
+    blk = dict(A=A, L0=L[0], L1=L[1], L2=0.75 * L[2], nonneg=nonneg)
+    return blk, Z, f, dict(ups_alpha=1.0, ups_beta=0.1, **kw)
+
+
+@pytest.mark.parametrize('nf', [80, 81, 82])
+@pytest.mark.parametrize('K', [80, 81, 82, 160, 161, 162])
+def test_every_shape_of_the_table_path_vs_oracle(nf, K):
+    """The Toeplitz-table GEMMs take nf = 80..82 and K = 80..82 / 160..162: zero, one or two rows of each part of A (and of A^T)
+    beyond the 16-row tiles go through the VALU dot products, and the rows of g beyond the chunks of four through the odd chunk of
+    the backward GEMM.  Every combination against the oracle, with and without the sign constraint, and with the outlier error
+    models (whose extra parameters the same evaluator handles outside the sampler)."""
+    Problem, orc = _mods()
+    for nonneg, extra in ((True, {}), (False, {}), (True, dict(outlier_mode=1, so_lambda=10.0, so_alpha=5.0, so_beta=1.0)),
+                          (True, dict(outlier_mode=2, so_lambda=10.0))):
+        blk, Z, f, kw = _log_uniform_problem(nf, K, nonneg, **extra)
+        prob = Problem([blk], Z, f, **kw)
+        # (with outlier parameters and K >= 160 the table does not fit beside the sampler's theta rows: streamed fragments, evaluator 2)
+        assert prob.evaluator() == 4 or (extra and K >= 160 and prob.evaluator() == 2), (nf, K, extra, prob.evaluator())
+        om = orc.OracleModel([blk], Z, f, **kw)
+        rng = np.random.default_rng(nf + K)
+        th = rng.uniform(-2, 2, (19, prob.D))
+        _compare(prob, om, th, True)
+        _compare(prob, om, th[:5], False)
+        prob.close()
+
+
 def test_shapes_beside_the_table_path_keep_the_streamed_fragments():
     """nf = 41 / K = 51 (not blocks of 80): one of the evaluators that stream the packed fragments, not 4."""
     Problem, orc = _mods()
