@@ -40,6 +40,14 @@ def make_case(n):
         f = np.sort(f * np.exp(0.3 * decades / nf * rng.standard_normal(nf)))[::-1].copy()
     nblocks = int(rng.choice([1, 1, 1, 2, 2, 3]))
     own_spacing = rng.random() < 0.25                    # basis spacing unrelated to the frequency spacing: A is not Toeplitz
+    # every tenth case from 1000 on: a shape of the Toeplitz-table evaluator (one block, nf = 80..82, K = 80..82 or 160..162 on the frequencies' own
+    # log-uniform grid); drawn from a generator of its own so that the other cases keep their numbers
+    ta_K = 0
+    if n >= 1000 and n % 10 == 7:
+        r2 = np.random.default_rng(7000001 * n + 3)
+        nf = int(r2.choice([80, 81, 82])); ta_K = int(r2.choice([80, 81, 82, 160, 161, 162]))
+        f = np.logspace(np.log10(f_hi), np.log10(f_hi) - decades, nf)
+        irregular, own_spacing, nblocks = False, False, 1
     blocks = []
     desc = []
     mats = []
@@ -51,6 +59,8 @@ def make_case(n):
         else:
             step = decades / (nf - 1)
             n_hi, n_lo = int(round(ext_hi / step)), int(round(ext_lo / step))
+            if ta_K:
+                n_hi = max(ta_K - nf, 0) // 2; n_lo = max(ta_K - nf, 0) - n_hi
             K = nf + n_hi + n_lo
             cap = 192 if nblocks == 1 else 129
             while K > cap:
@@ -131,6 +141,7 @@ def run_case(n, verbose=False):
         if 'LDS' in str(e):
             return 'skip', text + ' :: ' + str(e)[:60]
         raise
+    evaluator = prob.evaluator()
     n_spectra = len(case['Z'])
     oms = [orc.OracleModel(case['blocks'], case['Z'][s], case['freq'], **case['kw']) for s in range(n_spectra)]
     rng = np.random.default_rng(n)
@@ -253,7 +264,7 @@ def run_case(n, verbose=False):
     if not np.isfinite(lr) or lr < oms[0].logp_grad(th0[0], False)[0]:
         fails.append('MAP: lp at the answer %.6g below lp at the start' % lr)
     prob.close()
-    text += note + ' D=%d kernel=%d warm=%d map=%s' % (prob.D, kind, warm, 'converged/%d' % rep[0]['newton_iterations'] if conv else
+    text += note + ' D=%d evaluator=%d kernel=%d warm=%d map=%s' % (prob.D, evaluator, kind, warm, 'converged/%d' % rep[0]['newton_iterations'] if conv else
                                         'rc%d,|g|=%.1e' % (rep[0]['return_code'], rep[0]['grad_inf']))
     if fails:
         return 'FAIL', text + '\n    ' + '\n    '.join(fails)

@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 # the first 24 cases + the extremes of the generator: 25 (K = 192, Nf = 128), 7 / 287 (two distributions of 129 at 128 / 107
 # frequencies, with the stacked outlier model: D = 742), 3 (K = 6 ... 8), 16 (6 frequencies, 215 basis functions), 598
-CASES = sorted(set(range(24)) | {25, 287, 457, 598})
+# ... and four cases on the shapes of the Toeplitz-table evaluator (every tenth case from 1000 on)
+CASES = sorted(set(range(24)) | {25, 287, 457, 598, 3017, 3027, 3047, 3057})
 
 
 @pytest.mark.parametrize('n', CASES)
