@@ -207,10 +207,13 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
                 if (k < K) { GW(B.o_ups + k, xrow[MAXBW + k]); GW(B.o_x + k, wrow[MAXBW + k]); }
             }
             wave_sync();
-            sv0 = hsum<LPC>(sv0); sv1 = hsum<LPC>(sv1); sv2 = hsum<LPC>(sv2);
+            // one butterfly for the three sums: lane l ends with sum l & 3; the owner of d_i (lane 6 + 3 b + i) fetches sum i from lane i
+            const double q3[4] = {sv0, sv1, sv2, 0.0};
+            const double tot3 = sum32_by_lane<4>(q3, l32);
+            const int iown = l32 - 6 - 3 * b;
+            const double sv = __shfl(tot3, hb | (iown & 3));
             if (l32 >= 6 + 3 * b && l32 < 9 + 3 * b) {                     // d_i gradients of this block: lane 6 + 3 b + i
-                const int i = l32 - 6 - 3 * b;
-                const double sv = i == 0 ? sv0 : (i == 1 ? sv1 : sv2);
+                const int i = iown;
                 GW(B.o_d + i, -0.5 * sraw * sv - 6.0 + 5.0 * lean_rcp(sraw) + jac);
             }
         }
@@ -303,15 +306,12 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
                 io.sigma_tot[(size_t)c * N2 + nf + n] = sqrt(s2_im);
             }
         }
-        sR = hsum<LPC>(sR); sL = hsum<LPC>(sL); sH = hsum<LPC>(sH); sHz2 = hsum<LPC>(sHz2); sHzr2 = hsum<LPC>(sHzr2); sHzi2 = hsum<LPC>(sHzi2);
+        // the six sums in one butterfly (sum32_by_lane: lane j ends with sum j, which is where its scalar gradient is wanted); the factors
+        // 0.05 * 2 * s_res etc. are 0.005 x the lane's own raw value (s_res = 0.05 raw_2, alpha_* = 0.05 raw_3..5)
+        const double q6[8] = {sR, sL, sH, sHz2, sHzr2, sHzi2, 0.0, 0.0};
+        const double tot6 = sum32_by_lane<8>(q6, l32);
         if (l32 < 6) {
-            double dl;
-            if (l32 == 0) dl = 100.0 * sR;
-            else if (l32 == 1) dl = P.induc_scale * sL;
-            else if (l32 == 2) dl = 0.05 * 2.0 * s_res * sH;
-            else if (l32 == 3) dl = 0.05 * 2.0 * a_p * sHz2;
-            else if (l32 == 4) dl = 0.05 * 2.0 * a_r * sHzr2;
-            else dl = 0.05 * 2.0 * a_i * sHzi2;
+            const double dl = (l32 == 0 ? 100.0 : (l32 == 1 ? P.induc_scale : 0.005 * sraw)) * tot6;
             const int j = l32 < 2 ? l32 : P.o_err + (l32 - 2);
             gsc = sraw * (dl - sraw) + jac;
             GW(j, gsc);
