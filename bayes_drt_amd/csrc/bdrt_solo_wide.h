@@ -261,8 +261,11 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             wr[2 * g.XL + MAXBW + k] = -d2 * v2 * iu2;
         }
         if (wave < 3) {                                    // the K-threads live in waves 0..2 (K <= 192)
-            const double a = solo_wave_sum(sv0), c = solo_wave_sum(sv1), d = solo_wave_sum(sv2);
-            if (lane == 0) { ered[wave * 32 + 8 + 3 * b] = a; ered[wave * 32 + 9 + 3 * b] = c; ered[wave * 32 + 10 + 3 * b] = d; }
+            // one butterfly for the three sums (sum32_by_lane: lane j of each half-wave ends with sum j), the halves meet in lanes 0..2
+            const double q3[4] = {sv0, sv1, sv2, 0.0};
+            double t3 = sum32_by_lane<4>(q3, lane);
+            t3 += __shfl_xor(t3, 32);
+            if (lane < 3) ered[wave * 32 + 8 + 3 * b + lane] = t3;
         }
         __syncthreads();
         BDRT_W1_PROF(3);
@@ -345,12 +348,11 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
             }
         }
         if (wave < 2) {                                    // nf <= 128: the likelihood threads are waves 0 and 1
-            const double a = solo_wave_sum(sR), b2 = solo_wave_sum(sL), c = solo_wave_sum(sH), d = solo_wave_sum(sHz2),
-                         e = solo_wave_sum(sHzr2), f = solo_wave_sum(sHzi2);
-            if (lane == 0) {
-                double *o = ered + wave * 32;
-                o[0] = a; o[1] = b2; o[2] = c; o[3] = d; o[4] = e; o[5] = f;
-            }
+            // the six sums in one butterfly: lanes 0..5 -> slots 0..5
+            const double q6[8] = {sR, sL, sH, sHz2, sHzr2, sHzi2, 0.0, 0.0};
+            double t6 = sum32_by_lane<8>(q6, lane);
+            t6 += __shfl_xor(t6, 32);
+            if (lane < 6) ered[wave * 32 + lane] = t6;
         }
     }
     __syncthreads();
