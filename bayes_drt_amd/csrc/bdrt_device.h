@@ -139,9 +139,13 @@ __device__ __forceinline__ double lean_exp(double x)
 
 // log(x) for finite, normal x > 0: x = 2^e m with m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f),
 // log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with the classic degree-7 polynomial in s^2 (fdlibm's e_log.c coefficients, error
-// of the approximation < 2^-58.45), log x = e ln2_hi + (log(1 + f) + e ln2_lo).  ~33 instructions against 58.
+// of the approximation < 2^-58.45), log x = e ln2_hi + (log(1 + f) + e ln2_lo).  ~35 instructions against 58.
+// Anything else -- zero, a denormal, a negative number, inf, NaN -- gives NaN (one v_cmp_class and a select): a point whose
+// sigma^2 product has left the normal range is then rejected by the logarithm itself, not by what a neighbouring
+// reciprocal happens to return.
 __device__ __forceinline__ double lean_log(double x)
 {
+    const bool in_domain = __builtin_amdgcn_class(x, 0x100);       // positive normal
     double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(x);
     const bool low = m < 0.70710678118654752440;
@@ -154,7 +158,8 @@ __device__ __forceinline__ double lean_log(double x)
     const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
                                                          2.857142874366239149e-01), 6.666666666666735130e-01);
     const double R = t1 + t2, hfsq = 0.5 * f * f, de = (double)e;
-    return __builtin_fma(de, 6.93147180369123816490e-01, f - (hfsq - __builtin_fma(s, hfsq + R, de * 1.90821492927058770002e-10)));
+    const double r = __builtin_fma(de, 6.93147180369123816490e-01, f - (hfsq - __builtin_fma(s, hfsq + R, de * 1.90821492927058770002e-10)));
+    return in_domain ? r : __builtin_nan("");
 }
 
 // Sum over the 32 lanes of a half-wave, result in every lane.  Four of the five butterfly steps are DPP moves on the VALU

@@ -26,8 +26,17 @@
 #include "bdrt_lbfgs.h"
 #include "bdrt_nuts_device.h"
 #include "bdrt_solo.h"
+#include "bdrt_wave.h"
+#include "bdrt_nuts_args.h"
 
 namespace bdrt {
+
+// one-chain-per-wave sampler / evaluator (bdrt_wave.hip)
+size_t wave_lds_request(const WaveGeom &g, int n_wg, int n_cu, int *nhot);
+int launch_wave_nuts(const DevProblem *dp, const NutsParams &np, const NutsArgs &args, const WaveGeom &g, int nhot, int n_wg, size_t lds,
+                     hipStream_t stream);
+int launch_wave_eval(const DevProblem *dp, const WaveGeom &g, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
+                     double *d_grad, int n_wg, size_t lds, hipStream_t stream);
 
 constexpr int MAXD = 10;            // checkpoint slots (>= max_treedepth)
 constexpr int NQ_CHK = 2 * MAXD + 2;
@@ -55,23 +64,6 @@ __device__ __forceinline__ void lds_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-struct NutsArgs {
-    double *vecs;          // [n_wg][V_COUNT][16 chains][ds]  (one contiguous row per chain and vector)
-    ChainState *states;    // [n_units]
-    double *draws;         // [n_units][n_draws][D]
-    double *lp_draws;      // [n_units][n_draws]
-    unsigned long long *leap_counter;   // total leapfrogs (all chains)
-    int *done_counter;     // workgroups whose chains are all finished
-    int n_units;
-    const int *slot_unit;  // 16-chain kernel: [n_wg][16] unit held by slot k of workgroup wg (-1: empty).  Unit <-> slot is an
-                           // indirection so that live chains can be re-packed into fewer workgroups during a run (compaction)
-    int cpw;               // chains per workgroup at creation (1..16): few chains are spread over many workgroups / waves
-    int rounds;
-    int ds;                // row stride of the state vectors (D rounded up to 32)
-    long long *prof;       // optional [n_wg][32] cycle counters (phase profile)
-    const int *unit_map;   // one-chain-per-workgroup kernel: unit of workgroup b (nullptr: b) -- the tail of a large run (below)
-    int *active_counter;   // 16-chain kernel: chains still running at the end of the launch (all workgroups)
-};
 
 #include "bdrt_nuts_wide.h"
 #include "bdrt_solo_wide.h"
@@ -891,25 +883,6 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 // One chain per workgroup (bdrt_solo.h): the same transition logic as nuts_kernel, element j of every vector in thread j,
 // all vectors in LDS.  Global state layout: vecs [n_units][SG_COUNT][ds]; states [n_units].
 // ---------------------------------------------------------------------------------------------------------------------------
-// The part of a chain's scalar state that a leapfrog touches: kept in registers by every thread (identical updates).  The
-// rest (adaptation windows, dual averaging, counters) stays in LDS and is visited when a transition ends or the step size is
-// searched; same member names as ChainState, so the statements of the three samplers read alike.
-struct SoloHot {
-    int phase, iter, depth, leaf, nleaves, dir, n_leap_iter, init_attempt, eps_dir, eps_trials;
-    double eps, H0, lsw, lsw_sub, lps, lpq, sum_metro;
-    __device__ __forceinline__ void from(const ChainState &c)
-    {
-        phase = c.phase; iter = c.iter; depth = c.depth; leaf = c.leaf; nleaves = c.nleaves; dir = c.dir; n_leap_iter = c.n_leap_iter;
-        init_attempt = c.init_attempt; eps_dir = c.eps_dir; eps_trials = c.eps_trials;
-        eps = c.eps; H0 = c.H0; lsw = c.lsw; lsw_sub = c.lsw_sub; lps = c.lps; lpq = c.lpq; sum_metro = c.sum_metro;
-    }
-    __device__ __forceinline__ void to(ChainState &c) const
-    {
-        c.phase = phase; c.iter = iter; c.depth = depth; c.leaf = leaf; c.nleaves = nleaves; c.dir = dir; c.n_leap_iter = n_leap_iter;
-        c.init_attempt = init_attempt; c.eps_dir = eps_dir; c.eps_trials = eps_trials;
-        c.eps = eps; c.H0 = H0; c.lsw = lsw; c.lsw_sub = lsw_sub; c.lps = lps; c.lpq = lpq; c.sum_metro = sum_metro;
-    }
-};
 
 template <int WPE>   // waves per SIMD the register budget allows: 2 = one workgroup per CU, 4 = two (when their LDS fits)
 __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, SoloGeom g)
@@ -1460,6 +1433,13 @@ static bool solo_duo_fits(const DevProblem &P)
     return 2 * (((size_t)g.o_vec + (size_t)SOLO_NHOT * g.DSS) * sizeof(double) + 64) <= 160 * 1024;
 }
 
+// Which kernel advances the one-chain layout (state rows [unit][SG_COUNT][ds]) while `live` chains are running: the one-chain-per-
+// wave kernel from 2.5 live chains per CU on (measured at 81 x 161, profiles/r04/wave_sweep.txt: below that two 512-thread
+// workgroups per CU are faster per leapfrog, above it eight independent waves per CU are), up to the eight per CU it keeps
+// resident.  BDRT_WAVE=1 / 0: always / never.
+static bool wave_pays(int live, int n_cu) { return 2 * live > 5 * n_cu; }
+static int wave_max_units(int n_cu) { return 8 * n_cu + n_cu / 4; }
+
 // liveness of every unit (1: the chain is still running), for the host's re-packing decision
 __global__ void nuts_live_kernel(const ChainState *states, int n, int *live)
 {
@@ -1484,6 +1464,12 @@ struct Sampler {
     bool hw = false;         // general half-wave evaluator (MODE 4: several distributions, parallel blocks)
     bool solo = false;       // one chain per workgroup, state in LDS (bdrt_solo.h): few chains of the headline family
     SoloGeom geom;
+    bool wave = false;       // the one-chain layout may be advanced by the one-chain-per-WAVE kernel (bdrt_wave.h: same state layout)
+    int wave_force = -1;     // BDRT_WAVE: 1 always, 0 never (-1: by the number of live chains, wave_pays)
+    bool solo_ok = false;    // the 512-thread one-chain kernels take this problem (else the wave kernel advances the layout whatever `live`)
+    bool wave_last = false;  // the last launch used the wave kernel (bdrt_sampler_kind)
+    int live = 0;            // chains of the one-chain layout still running (after the last launch that read the done counter)
+    WaveGeom geomw;
     bool wide1 = false;      // one chain per workgroup, general block model (bdrt_solo_wide.h): few chains of any other Toeplitz family
     Wide1Geom geom1;
     int nhot1 = 0;           // rows of the chain that kernel keeps in LDS
@@ -1496,6 +1482,7 @@ struct Sampler {
     unsigned long long *d_leaps = nullptr;
     int rounds_default = 256;
     long long *d_prof = nullptr;
+    int prof_wg = 0;                  // workgroups d_prof was allocated for (the layout can change under it: compaction, tail migration)
     // tail migration (nuts_migrate_kernel)
     int *d_active = nullptr;          // live chains after the last launch of the 16-chain kernel
     int n_cu = 256;
@@ -1708,13 +1695,24 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     S.solo = solo_capable(P.dev) && n_units <= (solo_duo_fits(P.dev) ? 5 * n_cu : 4 * n_cu);
     S.n_cu = n_cu;
     // a run that starts on the 16-chain kernel may hand its last live chains to the one-chain-per-workgroup kernel
-    S.may_migrate = (solo_capable(P.dev) || wide1_capable(P.dev)) && !S.solo;
+    S.may_migrate = (solo_capable(P.dev) || wide1_capable(P.dev) || wave_capable(P.dev)) && !S.solo;
     if (const char *e = getenv("BDRT_SOLO")) {                                                  // diagnostics: force / forbid
         S.solo = solo_capable(P.dev) && atoi(e) != 0;
         S.may_migrate = false;
     }
     if (const char *e = getenv("BDRT_TAIL_MIGRATION")) S.may_migrate = S.may_migrate && atoi(e) != 0;
     if (getenv("BDRT_WIDE1") && atoi(getenv("BDRT_WIDE1")) == 0 && !solo_capable(P.dev)) S.may_migrate = false;
+    // one chain per wave (bdrt_wave.h) for the one-chain layout: BDRT_WAVE=1 whenever the problem allows, 0 never
+    S.solo_ok = solo_capable(P.dev);
+    S.wave = wave_capable(P.dev);
+    if (const char *e = getenv("BDRT_WAVE")) { S.wave_force = atoi(e) != 0; S.wave = S.wave && S.wave_force; }
+    if (getenv("BDRT_CHAINS_PER_WG")) S.wave = false;                                           // (a forced packing means the 16-chain kernel)
+    if (getenv("BDRT_SOLO") && S.wave_force != 1) S.wave = false;                                // (BDRT_SOLO=0 / 1: the 16-chain kernel / the 512-thread one-chain kernels, forced)
+    if (S.wave && !getenv("BDRT_SOLO") && (S.wave_force == 1 || (n_units <= wave_max_units(n_cu) && (wave_pays(n_units, n_cu) || !S.solo_ok)))) {
+        S.solo = true;                                                                          // start in the one-chain layout
+        S.may_migrate = false;
+    }
+    if (S.wave) S.geomw = wave_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
     if (S.solo) S.geom = solo_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
     // chains per workgroup: fill every CU with one workgroup before putting a second chain on any wave
     {
@@ -1764,7 +1762,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     S.args.ds = DS;
     const int ncol = (S.solo || S.wide1) ? 1 : NC, nrow = S.solo ? (int)SG_COUNT : (int)V_COUNT;
     const int r_minv = S.solo ? (int)SV_MINV : (int)V_MINV, r_th = S.solo ? (int)SV_TH : (int)V_TH;
-    if (S.solo) S.lds_bytes = (size_t)S.geom.total * sizeof(double) + 64;
+    if (S.solo && S.solo_ok) S.lds_bytes = (size_t)S.geom.total * sizeof(double) + 64;
     const size_t nvec = (size_t)S.n_wg * nrow * ncol * DS;
     std::vector<double> hv(nvec, 0.0);
     std::vector<ChainState> hs((size_t)n_units);
@@ -1840,6 +1838,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     S.args.active_counter = S.d_active;
     S.args.unit_map = nullptr;
     S.n_solo = n_units;
+    S.live = n_units;
     S.args.n_units = n_units;
     if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     static LdsAttrCache attr_cache;
@@ -1907,8 +1906,17 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
         if (S.wide1)
             hipLaunchKernelGGL(nuts_wide1_kernel, dim3(S.n_wg), dim3(SOLO_NT), wide1_lds_bytes(S.geom1, S.args.ds, S.nhot1), S.stream, dp,
                                S.np, S.args, S.geom1, S.nhot1);
+        else if (S.solo && S.wave && (S.wave_force == 1 || !S.solo_ok || wave_pays(S.live, S.n_cu)))
+        {
+            // LDS share (= chains per CU) by the chains still running: finished ones leave their wave at once
+            int nhot = 0;
+            const size_t lds = wave_lds_request(S.geomw, std::max(1, std::min(S.live, S.n_solo)), S.n_cu, &nhot);
+            if (launch_wave_nuts(dp, S.np, S.args, S.geomw, nhot, S.n_solo, lds, S.stream)) return -10;
+            S.wave_last = true;
+        }
         else if (S.solo)
         {
+            S.wave_last = false;
             // more chains than CUs: two workgroups per CU (128 VGPRs each, 16 of the chain's rows in LDS) overlap each other's
             // latencies; with at most one chain per CU the full-LDS variant is the faster one.  BDRT_SOLO_DUO=0 / 1: never / always.
             const size_t lds2 = ((size_t)S.geom.o_vec + (size_t)SOLO_NHOT * S.geom.DSS) * sizeof(double) + 64;
@@ -1951,6 +1959,7 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
         BDRT_HIP(hipMemcpyAsync(&done, S.d_done, sizeof(int), hipMemcpyDeviceToHost, S.stream));
         BDRT_HIP(hipStreamSynchronize(S.stream));
         *all_done = done >= S.n_wg;
+        if (S.solo) S.live = std::max(0, S.n_solo - done);
         return harvest_events(S, true);
     }
     return harvest_events(S, false);
@@ -2031,8 +2040,10 @@ static int maybe_migrate_tail(Sampler &S, int active)
 {
     // the one-chain kernels run one or two chains per CU at a time, ~4x faster per leapfrog: the LDS-resident one wins below ~4.75
     // live chains per CU when two of its workgroups fit a CU (else ~3.5), the general one below ~2.75
-    const bool to_solo = solo_capable(S.prob->dev);
-    if (active <= 0 || active > (to_solo ? (solo_duo_fits(S.prob->dev) ? (19 * S.n_cu) / 4 : (7 * S.n_cu) / 2) : (11 * S.n_cu) / 4)) return 0;
+    const bool to_solo = solo_capable(S.prob->dev) || S.wave;
+    // (the one-chain-per-wave kernel runs eight chains per CU at 108 M evals/s against 73 M of half-empty tiles: profiles/r04/wave_sweep.txt)
+    const int limit = S.wave ? 8 * S.n_cu : (to_solo ? (solo_duo_fits(S.prob->dev) ? (19 * S.n_cu) / 4 : (7 * S.n_cu) / 2) : (11 * S.n_cu) / 4);
+    if (active <= 0 || active > limit) return 0;
     std::vector<ChainState> hs((size_t)S.n_units);
     BDRT_HIP(hipMemcpy(hs.data(), S.args.states, hs.size() * sizeof(ChainState), hipMemcpyDeviceToHost));
     std::vector<int> map;
@@ -2068,7 +2079,7 @@ static int maybe_migrate_tail(Sampler &S, int active)
     }
     const SoloGeom g = solo_geometry(S.prob->dev.nf, S.prob->dev.blk[0].K, S.prob->dev.D);
     const size_t lds = (size_t)g.total * sizeof(double) + 64;
-    if (lds > S.lds_bytes) return 0;                      // (bdrt_sampler_create raised every kernel's LDS limit to the 16-chain size)
+    if (S.solo_ok && lds > S.lds_bytes) return 0;         // (bdrt_sampler_create raised every kernel's LDS limit to the 16-chain size)
     if (hipMalloc(&vnew.p, map.size() * (size_t)SG_COUNT * g.DSS * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return 0; }   // (keep going as is)
     if (hipMalloc(&dmap.p, map.size() * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return 0; }
     BDRT_HIP(hipMemcpy(dmap.p, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -2086,6 +2097,7 @@ static int maybe_migrate_tail(Sampler &S, int active)
     S.lds_bytes = lds;
     S.solo = true;
     S.n_solo = (int)map.size();
+    S.live = S.n_solo;
     S.n_wg = S.n_solo;                                   // (the all-done test counts finished workgroups)
     S.migrated = true;
     return 0;
@@ -2140,7 +2152,16 @@ int bdrt_sampler_results(bdrt_sampler *s, double *draws, double *lp, bdrt_chain_
 
 int bdrt_sampler_tail_units(bdrt_sampler *s) { return s && s->impl.migrated ? s->impl.n_solo : 0; }
 int bdrt_sampler_compactions(bdrt_sampler *s) { return s ? s->impl.n_compactions : -1; }
-int bdrt_sampler_kind(bdrt_sampler *s) { return !s ? -1 : (s->impl.wide1 ? 2 : (s->impl.solo ? 1 : 0)); }
+int bdrt_sampler_kind(bdrt_sampler *s)
+{
+    if (!s) return -1;
+    const Sampler &S = s->impl;
+    if (S.wide1) return 2;
+    if (!S.solo) return 0;
+    // before the first launch: what the first launch will use
+    const bool w = S.n_launch ? S.wave_last : (S.wave && (S.wave_force == 1 || !S.solo_ok || wave_pays(S.live, S.n_cu)));
+    return w ? 3 : 1;
+}
 
 int64_t bdrt_sampler_total_leapfrogs(bdrt_sampler *s)
 {
@@ -2170,23 +2191,26 @@ int bdrt_sampler_phase_profile(bdrt_sampler *s, int enable, long long *cycles32)
     if (!s) return -1;
     Sampler &S = s->impl;
     BDRT_HIP(hipStreamSynchronize(S.stream));
+    // d_prof holds prof_wg workgroups' slots: the layout may have changed since (compaction, tail migration switch the profile off
+    // and can leave MORE workgroups than it was allocated for) -- every copy / fill below is sized by the allocation
     if (cycles32) {
         for (int k = 0; k < 32; ++k) cycles32[k] = 0;
         if (S.d_prof) {
-            std::vector<long long> h((size_t)S.n_wg * 32);
+            std::vector<long long> h((size_t)S.prof_wg * 32);
             BDRT_HIP(hipMemcpy(h.data(), S.d_prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-            for (int w = 0; w < S.n_wg; ++w)
+            for (int w = 0; w < S.prof_wg; ++w)
                 for (int k = 0; k < 32; ++k) cycles32[k] += h[(size_t)w * 32 + k];
         }
     }
+    if (S.d_prof && (!enable || S.prof_wg < S.n_wg)) { hipFree(S.d_prof); S.d_prof = nullptr; S.prof_wg = 0; }
     if (enable && !S.d_prof) {
         BDRT_HIP(hipMalloc((void **)&S.d_prof, (size_t)S.n_wg * 32 * sizeof(long long)));
+        S.prof_wg = S.n_wg;
     }
     if (S.d_prof) {
-        BDRT_HIP(hipMemset(S.d_prof, 0, (size_t)S.n_wg * 32 * sizeof(long long)));
+        BDRT_HIP(hipMemset(S.d_prof, 0, (size_t)S.prof_wg * 32 * sizeof(long long)));
         BDRT_HIP(hipStreamSynchronize(nullptr));        // (same ordering rule as in bdrt_sampler_create)
     }
-    if (!enable && S.d_prof) { hipFree(S.d_prof); S.d_prof = nullptr; }
     S.args.prof = S.d_prof;
     return 0;
 }
@@ -2254,6 +2278,31 @@ int bdrt_debug_solo_logp_grad(bdrt_problem *p, const double *theta, const int *s
     if (e == hipSuccess && grad) e = hipMemcpy(grad, dg, nb, hipMemcpyDeviceToHost);
     hipFree(dth); hipFree(dg); hipFree(dlp); hipFree(dsp);
     if (e != hipSuccess) { set_error("bdrt_debug_solo_logp_grad: %s", hipGetErrorString(e)); return -10; }
+    return 0;
+}
+
+// the one-chain-per-wave evaluator (bdrt_wave.h) on B points: parity tests
+int bdrt_debug_wave_logp_grad(bdrt_problem *p, const double *theta, const int *spec, int B, int jacobian, double *lp, double *grad)
+{
+    if (!p || !theta || B < 1) { set_error("bdrt_debug_wave_logp_grad: bad arguments"); return -1; }
+    Problem &P = p->impl;
+    if (!wave_capable(P.dev)) { set_error("problem does not take the one-chain-per-wave path"); return -2; }
+    BDRT_HIP(hipSetDevice(P.device));
+    const WaveGeom g = wave_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
+    const size_t lds = wave_lds_bytes(g, 0);
+    double *dth = nullptr, *dlp = nullptr, *dg = nullptr;
+    int *dsp = nullptr;
+    const size_t nb = (size_t)B * P.dev.D * sizeof(double);
+    BDRT_HIP(hipMalloc((void **)&dth, nb)); BDRT_HIP(hipMalloc((void **)&dg, nb)); BDRT_HIP(hipMalloc((void **)&dlp, B * sizeof(double)));
+    BDRT_HIP(hipMemcpy(dth, theta, nb, hipMemcpyHostToDevice));
+    if (spec) { BDRT_HIP(hipMalloc((void **)&dsp, B * sizeof(int))); BDRT_HIP(hipMemcpy(dsp, spec, B * sizeof(int), hipMemcpyHostToDevice)); }
+    int rc = launch_wave_eval((const DevProblem *)P.d_dev, g, dth, dsp, B, jacobian, dlp, dg, std::min(B, 2048), lds, 0);
+    hipError_t e = rc ? hipErrorUnknown : hipDeviceSynchronize();
+    if (e == hipSuccess && lp) e = hipMemcpy(lp, dlp, B * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && grad) e = hipMemcpy(grad, dg, nb, hipMemcpyDeviceToHost);
+    hipFree(dth); hipFree(dg); hipFree(dlp); hipFree(dsp);
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error("bdrt_debug_wave_logp_grad: %s", hipGetErrorString(e)); return -10; }
     return 0;
 }
 

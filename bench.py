@@ -190,6 +190,9 @@ def _free_port():
         return so.getsockname()[1]
 
 
+WATCHDOG_EXIT = 4      # exit code of a run whose rate line is valid but whose multi-rank round trip / teardown hung
+
+
 def self_launch(n, argv):
     """`bench.py --gpus N` started without a launcher: run the N ranks as a child `python -m torch.distributed.run` (the
     command the driver itself uses), relay its output and return its exit code.  Refuses (non-zero) when the box has fewer
@@ -212,6 +215,13 @@ def self_launch(n, argv):
     for ln in child.stdout.splitlines():
         if ln not in lines:
             sys.stderr.write(ln + '\n')
+    if child.returncode != 0 and len(lines) == 1 and '"timed out; the rate above was measured before it"' in lines[0]:
+        # a rank's watchdog ended the job (exit code WATCHDOG_EXIT; torchrun reports its own non-zero code): the rate in the line
+        # was measured before the sharded round trip hung -- relay the line, and a non-zero code so that this is never a success
+        sys.stderr.write('bench.py: the sharded round trip (or the teardown) hung; launcher exited %d; the rate was measured before it\n'
+                         % child.returncode)
+        print(lines[0])
+        return WATCHDOG_EXIT
     if child.returncode != 0 or len(lines) != 1:
         sys.stderr.write('bench.py: launcher exited %d with %d result line(s)\n' % (child.returncode, len(lines)))
         return child.returncode or 3
@@ -490,19 +500,24 @@ def main():
     # (or the teardown of the process group) not come back -- the steady-state measurement must not hang on it
     printed = threading.Event()
     finished = threading.Event()
+    emit_lock = threading.Lock()
 
-    def emit():
-        if rank == 0 and not printed.is_set():
-            printed.set()
-            print(json.dumps(line), flush=True)
+    def emit(extra=None):
+        # one critical section for "amend the line + print it": the main thread and the watchdog can both get here
+        with emit_lock:
+            if rank == 0 and not printed.is_set():
+                if extra:
+                    line['config'].update(extra)
+                printed.set()
+                print(json.dumps(line), flush=True)
 
     if use_dist:
         def watchdog():
             if not finished.wait(float(os.environ.get('BDRT_BENCH_ROUNDTRIP_TIMEOUT', '180'))):
-                if rank == 0 and not printed.is_set():
-                    line['config']['dist_roundtrip'] = {'error': 'timed out; the rate above was measured before it'}
-                emit()
-                os._exit(0)
+                emit({'dist_roundtrip': {'error': 'timed out; the rate above was measured before it'}})
+                # a hung collective / teardown is never a success: the line stands (the rate was measured before the
+                # exercise), the exit code says the round trip failed (WATCHDOG_EXIT; self_launch relays both)
+                os._exit(WATCHDOG_EXIT)
         threading.Thread(target=watchdog, daemon=True).start()
         small = dict(kw, Z=np.atleast_2d(Zall)[:8 * world]) if rank == 0 else None
         t_rt = time.perf_counter()
@@ -516,8 +531,7 @@ def main():
                          'warmup': 6, 'draws': 4, 'gather': 'summary', 'finite': bool(np.all(np.isfinite(res['mean'])))}
         except Exception as exc:                  # reported in the line; the steady-state rate stands on its own
             roundtrip = {'error': '%s: %s' % (type(exc).__name__, exc)}
-        if rank == 0:
-            line['config']['dist_roundtrip'] = roundtrip
+        emit({'dist_roundtrip': roundtrip})
     emit()
     if use_dist:
         dist.destroy_process_group()

@@ -86,37 +86,40 @@ def test_summary_on_host_draws_equals_summary_on_the_sampler():
     prob.close()
 
 
-def test_tail_of_a_large_run_moves_to_the_one_chain_kernel(monkeypatch):
-    """A run with more than five chains per CU starts on the 16-chain kernel; when few chains are still alive `bdrt_sampler_run`
-    hands them to the one-chain-per-workgroup kernel (nuts_migrate_kernel; two workgroups per CU while there are more chains
-    than CUs).  Same random numbers, same arithmetic up to summation order: the run with the hand-over equals the run without
-    it (BDRT_TAIL_MIGRATION=0) chain by chain."""
+def test_tail_of_a_large_run_moves_to_the_one_chain_kernels(monkeypatch):
+    """A run with more than eight chains per CU starts on the 16-chain kernel; once eight per CU or fewer are still alive
+    `bdrt_sampler_run` hands them to the one-chain layout (nuts_migrate_kernel), where the one-chain-per-wave kernel advances
+    them while more than 2.5 per CU are running and the 512-thread one-chain kernels finish the rest.  Same random numbers, same
+    arithmetic up to summation order: the run with the hand-over equals the run without it (BDRT_TAIL_MIGRATION=0) chain by
+    chain."""
     import bench
     from bayes_drt_amd.engine import Sampler
     from bayes_drt_amd.model import Problem
-    kw = bench.build_problem_kwargs(200)
+    ns = 300
+    kw = bench.build_problem_kwargs(ns)
     blocks, Z, freq = kw.pop('blocks'), kw.pop('Z'), kw.pop('freq')
     prob = Problem(blocks, Z, freq, **kw)
-    n_units, warm, nd = 200 * 8, 24, 12
-    spec = np.repeat(np.arange(200, dtype=np.int32), 8)
-    cid = np.tile(np.arange(8, dtype=np.int32), 200)
+    n_units, warm, nd = ns * 8, 24, 12
+    spec = np.repeat(np.arange(ns, dtype=np.int32), 8)
+    cid = np.tile(np.arange(8, dtype=np.int32), ns)
     from bayes_drt_amd._lib import NutsControl
     ctrl = NutsControl(); prob._lib.bdrt_nuts_defaults(C.byref(ctrl)); ctrl.max_treedepth = 6
 
     def run():
         with Sampler(prob, n_units, warm, nd, 77, ctrl, spec=spec, chain_ids=cid) as smp:
+            assert smp.kind() == 0
             smp.run()
             tail = smp.tail_units()
-            return smp.results() + (tail,)
+            return smp.results() + (tail, smp.kind())
 
-    d1, lp1, g1, tail1 = run()
+    d1, lp1, g1, tail1, kind1 = run()
     monkeypatch.setenv('BDRT_TAIL_MIGRATION', '0')
-    d0, lp0, g0, tail0 = run()
-    assert tail0 == 0 and 0 < tail1 <= 1216, (tail0, tail1)
+    d0, lp0, g0, tail0, kind0 = run()
+    assert tail0 == 0 and kind0 == 0 and 0 < tail1 <= 2048 and kind1 in (1, 3), (tail0, tail1, kind0, kind1)
     assert np.all(np.isfinite(d1)) and np.all(np.isfinite(lp1))
     err = np.max(np.abs(d1 - d0), axis=(1, 2)) / np.max(np.abs(d0))
     # chains that had finished before the hand-over are untouched; the others continue with other summation orders
-    assert np.mean(err == 0.0) > 0.2 and np.mean(err < 1e-6) > 0.9, (np.mean(err == 0.0), np.mean(err < 1e-6))
+    assert np.mean(err == 0.0) > 0.1 and np.mean(err < 1e-6) > 0.9, (np.mean(err == 0.0), np.mean(err < 1e-6))
     n1, n0 = sum(x['n_leapfrog'] for x in g1), sum(x['n_leapfrog'] for x in g0)
     assert abs(n1 - n0) < 0.01 * n0
 

@@ -209,9 +209,14 @@ def _usable_kats():
 # distance between the stored coefficients (an L-BFGS iterate that stopped by a tolerance test) and the
 # stationary point reached from them, per model family: measured maxima (profiles/r03/map_kats.txt) with head-room.  The
 # sign-free `Series` fits of the truncated spectra sit in long flat valleys (stored gradient max-norm up to 10): there the
-# iterate is far from the optimum in coefficient space while both reproduce the spectrum.
+# iterate is far from the optimum in coefficient space while both reproduce the spectrum.  For `Series` / `Series_outliers`
+# (bound 4.6 = 460 %) the coefficient distance is therefore REPORT-ONLY: what the test asserts for them is lp >= lp_stored,
+# the predicted spectrum (Z_hat) and -- identifiable in the flat valleys -- gamma on the well-determined directions (below).
 _COEF_BOUND = {'Series_pos': 0.75, 'Series-Parallel_pos': 1.0, 'Series-2Parallel_pos': 0.4, 'Series': 4.6,
                'Series_outliers': 4.6, 'Series-Parallel_pos_outliers': 1.0}
+
+
+_PROJ_BOUND = 0.5      # (measured maximum over the 36 fits: see profiles/r04/map_kats.txt)
 
 
 @pytest.mark.parametrize('name', _usable_kats())
@@ -238,9 +243,19 @@ def test_map_vs_reference_stored_fit(name):
     d = rel_l2(coef(con[0]), coef(k['params']))
     _, Zh, _ = prob.transformed(out)
     dz = rel_l2(Zh[0], k['opt']['Z_hat'])
-    print('%s [%s]: lp stored %.4f -> %.4f, |g stored|inf %.3e, coef rel-L2 %.3e, Z_hat rel-L2 %.3e, rc %d'
-          % (name, k['family'], lp_ref[0], rep[0]['lp'], np.max(np.abs(g_ref)), d, dz, rep[0]['return_code']))
+    # identifiable part of the coefficients: their projection on the well-determined right singular directions of the first
+    # block's A (singular value >= 1 % of the largest) -- what the data pin down even in the flat valleys
+    A0 = np.asarray(k['kw']['blocks'][0]['A'], dtype=float)
+    K0 = prob.Ks[0]
+    U, sv, Vt = np.linalg.svd(A0, full_matrices=False)
+    V = Vt[sv >= 1e-2 * sv[0]]
+    x_ours, x_ref = con[0][lay['x'][0]:lay['x'][0] + K0], k['params'][lay['x'][0]:lay['x'][0] + K0]
+    dproj = float(np.linalg.norm(V @ (x_ours - x_ref)) / np.linalg.norm(V @ x_ref))
+    print('%s [%s]: lp stored %.4f -> %.4f, |g stored|inf %.3e, coef rel-L2 %.3e (well-determined directions: %.3e, %d of %d), '
+          'Z_hat rel-L2 %.3e, rc %d' % (name, k['family'], lp_ref[0], rep[0]['lp'], np.max(np.abs(g_ref)), d, dproj, len(V), K0, dz,
+                                        rep[0]['return_code']))
     assert d < _COEF_BOUND[k['family']], (k['family'], d)
+    assert dproj < _PROJ_BOUND, (k['family'], dproj)
     assert dz < 0.05, dz
 
 

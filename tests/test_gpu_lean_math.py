@@ -47,6 +47,10 @@ def test_lean_log():
     assert np.all(got[bad] == 0.0)
     u = _ulps(got[~bad], ref[~bad])
     assert u.max() <= 1.5, (u.max(), x[~bad][np.argmax(u)])
+    # outside the domain (zero, denormal, negative, inf, NaN): NaN, so that a point whose sigma^2 product has left the normal
+    # range is rejected by the logarithm itself -- whatever the companion reciprocal returns
+    out = _run(np.array([0.0, -0.0, 5e-324, 1e-310, -1.0, -1e-300, np.inf, -np.inf, np.nan]))[1]
+    assert np.all(np.isnan(out)), out
 
 
 def test_lean_rcp():

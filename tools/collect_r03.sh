@@ -60,5 +60,6 @@ if has fuzz; then
   python -m tests.fuzz_inverter --first 3000 --count 200 > $OUT/fuzz_inverter.txt 2>&1
   python -m tests.fuzz_post --first 3000 --count 200 > $OUT/fuzz_post.txt 2>&1
 fi
-find gpurun_out -name '*.db' -size +1M -delete 2>/dev/null
+# only what this script produced (other rounds' / tags' databases are read by tools/make_traffic_json.py, rocpd_pmc.py afterwards)
+find $OUT gpurun_out/prof_r03 gpurun_out/sq_r03 -name '*.db' -size +20M -delete 2>/dev/null
 ls -la $OUT
