@@ -2,7 +2,8 @@
 
 The path shards naturally: chains are independent given the data (the reference runs one process per
 chain, bayes_drt/inversion.py:1218-1221) and spectra are independent fits.  Communication is limited to
-  (1) one broadcast of the problem description from rank 0 (matrices + spectra, a few MB), and
+  (1) one broadcast of the shared problem description from rank 0 (matrices, grids, scalars: a few MB) and one SCATTER of
+      the spectra (each rank receives the rows of Z it samples), and
   (2) one gather at the end -- per-spectrum posterior SUMMARIES (mean + percentiles, reduced on each GPU by
       bdrt_sampler_summary) or, on request, the raw draws, taken straight from HBM (no host round trip) --
 over RCCL / xGMI when the process group backend is "nccl", gloo on CPU tensors in the tests.
@@ -116,6 +117,31 @@ def gather_rows(local, counts, group=None):
     return full.cpu().numpy().reshape((int(sum(counts)),) + tail)
 
 
+def scatter_rows(full, counts, width, src=0, group=None):
+    """Scatter row blocks of unequal length from `src`: rank r receives rows [sum(counts[:r]), sum(counts[:r + 1])) of
+    `full` ([sum(counts), width], needed on `src` only) as a numpy array [counts[r], width].  One collective; the blocks are
+    padded to the longest one (a scatter moves equal pieces)."""
+    import torch
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = _device_for_group(group)
+    maxc = int(max(counts)) if len(counts) else 0
+    if maxc == 0 or width == 0:
+        return np.zeros((0, width))
+    out = torch.empty((maxc, width), dtype=torch.float64, device=dev)
+    pieces = None
+    if rank == src:
+        a = np.ascontiguousarray(np.asarray(full, dtype=np.float64).reshape(int(sum(counts)), width))
+        pieces, o = [], 0
+        for r in range(world):
+            blk = np.zeros((maxc, width))
+            blk[:counts[r]] = a[o:o + counts[r]]
+            o += counts[r]
+            pieces.append(torch.from_numpy(blk).to(dev))
+    dist.scatter(out, pieces, src=src, group=group)
+    return out[:counts[rank]].cpu().numpy()
+
+
 class GpuWorker:
     """Per-rank worker: the problem in this rank's HBM + the device-resident NUTS chains of this rank's units."""
 
@@ -226,22 +252,39 @@ def sample_sharded(problem_kwargs, n_spectra, chains, warmup, n_draws, seed=1234
         raise ValueError("gather must be 'draws' or 'summary'")
     dist = _dist()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    flat = broadcast_arrays(_pack_problem(problem_kwargs) if rank == 0 else None, src=0, group=group)
-    kw = _unpack_problem(flat)
-    dev = _device_for_group(group)
-    q = [float(v) for v in np.atleast_1d(q)]
     spec, chain = make_units(n_spectra, chains)
     parts = partition_units(n_spectra, chains, world)
     u0, u1 = parts[rank]
     whole = n_spectra >= world                                     # every spectrum lives on exactly one rank
     counts = [hi - lo for lo, hi in parts]
+    # (1) the shared problem (matrices, grids, scalars) is BROADCAST; (2) the spectra are SCATTERED by rank -- each rank
+    # receives the rows of Z it samples -- unless the chains of a spectrum are spread over ranks (fewer spectra
+    # than ranks: every rank then needs the few spectra, and they travel with the broadcast)
+    Zfull = None
+    if rank == 0:
+        flat0 = _pack_problem(problem_kwargs)
+        Zfull = np.atleast_2d(flat0['kw_Z'])
+        if Zfull.shape[0] != n_spectra:
+            raise ValueError('sample_sharded: Z has %d spectra, n_spectra = %d' % (Zfull.shape[0], n_spectra))
+        if whole:
+            flat0.pop('kw_Z')
+            flat0['Z_width'] = np.array(Zfull.shape[1])
+    flat = broadcast_arrays(flat0 if rank == 0 else None, src=0, group=group)
+    if whole:
+        width = int(flat.pop('Z_width'))
+        rows = [c // chains for c in counts]                        # whole spectra per rank
+        flat['kw_Z'] = scatter_rows(Zfull, rows, width, src=0, group=group)
+    kw = _unpack_problem(flat)
+    dev = _device_for_group(group)
+    q = [float(v) for v in np.atleast_1d(q)]
     cls = worker_cls or GpuWorker
     worker = None
     D = None
     if u1 > u0:
         s0, s1 = int(spec[u0]), int(spec[u1 - 1]) + 1
         local_kw = dict(kw)
-        local_kw['Z'] = np.atleast_2d(kw['Z'])[s0:s1]                # only this rank's spectra go to HBM
+        # only this rank's spectra go to HBM: what the scatter delivered, or this rank's rows of the broadcast copy
+        local_kw['Z'] = np.atleast_2d(kw['Z']) if whole else np.atleast_2d(kw['Z'])[s0:s1]
         worker = cls(local_kw)
         worker.run(spec[u0:u1] - s0, chain[u0:u1], warmup, n_draws, seed, control)
         D = int(worker.D)

@@ -242,6 +242,53 @@ def build_problem_kwargs(n_spectra, lib=None):
     return dict(blocks=[blk], Z=Z, freq=f, sigma_min=0.002, ups_alpha=1.0, ups_beta=0.1, induc_scale=1.0)
 
 
+SHAPES = ((81, 161), (81, 101), (81, 81), (41, 51), (53, 81), (106, 101))       # (frequencies, basis functions): the headline, the
+# package default for an 81-point spectrum (inversion.py:2191-2197) and the other shapes of the reference's stored fits
+
+
+def shape_problem_kwargs(nf, k, n_spectra, seed=7):
+    """A single-DRT problem on ten-points-per-decade grids with nf frequencies and k basis functions (the basis grid contains the
+    measurement grid or lies inside it, so that A is exactly Toeplitz as for the reference's default grids) and n_spectra
+    synthetic two-ZARC spectra."""
+    from bayes_drt_amd import matrices as gm
+    f = np.logspace(6, 6 - (nf - 1) / 10.0, nf)
+    half = (k - nf) // 2
+    top = 6 + half / 10.0
+    basis_freq = np.logspace(top, top - (k - 1) / 10.0, k)
+    tau = 1 / (2 * np.pi * basis_freq)
+    eps = 1 / np.mean(np.diff(np.log(tau)))
+    A = np.vstack([gm.construct_A(f, 'real', tau=tau, epsilon=eps), gm.construct_A(f, 'imag', tau=tau, epsilon=eps)])
+    L = [gm.construct_L(basis_freq, tau=tau, epsilon=eps, order=o) for o in (0, 1, 2)]
+    rs = np.random.RandomState(seed)
+    w = 2 * np.pi * f
+    Z = np.empty((n_spectra, 2 * nf))
+    for i in range(n_spectra):
+        R1, R2 = rs.uniform(0.5, 2, 2)
+        t1, t2 = 10 ** rs.uniform(-3, -1), 10 ** rs.uniform(-4, -2)
+        n1, n2 = rs.uniform(0.6, 0.95, 2)
+        z = 1.0 + R1 / (1 + (1j * w * t1) ** n1) + R2 / (1 + (1j * w * t2) ** n2)
+        z = z + 0.0025 * (z.real.max() - z.real.min()) * (rs.normal(size=nf) + 1j * rs.normal(size=nf))
+        z = z / (np.std(np.abs(z)) / np.sqrt(nf / 81))
+        Z[i] = np.concatenate([z.real, z.imag])
+    blk = dict(A=A, L0=L[0], L1=L[1], L2=0.75 * L[2], nonneg=True)
+    return dict(blocks=[blk], Z=Z, freq=f, sigma_min=0.002, ups_alpha=1.0, ups_beta=0.1, induc_scale=1.0)
+
+
+def steady_rate(prob, n_units, ctrl, n_spectra, rounds=500, launches=4, warm_rounds=600):
+    """evals/s of n_units real NUTS chains in their warm-up (no chain finishes), after warm_rounds untimed rounds: the short form
+    of the headline measurement, for the tables that accompany it (outside the timed region)."""
+    from bayes_drt_amd.engine import Sampler
+    spec = (np.arange(n_units) % n_spectra).astype(np.int32)
+    with Sampler(prob, n_units, 1000000, 1, 1234, ctrl, spec=spec) as smp:
+        smp.advance(warm_rounds); smp.sync()
+        n0 = smp.total_leapfrogs(); t0 = time.perf_counter()
+        for _ in range(launches):
+            smp.advance(rounds)
+        smp.sync()
+        dt = time.perf_counter() - t0
+        return (smp.total_leapfrogs() - n0) / dt, smp.kind()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -374,6 +421,71 @@ def main():
         print('half-waves per round in stage E (new start point): %.2f of 16' % (cyc[24] / n_wg / rounds_total * 2), file=sys.stderr)
     smp.close()
 
+    # ---- strong scaling: BASELINE config 4 AS WRITTEN -- 512 spectra x 8 chains in total, 512 / N spectra per rank -- timed the
+    # same way (barrier + synchronize on both sides, max over ranks), beside the weak-scaling value above.  At N = 1 it is the
+    # same job as the headline and is not run twice.
+    strong = None
+    if world > 1:
+        ns_total = min(N_SPECTRA, n_global)               # (a test run with fewer spectra than config 4 has: all of them)
+        su0, su1 = par.partition_units(ns_total, args.chains, world)[rank]
+        sspec, schain = par.make_units(ns_total, args.chains)
+        n_strong = su1 - su0
+        if n_strong > 0:
+            ss0, ss1 = int(sspec[su0]), int(sspec[su1 - 1]) + 1
+            # this rank's rows of the global Z: the first 512 spectra are partitioned again, a rank samples those it holds a copy of
+            sprob = Problem(blocks, np.atleast_2d(Zall)[ss0:ss1], freq, **local_kw)
+            ssmp = Sampler(sprob, n_strong, 1000000, 1, 1234, ctrl, spec=sspec[su0:su1] - ss0, chain_ids=schain[su0:su1])
+        steps_s = max(2, min(args.steps, 10))
+
+        def sync_strong():
+            if n_strong > 0:
+                ssmp.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+        for _ in range(max(1, min(args.warmup, 3))):
+            if n_strong > 0:
+                ssmp.advance(args.rounds)
+        sync_strong()
+        m0 = ssmp.total_leapfrogs() if n_strong > 0 else 0
+        sync_strong()
+        ts0 = time.perf_counter()
+        for _ in range(steps_s):
+            if n_strong > 0:
+                ssmp.advance(args.rounds)
+        sync_strong()
+        ts1 = time.perf_counter() - ts0
+        sev = float((ssmp.total_leapfrogs() - m0) if n_strong > 0 else 0)
+        tt = torch.tensor([ts1], dtype=torch.float64, device=red_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        te = torch.tensor([sev], dtype=torch.float64, device=red_dev); dist.all_reduce(te, op=dist.ReduceOp.SUM)
+        strong = {'workload': 'BASELINE config 4 as written: %d spectra x %d chains IN TOTAL (%d units per GPU)' % (ns_total, args.chains, ns_total * args.chains // world),
+                  'value': float(te.item() / tt.item()), 'unit': 'evals/s', 'steps': steps_s, 'ms_per_step': float(tt.item()) * 1e3 / steps_s,
+                  'sampler_kind_rank0': ssmp.kind() if n_strong > 0 else None}
+        if n_strong > 0:
+            ssmp.close(); sprob.close()
+
+    # ---- fewer chains than the tiles want (the regime of 8-GPU runs of config 4, of config 3 x many spectra, of a run's tail) and
+    # the other shapes of the reference's fits: steady-state rates of the same kind, outside the timed region (rank 0, N = 1)
+    mid, shapes = None, None
+    if rank == 0 and args.gpus == 1 and not os.environ.get('BDRT_BENCH_NO_TABLES'):
+        mid = []
+        for nu in (512, 1024, 2048):
+            r, kind = steady_rate(prob, nu, ctrl, prob.n_spectra)
+            mid.append({'units': nu, 'evals_per_s': r, 'sampler_kind': kind})
+        shapes = []
+        for nf_s, k_s in SHAPES:
+            try:
+                sp_ = Problem(**{**shape_problem_kwargs(nf_s, k_s, 64)})
+            except Exception as exc:
+                shapes.append({'nf': nf_s, 'K': k_s, 'error': str(exc)[:120]})
+                continue
+            e_s = 4 * (2 * nf_s * k_s + 3 * k_s * k_s)              # dense-formulation flop per evaluation
+            row = {'nf': nf_s, 'K': k_s, 'evaluator': sp_.evaluator(), 'flop_per_eval_algorithmic': e_s}
+            for nu in (4096, 2048):
+                r, kind = steady_rate(sp_, nu, ctrl, 64)
+                row['units_%d' % nu] = {'evals_per_s': r, 'sampler_kind': kind, 'frac': r * e_s / 1e12 / PEAK_F64_MFMA_TFLOPS}
+            shapes.append(row)
+            sp_.close()
+
     # ---- raw log-posterior+gradient kernel at B = 1 .. 4096 points, inputs resident in HBM; outside the timed region
     sweep = None
     if rank == 0 and args.gpus == 1:
@@ -490,6 +602,15 @@ def main():
             line['config']['raw_logp_grad_kernel_sweep'] = sweep
         if few is not None:
             line['config']['few_chains'] = few
+        if strong is not None:
+            line['config']['strong_scaling'] = strong
+        elif world == 1:
+            line['config']['strong_scaling'] = {'workload': 'BASELINE config 4 as written: %d spectra x %d chains in total' % (N_SPECTRA, args.chains),
+                                                'value': value, 'unit': 'evals/s', 'note': 'the headline job itself at N = 1'}
+        if mid is not None:
+            line['config']['mid_occupancy'] = mid          # sampler_kind 0: 16 chains per workgroup, 1: one chain per 512-thread workgroup, 3: one chain per wave
+        if shapes is not None:
+            line['config']['shapes'] = shapes
         if cpu is not None:
             line['cpu_baseline'] = cpu
     else:

@@ -49,6 +49,16 @@ def test_driver_command_line_times_the_steady_state():
     fc = c['few_chains']                      # BASELINE config 3 beside the throughput figure, labelled latency-bound
     assert fc['chains'] == 4 and fc['sampler_kind'] == 1 and fc['evals_per_s'] > 2e5 and 'latency' in fc['bound']
     assert 2.0 < fc['us_per_leapfrog_round'] < 20.0
+    # beside the headline: fewer chains than the tiles want (which kernel took them: 1 one chain per 512-thread workgroup, 3 one
+    # chain per wave), the other shapes of the reference's fits, and config 4 as written (= the headline job at N = 1)
+    mo = {m['units']: m for m in c['mid_occupancy']}
+    assert set(mo) == {512, 1024, 2048} and mo[1024]['sampler_kind'] == 3 and mo[2048]['sampler_kind'] == 3
+    assert mo[512]['evals_per_s'] > 3e7 and mo[1024]['evals_per_s'] > 6e7 and mo[2048]['evals_per_s'] > 9e7
+    sh = {(r_['nf'], r_['K']): r_ for r_ in c['shapes']}
+    assert set(sh) == {(81, 161), (81, 101), (81, 81), (41, 51), (53, 81), (106, 101)}
+    assert all('error' not in r_ and r_['units_4096']['evals_per_s'] > 5e7 for r_ in sh.values())
+    assert sh[(81, 161)]['evaluator'] == 4 and sh[(81, 101)]['units_2048']['sampler_kind'] == 3
+    assert c['strong_scaling']['value'] == d['value']
     b = d['cpu_baseline']
     assert 'untuned' in b['tuning'] and b['cores'] <= b['logical_cpus']
     assert b['kind'] == 'port' and b['cores'] >= 1 and 0 < b['single_core'] <= b['value']
@@ -86,6 +96,10 @@ def test_bench_two_ranks_on_the_one_device():
     assert d['value'] > 1e5
     rt = d['config']['dist_roundtrip']
     assert 'error' not in rt and rt['finite'] and rt['spectra'] == 16
+    # config 4 as written beside the weak-scaling value: the job's spectra IN TOTAL over the ranks (here all 64 of them: a test
+    # run has fewer than config 4's 512), timed the same way
+    ss = d['config']['strong_scaling']
+    assert ss['value'] > 1e5 and ss['unit'] == 'evals/s' and '64 spectra' in ss['workload'] and ss['steps'] >= 2
 
 
 def test_bare_gpus_2_launches_its_own_ranks():

@@ -36,6 +36,7 @@ class FakeWorker:
     def run(self, spec, chain_ids, warmup, n_draws, seed, control):
         self._draws, self._lp, self._stats = _fake_sampler(self.kw, spec, chain_ids, warmup, n_draws, seed, control)
         self._stats[:, 1] = dist.get_rank()            # "n_divergent" column abused as the rank that sampled the unit
+        self._stats[:, 2] = np.atleast_2d(self.kw['Z']).shape[0]     # "n_max_treedepth": spectra this rank was handed
 
     def lp(self):
         return self._lp
@@ -140,6 +141,10 @@ def test_world2_equals_world1(n_spectra):
     _same(ref, two)
     assert np.array_equal(ref['stats'][:, 0], two['stats'][:, 0])
     assert set(two['stats'][:, 1]) == {0.0, 1.0}                 # both ranks sampled
+    if n_spectra >= 2:
+        # the spectra are scattered, not broadcast: a rank holds only the rows it samples (3 + 2 of 5; 1 + 1 of 2)
+        held = {int(r): int(h) for r, h in zip(two['stats'][:, 1], two['stats'][:, 2])}
+        assert held == ({0: 3, 1: 2} if n_spectra == 5 else {0: 1, 1: 1}), held
     pk = _problem(n_spectra)
     spec, chain = par.make_units(n_spectra, 3)
     direct = _fake_sampler(pk, spec, chain, 5, 4, 11, None)
