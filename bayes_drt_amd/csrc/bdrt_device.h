@@ -57,6 +57,9 @@ struct DevBlock {
     // otherwise (measured spectra on their own frequency grid): plain copies of A for the one-chain-per-workgroup path,
     // Ad [2 nf][K] row-major (A^T r reads four consecutive columns) and At [K][2 nf] (A x reads four consecutive rows)
     const double *Ad, *At;
+    // problems beyond the LDS budget (bdrt_big.h; Ad / At are kept for them too): the stack [L0; L1; L2] row-major [3K][K]
+    // and its transpose [K][3K]
+    const double *Ld, *Lt;
 };
 
 struct DevProblem {
@@ -74,6 +77,7 @@ struct DevProblem {
     int tlen;                 // length of one part of that table: 8 leading zeros, the nf + K - 1 generators, trailing zeros
     int XCR;                  // rows of the x cache (0: exp(theta_x) is recomputed where needed)
     int xc_off[MAXB];         // first cache row of each block
+    int big;                  // beyond the LDS budget of every tile / one-chain evaluator: bdrt_big.h evaluates it (workspace in HBM)
     int dbg;                  // timing ablation only (env BDRT_DEBUG_SKIP): 1 skip forward GEMMs, 2 skip backward GEMM
     double sigma_min, ups_alpha, ups_beta, induc_scale;
     double so_lambda, so_alpha, so_beta, x_sum_invscale;

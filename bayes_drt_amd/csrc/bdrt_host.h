@@ -76,6 +76,10 @@ struct Problem {
     // launch_logp_grad_few: which one-workgroup-per-point evaluator the problem takes (-1 not looked at yet, 0 none, 1 the
     // headline family's, 2 the general one), decided once -- the call is launch-latency-bound, host microseconds count
     int few_kind = -1, few_ncu = 0;
+    // problems beyond the LDS budget (bdrt_big.h): per-point workspace of the evaluator, grown on demand
+    double *d_bigws = nullptr;
+    size_t bigws_doubles = 0;
+    int ensure_bigws(size_t doubles);
 };
 
 // launch the batched evaluator on device buffers (theta/grad [B x D] row-major)

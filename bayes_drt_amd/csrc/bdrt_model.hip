@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "bdrt_host.h"
+#include "bdrt_big.h"
 
 namespace bdrt {
 
@@ -68,6 +69,29 @@ int Problem::ensure_scratch(size_t rows)
     BDRT_HIP(hipMalloc((void **)&d_lp, n * sizeof(double)));
     BDRT_HIP(hipMalloc((void **)&d_spec, n * sizeof(int)));
     scratch_rows = n;
+    return 0;
+}
+
+// the streamed evaluator of problems beyond the LDS budget (bdrt_big.h): grid-stride over the points, one workspace per workgroup
+__global__ __launch_bounds__(BIG_NT) void big_eval_kernel(const DevProblem *__restrict__ Pp, double *ws, const double *theta, const int *spec,
+                                                           int B, int jacobian, double *lp, double *grad, double *params, double *Zhat, double *sig)
+{
+    __shared__ double red[9 * 8];
+    const DevProblem &P = *Pp;
+    const size_t wsz = big_ws_doubles(P);
+    for (int b = blockIdx.x; b < B; b += gridDim.x)
+        big_eval(P, ws + (size_t)blockIdx.x * wsz, theta + (size_t)b * P.D, grad ? grad + (size_t)b * P.D : nullptr, lp ? lp + b : nullptr,
+                 spec ? spec[b] : 0, jacobian, red, threadIdx.x, params ? params + (size_t)b * P.D : nullptr,
+                 Zhat ? Zhat + (size_t)b * 2 * P.nf : nullptr, sig ? sig + (size_t)b * 2 * P.nf : nullptr);
+}
+
+
+int Problem::ensure_bigws(size_t doubles)
+{
+    if (doubles <= bigws_doubles) return 0;
+    if (d_bigws) { hipFree(d_bigws); d_bigws = nullptr; bigws_doubles = 0; }
+    BDRT_HIP(hipMalloc((void **)&d_bigws, doubles * sizeof(double)));
+    bigws_doubles = doubles;
     return 0;
 }
 
@@ -178,7 +202,7 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
             }
             B.tg = nullptr;
             if (tz && (rc = upload(P, tgv, &B.tg))) return rc;
-            B.Ad = nullptr; B.At = nullptr;
+            B.Ad = nullptr; B.At = nullptr; B.Ld = nullptr; B.Lt = nullptr;
             if (!tz) {
                 std::vector<double> ad((size_t)N2 * K), at((size_t)K * N2);
                 for (int r = 0; r < N2; ++r)
@@ -271,10 +295,34 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
                 D.fast_s1, D.fast_hw, D.XR, D.ZR, 1 + D.npar, D.LR, D.XCR, lds_doubles(D) * sizeof(double));
     if (const char *e = getenv("BDRT_DEBUG_SKIP")) D.dbg = atoi(e);
     P.lds_bytes = std::max(std::max(lds_doubles(D), D.fast_hw ? hw_lds_doubles(D) : (size_t)0), D.fast_s1 ? s1_lds_doubles(D) : (size_t)0) * sizeof(double);
-    if (P.lds_bytes + SAMPLER_LDS_RESERVE > 160 * 1024) {
-        set_error("bdrt_problem_create: problem needs %zu B of LDS per workgroup (+ %zu B of sampler state > 160 KiB): nf=%d, K too large",
-                  P.lds_bytes, SAMPLER_LDS_RESERVE, nf);
-        return -2;
+    D.big = 0;
+    if (P.lds_bytes + SAMPLER_LDS_RESERVE > 160 * 1024 || getenv("BDRT_BIG")) {
+        // Beyond the LDS budget of the tile evaluators (the reference takes any grid: inversion.py:2127-2209): the streamed
+        // evaluator of bdrt_big.h -- plain copies of the matrices and their transposes in HBM, vectors in a per-point workspace
+        D.big = 1;
+        D.fast_s1 = 0; D.fast_hw = 0; D.toepA = 0; D.tlen = 0;
+        P.lds_bytes = 4096;
+        for (int b = 0; b < dat->nblocks; ++b) {
+            DevBlock &B = D.blk[b];
+            const int K = B.K;
+            const double *A = dat->A[b];
+            const double *Ls[3] = {dat->L0[b], dat->L1[b], dat->L2[b]};
+            int rc;
+            if (!B.Ad) {
+                std::vector<double> ad((size_t)N2 * K), at((size_t)K * N2);
+                for (int r = 0; r < N2; ++r)
+                    for (int m = 0; m < K; ++m) { ad[(size_t)r * K + m] = A[(size_t)r * K + m]; at[(size_t)m * N2 + r] = A[(size_t)r * K + m]; }
+                if ((rc = upload(P, ad, &B.Ad)) || (rc = upload(P, at, &B.At))) return rc;
+            }
+            std::vector<double> ld((size_t)3 * K * K), lt((size_t)3 * K * K);
+            for (int i = 0; i < 3; ++i)
+                for (int r = 0; r < K; ++r)
+                    for (int m = 0; m < K; ++m) {
+                        ld[((size_t)i * K + r) * K + m] = Ls[i][(size_t)r * K + m];
+                        lt[(size_t)m * 3 * K + (size_t)i * K + r] = Ls[i][(size_t)r * K + m];
+                    }
+            if ((rc = upload(P, ld, &B.Ld)) || (rc = upload(P, lt, &B.Lt))) return rc;
+        }
     }
     std::vector<double> w(nf);
     for (int n = 0; n < nf; ++n) w[n] = 2.0 * M_PI * dat->freq[n];
@@ -357,6 +405,14 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
 {
     if (B <= 0) return 0;
     BDRT_HIP(hipSetDevice(p->device));
+    if (p->dev.big) {
+        const int grid = std::min(B, 1024);
+        if (int rc = p->ensure_bigws((size_t)grid * big_ws_doubles(p->dev))) return rc;
+        hipLaunchKernelGGL(big_eval_kernel, dim3(grid), dim3(BIG_NT), 0, stream, (const DevProblem *)p->d_dev, p->d_bigws, d_theta, d_spec, B,
+                           jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
+        BDRT_HIP(hipGetLastError());
+        return 0;
+    }
     static LdsAttrCache attr_cache;
     BDRT_HIP(attr_cache.ensure(p->lds_bytes, [&]() {
         const void *fns[6] = {(const void *)logp_grad_kernel<0>, (const void *)logp_grad_kernel<1>, (const void *)logp_grad_kernel<2>,
@@ -452,6 +508,7 @@ void bdrt_problem_destroy(bdrt_problem *p)
     if (P.d_Z) hipFree(P.d_Z);
     if (P.d_dev) hipFree(P.d_dev);
     if (P.d_theta) { hipFree(P.d_theta); hipFree(P.d_grad); hipFree(P.d_lp); hipFree(P.d_spec); }
+    if (P.d_bigws) hipFree(P.d_bigws);
     if (P.stream) hipStreamDestroy(P.stream);
     delete p;
 }
@@ -461,7 +518,7 @@ int bdrt_problem_evaluator(const bdrt_problem *p)
 {
     if (!p) return -1;
     const bdrt::DevProblem &D = p->impl.dev;
-    return D.fast_hw ? 3 : (D.fast_s1 ? (D.toepA ? 4 : 2) : (D.toep_all ? 1 : 0));
+    return D.big ? 5 : (D.fast_hw ? 3 : (D.fast_s1 ? (D.toepA ? 4 : 2) : (D.toep_all ? 1 : 0)));
 }
 
 int bdrt_param_is_pos(const bdrt_problem *p, unsigned char *is_pos)

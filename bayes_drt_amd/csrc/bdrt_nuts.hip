@@ -28,6 +28,7 @@
 #include "bdrt_solo.h"
 #include "bdrt_wave.h"
 #include "bdrt_nuts_args.h"
+#include "bdrt_big.h"
 
 namespace bdrt {
 
@@ -1341,6 +1342,71 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
 }
 
 // the general one-chain evaluator (bdrt_solo_wide.h) on its own: one point per workgroup (tests)
+// ---------------------------------------------------------------------------------------------------------------------------
+// Problems beyond the LDS budget (bdrt_big.h): one chain per workgroup, every row of the chain in HBM, the evaluation by the
+// streamed evaluator (workspace in HBM), everything after it by the cooperative stage of bdrt_nuts_wide.h.  Slow but working:
+// the reference accepts any grid (inversion.py:2127-2209).  State layout: that of nuts_wide1_kernel.
+// ---------------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t nuts_big_lds_bytes() { return (size_t)(W1_SCRATCH + 2 + 9 * 8) * sizeof(double) + sizeof(ChainState) + 128; }
+
+__global__ __launch_bounds__(SOLO_NT) void nuts_big_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const DevProblem &P = *Pp;
+    const int tid = threadIdx.x;
+    const int wg = blockIdx.x, unit = a.unit_map ? a.unit_map[wg] : wg;
+    const int D = P.D, DS = a.ds;
+    double *scr = smem;
+    double *lpn = scr + W1_SCRATCH;
+    double *red = lpn + 2;
+    ChainState *sts = reinterpret_cast<ChainState *>(red + 9 * 8);
+    signed char *hslot = reinterpret_cast<signed char *>(sts + 1);      // [V_COUNT] (64 bytes): no row is LDS-resident
+    double *V = a.vecs + (size_t)wg * V_COUNT * DS;       // this chain's rows [V_COUNT][ds]
+    double *ws = a.bigws + (size_t)wg * big_ws_doubles(P);
+    auto row = [&](int v) -> double * { return V + (size_t)v * DS; };
+    if (tid == 0) sts[0] = a.states[unit];
+    if (tid < V_COUNT) hslot[tid] = (signed char)-1;
+    __syncthreads();
+    const int spec = sts[0].spec;
+    if (!sts[0].kicked) {
+        const int ph = sts[0].phase;
+        const double e = ph == PH_EPS ? sts[0].eps : (ph == PH_TREE ? sts[0].dir * sts[0].eps : 0.0);
+        double *TH = row(V_TH), *Pm = row(V_P), *Gr = row(V_G), *MI = row(V_MINV);
+        if (ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)
+            for (int j = tid; j < D; j += SOLO_NT) {
+                const double p = Pm[j] + 0.5 * e * Gr[j];
+                Pm[j] = p;
+                TH[j] += e * MI[j] * p;
+            }
+        __syncthreads();
+        if (tid == 0) sts[0].kicked = 1;
+        __syncthreads();
+    }
+    WideCtx wx;
+    wx.P = Pp; wx.np = &np; wx.a = &a; wx.V = V; wx.smem = scr; wx.sts = sts; wx.lpn = lpn; wx.hvy = nullptr; wx.hvk = nullptr;
+    wx.prof = nullptr; wx.D = D; wx.DS = DS; wx.TH2OFF = 0; wx.c0 = unit; wx.nvalid = 1; wx.slot_unit = nullptr; wx.ncol = 1;
+    wx.hot_base = scr; wx.hot_slot = hslot;
+    unsigned long long my_leaps = 0;
+    for (int round = 0; round < a.rounds; ++round) {
+        const int ph = sts[0].phase;
+        if (!(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)) break;
+        // the rows of the last cooperative stage (global stores of other threads) are read by this evaluation
+        __threadfence_block();
+        __syncthreads();
+        big_eval(P, ws, row(V_TH), row(V_G), lpn, spec, 1, red, tid);
+        __threadfence_block();
+        __syncthreads();
+        wide_coop_tail<2, true>(wx, 0, false, my_leaps, tid);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.states[unit] = sts[0];
+        if (my_leaps) atomicAdd(a.leap_counter, my_leaps);
+        const int ph = sts[0].phase;
+        if (!(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)) atomicAdd(a.done_counter, 1);
+    }
+}
+
 __global__ __launch_bounds__(SOLO_NT) void wide1_eval_kernel(const DevProblem *__restrict__ Pp, Wide1Geom G, const double *theta,
                                                              const int *spec, int B, int jacobian, double *lp, double *grad)
 {
@@ -1473,6 +1539,8 @@ struct Sampler {
     bool wide1 = false;      // one chain per workgroup, general block model (bdrt_solo_wide.h): few chains of any other Toeplitz family
     Wide1Geom geom1;
     int nhot1 = 0;           // rows of the chain that kernel keeps in LDS
+    bool big = false;        // problem beyond the LDS budget (bdrt_big.h): the wide1 layout advanced by nuts_big_kernel
+    double *d_bigws = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double ms_total = 0.0;
@@ -1651,6 +1719,7 @@ void bdrt_sampler_destroy(bdrt_sampler *s)
     if (S.d_leaps) hipFree(S.d_leaps);
     if (S.d_prof) hipFree(S.d_prof);
     if (S.d_active) hipFree(S.d_active);
+    if (S.d_bigws) hipFree(S.d_bigws);
     if (S.vecs16) hipFree(S.vecs16);
     if (S.d_unit_map) hipFree(S.d_unit_map);
     if (S.d_slot_unit) hipFree(S.d_slot_unit);
@@ -1731,6 +1800,14 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         S.args.cpw = 1; S.n_wg = n_units;
         S.may_migrate = false;
     }
+    // a problem beyond the LDS budget of the tile evaluators (bdrt_big.h): one chain per workgroup in the same row layout, the
+    // streamed evaluator, whatever the number of units
+    S.big = P.dev.big != 0 && !S.wide1;
+    if (S.big) {
+        S.solo = false; S.wave = false; S.wide1 = true;
+        S.args.cpw = 1; S.n_wg = n_units;
+        S.may_migrate = false;
+    }
     S.np.warmup = warmup; S.np.n_draws = n_draws; S.np.max_depth = c.max_treedepth;
     S.np.delta = c.adapt_delta; S.np.gamma = c.adapt_gamma; S.np.t0 = c.adapt_t0; S.np.kappa = c.adapt_kappa;
     S.np.init_radius = c.init_radius; S.np.max_deltaH = c.max_deltaH; S.np.stepsize0 = c.stepsize0;
@@ -1746,19 +1823,22 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
                       3 * NC * sizeof(int) + 16;
     else
         S.lds_bytes = nuts_lds_bytes(P.dev, S.use_s1);
-    if (S.wide1) {
+    if (S.wide1 && !S.big) {
         const int ds1 = S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : 32 * 27);
         S.nhot1 = wide1_hot_rows(S.geom1, ds1);
         S.lds_bytes = std::max(S.lds_bytes, wide1_lds_bytes(S.geom1, ds1, S.nhot1));     // (one attribute value for every kernel)
     }
+    if (S.big) S.lds_bytes = nuts_big_lds_bytes();
     auto fail = [&](const char *msg) -> bdrt_sampler * { set_error("%s", msg); bdrt_sampler_destroy(s); return nullptr; };
     if (S.lds_bytes > 160 * 1024) return fail("bdrt_sampler_create: problem too large for the 160 KiB LDS budget");
     for (int u = 0; u < n_units; ++u)
         if (spec && (spec[u] < 0 || spec[u] >= P.dev.n_spectra)) return fail("bdrt_sampler_create: spectrum index out of range");
 
     // row stride of the state vectors = 32*NJ of the kernel instantiation; the solo kernel keeps [unit][row][ds] with one column
-    const int DS = S.solo ? S.geom.DSS : (S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : 32 * 27));
-    if (S.D > 32 * 27) { set_error("bdrt_sampler_create: D = %d > 864 not supported", S.D); bdrt_sampler_destroy(s); return nullptr; }
+    const int DS = S.solo ? S.geom.DSS : (S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : (S.D <= 32 * 27 ? 32 * 27 : 32 * 32)));
+    if (S.D > (S.big ? 1024 : 32 * 27)) {
+        set_error("bdrt_sampler_create: D = %d > %d not supported", S.D, S.big ? 1024 : 864); bdrt_sampler_destroy(s); return nullptr;
+    }
     S.args.ds = DS;
     const int ncol = (S.solo || S.wide1) ? 1 : NC, nrow = S.solo ? (int)SG_COUNT : (int)V_COUNT;
     const int r_minv = S.solo ? (int)SV_MINV : (int)V_MINV, r_th = S.solo ? (int)SV_TH : (int)V_TH;
@@ -1822,6 +1902,8 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     if (hipMalloc((void **)&S.d_done, sizeof(int)) != hipSuccess) return fail("hipMalloc failed");
     if (hipMalloc((void **)&S.d_leaps, sizeof(unsigned long long)) != hipSuccess) return fail("hipMalloc failed");
     if (hipMalloc((void **)&S.d_active, sizeof(int)) != hipSuccess) return fail("hipMalloc failed");
+    if (S.big && hipMalloc((void **)&S.d_bigws, (size_t)S.n_wg * big_ws_doubles(P.dev) * sizeof(double)) != hipSuccess) return fail("hipMalloc(workspace) failed");
+    S.args.bigws = S.d_bigws;
     if (hipMemcpy(S.args.vecs, hv.data(), nvec * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
         return fail("bdrt_sampler_create: upload of the chain vectors failed");
     if (hipMemcpy(S.args.states, hs.data(), hs.size() * sizeof(ChainState), hipMemcpyHostToDevice) != hipSuccess)
@@ -1903,7 +1985,9 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             if (tp) hipLaunchKernelGGL((nuts_kernel<NJV, 1>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args); \
             else hipLaunchKernelGGL((nuts_kernel<NJV, 0>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);   \
         } while (0)
-        if (S.wide1)
+        if (S.big)
+            hipLaunchKernelGGL(nuts_big_kernel, dim3(S.n_wg), dim3(SOLO_NT), nuts_big_lds_bytes(), S.stream, dp, S.np, S.args);
+        else if (S.wide1)
             hipLaunchKernelGGL(nuts_wide1_kernel, dim3(S.n_wg), dim3(SOLO_NT), wide1_lds_bytes(S.geom1, S.args.ds, S.nhot1), S.stream, dp,
                                S.np, S.args, S.geom1, S.nhot1);
         else if (S.solo && S.wave && (S.wave_force == 1 || !S.solo_ok || wave_pays(S.live, S.n_cu)))
@@ -2156,6 +2240,7 @@ int bdrt_sampler_kind(bdrt_sampler *s)
 {
     if (!s) return -1;
     const Sampler &S = s->impl;
+    if (S.big) return 4;
     if (S.wide1) return 2;
     if (!S.solo) return 0;
     // before the first launch: what the first launch will use

@@ -21,6 +21,7 @@ struct NutsArgs {
     long long *prof;       // optional [n_wg][32] cycle counters (phase profile)
     const int *unit_map;   // one-chain-per-workgroup kernel: unit of workgroup b (nullptr: b) -- the tail of a large run (below)
     int *active_counter;   // 16-chain kernel: chains still running at the end of the launch (all workgroups)
+    double *bigws;         // problems beyond the LDS budget (bdrt_big.h): [n_wg][big_ws_doubles] workspace of the evaluator
 };
 
 // The part of a chain's scalar state that a leapfrog touches: kept in registers by every thread (identical updates).  The

@@ -16,24 +16,24 @@ CASES = sorted(set(range(24)) | {25, 287, 457, 598, 3017, 3027, 3047, 3057})
 def test_random_problem_matches_the_oracle(n):
     from tests.fuzz_parity import run_case
     status, text = run_case(n)
-    assert status in ('ok', 'skip'), text
-    if status == 'skip':
-        assert n == 14, text                    # three distributions of 129 at 107 frequencies: beyond the LDS budget
+    # (case 14 -- three distributions of 129 at 107 frequencies, beyond the LDS budget of the tiles -- takes the streamed
+    #  evaluator of bdrt_big.h since round 4: every stage against the oracle like the others)
+    assert status == 'ok', text
 
 
-def test_whatever_is_accepted_as_a_problem_can_be_sampled():
-    """Cases 207 and 283 (three distributions, > 107 frequencies) need 155-160 KiB of LDS for the evaluator alone: they used to
-    be accepted by bdrt_problem_create and then refused by bdrt_sampler_create.  The budget check now includes the sampler's
-    share, so the refusal comes at problem creation."""
-    from bayes_drt_amd._lib import BdrtError
+def test_problems_beyond_the_lds_budget_take_the_streamed_path():
+    """Cases 207 and 283 (three distributions, > 107 frequencies) need 155-160 KiB of LDS for the tile evaluator alone: refused
+    at problem creation until round 3, they are evaluated, optimised and sampled by the streamed path of bdrt_big.h now
+    (evaluator code 5) -- every stage of the case against the oracle."""
     from bayes_drt_amd.model import Problem
     from tests.fuzz_parity import make_case, run_case
     for n in (207, 283):
         case, text = make_case(n)
-        with pytest.raises(BdrtError) as e:
-            Problem(case['blocks'], case['Z'], case['freq'], **case['kw'])
-        assert 'LDS' in str(e.value)
-        assert run_case(n)[0] == 'skip'
+        prob = Problem(case['blocks'], case['Z'], case['freq'], **case['kw'])
+        assert prob.evaluator() == 5
+        prob.close()
+        status, text = run_case(n)
+        assert status == 'ok', text
 
 
 def test_parameter_vectors_beyond_864_are_refused_by_the_sampler_not_mis_sampled():
