@@ -106,6 +106,25 @@ def test_big_problem_map_and_a_short_nuts_run_against_the_oracle():
     prob.close()
 
 
+def test_ridge_fit_with_303_unknowns():
+    """ridge_fit at 200 frequencies x 301 basis functions: 303 unknowns -- the KKT triangle of the QP kernel (coneqp restated,
+    bdrt_qp.hip) lives in a global work buffer from n = 201 on, the hyper-lambda loop runs on the device as for the small grids."""
+    import warnings
+    from bayes_drt_amd.inversion import Inverter
+    prob, om, (f, Z, bf) = _big_problem()
+    prob.close()
+    inv = Inverter(basis_freq=bf)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        inv.ridge_fit(f, Z)
+    coef = inv.distribution_fits['DRT']['coef']
+    assert coef.shape == (301,) and np.all(np.isfinite(coef)) and np.all(coef >= -1e-9)
+    rms = np.sqrt(np.mean(np.abs(inv.predict_Z(f) - Z) ** 2)) / np.std(np.abs(Z))
+    assert rms < 0.02, rms
+    # the polarisation resistance of the two arcs (1.2 + 0.7) comes back
+    assert abs(inv.predict_Rp() - 1.9) < 0.1, inv.predict_Rp()
+
+
 def test_inverter_fit_on_a_grid_beyond_the_tiles():
     """Inverter.fit end to end on 200 frequencies with a 301-point basis: MAP and a short HMC run follow the spectrum."""
     import warnings
