@@ -1504,7 +1504,7 @@ static bool solo_duo_fits(const DevProblem &P)
 // workgroups per CU are faster per leapfrog, above it eight independent waves per CU are), up to the eight per CU it keeps
 // resident.  BDRT_WAVE=1 / 0: always / never.
 static bool wave_pays(int live, int n_cu) { return 2 * live > 5 * n_cu; }
-static int wave_max_units(int n_cu) { return 8 * n_cu + n_cu / 4; }
+static int wave_max_units(int n_cu) { return 8 * n_cu; }      // (a ninth chain on any CU is a second turn of the machine: 31 us per round instead of 19)
 
 // liveness of every unit (1: the chain is still running), for the host's re-packing decision
 __global__ void nuts_live_kernel(const ChainState *states, int n, int *live)

@@ -423,7 +423,8 @@ class Sampler:
 
     def kind(self):
         """0: sixteen chains per workgroup, 1: one chain per workgroup with its state in LDS, 2: one chain per workgroup,
-        general block model."""
+        general block model, 3: one chain per wavefront (2.5 ... 8 live chains per CU of the single-DRT family), 4: one chain per
+        workgroup on the streamed evaluator (problem beyond the LDS budget)."""
         return int(self._lib.bdrt_sampler_kind(self.handle))
 
     def tail_units(self):

@@ -207,7 +207,9 @@ int bdrt_sampler_tail_units(bdrt_sampler *s);
 int bdrt_sampler_compactions(bdrt_sampler *s);
 /* which kernel advances the chains now: 0 sixteen chains per workgroup (bdrt_nuts.hip), 1 one chain per workgroup with its
  * state in LDS (bdrt_solo.h: few chains of the single-DRT family), 2 one chain per workgroup, general block model
- * (bdrt_solo_wide.h: few chains of any other model on log-uniform grids) */
+ * (bdrt_solo_wide.h: few chains of any other model on log-uniform grids), 3 one chain per WAVEFRONT (bdrt_wave.h: the single-DRT
+ * family while more than 2.5 and at most 8 chains per CU are running: chosen per launch by the number of live chains), 4 one
+ * chain per workgroup on the streamed evaluator of a problem beyond the LDS budget (bdrt_big.h) */
 int bdrt_sampler_kind(bdrt_sampler *s);
 /* total leapfrogs executed so far, summed over chains (device counter) */
 int64_t bdrt_sampler_total_leapfrogs(bdrt_sampler *s);
