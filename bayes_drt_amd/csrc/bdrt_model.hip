@@ -272,7 +272,7 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
         // headline family on a log-uniform grid: half-wave-per-chain evaluator (bdrt_tile_s1.h)
         D.fast_s1 = (all && dat->nblocks == 1 && !D.blk[0].is_parallel && !D.use_x_sum &&
                      D.blk[0].x_scale == 1.0 && nf <= 128 && D.blk[0].K <= 32 * UK &&
-                     s1_lds_doubles(D) <= lds_doubles(D) && !getenv("BDRT_GENERIC_TILE")) ? 1 : 0;
+                     !getenv("BDRT_GENERIC_TILE")) ? 1 : 0;
         // ... and with A_re, A_im exactly Toeplitz (equal log spacing of frequencies and tau) on the shapes of the reference's
         // default grids (ten points per decade over eight decades: nf = 80..82; K = 80..82 or 160..162), which tile as whole
         // blocks of 80 plus at most two rows: GEMM operands from an LDS-resident generator table (bdrt_tile_s1.h::toep_gemm)
@@ -280,8 +280,27 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
             !getenv("BDRT_STREAM_A")) {
             D.toepA = 1;
             D.tlen = (8 + nf + D.blk[0].K - 1 + 8 + 1) & ~1;
-            const size_t nj = D.D <= 32 * 11 ? 11 : 16;      // (the sampler's theta rows, bdrt_nuts.hip::nuts_lds_bytes)
+            // (the sampler's theta rows, bdrt_nuts.hip::nuts_lds_bytes; with outlier parameters its state stays in HBM)
+            const size_t nj = D.outlier_mode ? 0 : (D.D <= 32 * 11 ? 11 : 16);
             if ((s1_lds_doubles(D) + (size_t)NC * 32 * nj) * sizeof(double) + SAMPLER_LDS_RESERVE > 160 * 1024) { D.toepA = 0; D.tlen = 0; }
+        }
+        // ... and on every other shape (partial tiles, any reduction length: bdrt_tile_s1.h::toep_gemm_gen; BDRT_TOEP_GEN=1: on the
+        // default shapes too, for the tests).  The imaginary rows of A x start at nf rounded up to four.
+        if (D.fast_s1 && D.blk[0].tg && nf >= 32 && D.blk[0].K >= 32 && !getenv("BDRT_STREAM_A") &&
+            (!D.toepA || (getenv("BDRT_TOEP_GEN") && atoi(getenv("BDRT_TOEP_GEN")) != 0)) &&
+            !(getenv("BDRT_TOEP_GEN") && atoi(getenv("BDRT_TOEP_GEN")) == 0)) {
+            const int toepA0 = D.toepA, tlen0 = D.tlen;
+            D.toepA = 2;
+            D.tlen = (16 + nf + D.blk[0].K - 1 + 16 + 1) & ~1;
+            D.zrows = std::max(2 * ((nf + 3) & ~3), 16 * D.blk[0].tilesA);     // (never below what the other S1 instantiations lay out)
+            const size_t nj = D.outlier_mode ? 0 : (D.D <= 32 * 11 ? 11 : 16);
+            std::vector<unsigned> steps(TOEP_STEP_WORDS);
+            bool ok = true;
+            for (int dir = 0; dir < 2 && ok; ++dir)
+                for (int w = 0; w < 8 && ok; ++w)
+                    ok = toep_gen_steps(dir == 0, nf, D.blk[0].K, D.tlen, w, steps.data() + (size_t)(dir * 8 + w) * 2 * TOEP_STEPS) >= 0;
+            if (!ok || (s1_lds_doubles(D) + (size_t)NC * 32 * nj) * sizeof(double) + SAMPLER_LDS_RESERVE > 160 * 1024) { D.toepA = toepA0; D.tlen = tlen0; D.zrows = 0; }
+            else if (int rc = upload(P, steps, &D.tsteps)) return rc;
         }
         // every other family (several distributions, parallel blocks, x_sum prior): the general half-wave evaluator
         bool hw = all && !D.fast_s1 && nf <= 128 && !getenv("BDRT_GENERIC_TILE") &&
@@ -300,7 +319,7 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
         // Beyond the LDS budget of the tile evaluators (the reference takes any grid: inversion.py:2127-2209): the streamed
         // evaluator of bdrt_big.h -- plain copies of the matrices and their transposes in HBM, vectors in a per-point workspace
         D.big = 1;
-        D.fast_s1 = 0; D.fast_hw = 0; D.toepA = 0; D.tlen = 0;
+        D.fast_s1 = 0; D.fast_hw = 0; D.toepA = 0; D.tlen = 0; D.zrows = 0;
         P.lds_bytes = 4096;
         for (int b = 0; b < dat->nblocks; ++b) {
             DevBlock &B = D.blk[b];
@@ -347,7 +366,7 @@ static int set_Z(Problem &P, const double *Z, int n_spectra)
     return P.sync_dev();
 }
 
-// MODE 0: dense L path, 1: structured L path (generic tile), 2: fast S1 tile, 3: general half-wave tile, 4: S1 tile with the A operands from the LDS table
+// MODE 0: dense L path, 1: structured L path (generic tile), 2: fast S1 tile, 3: general half-wave tile, 4: S1 tile with the A operands from the LDS table, 6: the same on any shape (toepA == 2)
 template <int MODE>
 __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restrict__ Pp, const double *theta, const int *spec, int B,
                                                        int jacobian, double *lp, double *grad, double *params,
@@ -369,7 +388,8 @@ __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restr
     io.sigma_tot = sig ? sig + (size_t)c0 * 2 * P.nf : nullptr;
     io.params = params ? params + (size_t)c0 * P.D : nullptr;
     io.prof = nullptr;
-    if (MODE == 4) { s1_toep_init(P, smem); logp_grad_tile_s1<false, 32, NoHook, NoHook, true>(P, io, smem); }
+    if (MODE == 4) { s1_toep_init(P, smem); logp_grad_tile_s1<false, 32, NoHook, NoHook, 1>(P, io, smem); }
+    else if (MODE == 6) { s1_toep_init(P, smem); logp_grad_tile_s1<false, 32, NoHook, NoHook, 2>(P, io, smem); }
     else if (MODE == 3) logp_grad_tile_hw(P, io, smem);
     else if (MODE == 2) logp_grad_tile_s1<false>(P, io, smem);
     else if (MODE == 1) logp_grad_tile<true>(P, io, smem);
@@ -415,10 +435,11 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
     }
     static LdsAttrCache attr_cache;
     BDRT_HIP(attr_cache.ensure(p->lds_bytes, [&]() {
-        const void *fns[6] = {(const void *)logp_grad_kernel<0>, (const void *)logp_grad_kernel<1>, (const void *)logp_grad_kernel<2>,
-                              (const void *)logp_grad_kernel_wide, (const void *)logp_grad_kernel<3>, (const void *)logp_grad_kernel<4>};
+        const void *fns[7] = {(const void *)logp_grad_kernel<0>, (const void *)logp_grad_kernel<1>, (const void *)logp_grad_kernel<2>,
+                              (const void *)logp_grad_kernel_wide, (const void *)logp_grad_kernel<3>, (const void *)logp_grad_kernel<4>,
+                              (const void *)logp_grad_kernel<6>};
         hipError_t e = hipSuccess;
-        for (int i = 0; i < 6 && e == hipSuccess; ++i)
+        for (int i = 0; i < 7 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
         return e;
     }));
@@ -429,6 +450,9 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
                            d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
     else if (p->dev.fast_hw)
         hipLaunchKernelGGL(logp_grad_kernel<3>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
+                           d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
+    else if (p->dev.fast_s1 && p->dev.toepA == 2)
+        hipLaunchKernelGGL(logp_grad_kernel<6>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
                            d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
     else if (p->dev.fast_s1 && p->dev.toepA)
         hipLaunchKernelGGL(logp_grad_kernel<4>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,

@@ -77,11 +77,11 @@ __device__ __forceinline__ void lds_wave_sync()
 // NJ = elements of a D-vector per lane (D <= 32*NJ): compile-time so that every pass over a chain's vectors is fully
 // unrolled into a batch of independent loads followed by the arithmetic (one memory round trip per stage instead of one
 // per element -- the state vectors of 2048+ chains live in HBM/MALL, not in L2).
-// TA (MODE 2 only): DevProblem::toepA, the S1 tile's GEMMs take the A operands from the generator table in LDS
+// TA (MODE 2 only): DevProblem::toepA (1: the default shapes, 2: any shape), the S1 tile's GEMMs take the A operands from the generator table in LDS
 #ifndef BDRT_NUTS_EARLY_STATE
 #define BDRT_NUTS_EARLY_STATE 1
 #endif
-template <int NJ, int MODE, bool TA = false>   // MODE 0: dense L, 1: structured L (generic tile), 2: S1 tile + theta rows in LDS, 3: S1 tile, state in HBM, 4: general half-wave tile
+template <int NJ, int MODE, int TA = 0>   // MODE 0: dense L, 1: structured L (generic tile), 2: S1 tile + theta rows in LDS, 3: S1 tile, state in HBM, 4: general half-wave tile
 __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1925,7 +1925,8 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     static LdsAttrCache attr_cache;
     const hipError_t ae = attr_cache.ensure(S.lds_bytes, [&]() {
-        const void *fns[15] = {(const void *)nuts_kernel<11, 2, true>, (const void *)nuts_kernel<16, 2, true>,
+        const void *fns[17] = {(const void *)nuts_kernel<11, 2, 2>, (const void *)nuts_kernel<16, 2, 2>,
+                               (const void *)nuts_kernel<11, 2, 1>, (const void *)nuts_kernel<16, 2, 1>,
                                (const void *)nuts_kernel<11, 1>, (const void *)nuts_kernel<11, 0>,
                                (const void *)nuts_kernel<16, 1>, (const void *)nuts_kernel<16, 0>,
                                (const void *)nuts_kernel<27, 1>, (const void *)nuts_kernel<27, 0>,
@@ -1937,7 +1938,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
             e = hipFuncSetAttribute((const void *)nuts_solo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)nuts_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
-        for (int i = 0; i < 15 && e == hipSuccess; ++i)
+        for (int i = 0; i < 17 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         return e;
     });
@@ -2011,10 +2012,14 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             else
                 hipLaunchKernelGGL(nuts_solo_kernel<2>, dim3(S.n_solo), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
         }
+        else if (S.use_s1 && S.prob->dev.toepA == 2 && S.D <= 32 * 11)
+            hipLaunchKernelGGL((nuts_kernel<11, 2, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
+        else if (S.use_s1 && S.prob->dev.toepA == 2)
+            hipLaunchKernelGGL((nuts_kernel<16, 2, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
         else if (S.use_s1 && S.prob->dev.toepA && S.D <= 32 * 11)
-            hipLaunchKernelGGL((nuts_kernel<11, 2, true>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
+            hipLaunchKernelGGL((nuts_kernel<11, 2, 1>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
         else if (S.use_s1 && S.prob->dev.toepA)
-            hipLaunchKernelGGL((nuts_kernel<16, 2, true>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
+            hipLaunchKernelGGL((nuts_kernel<16, 2, 1>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
         else if (S.use_s1 && S.D <= 32 * 11)
             hipLaunchKernelGGL((nuts_kernel<11, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
         else if (S.use_s1)

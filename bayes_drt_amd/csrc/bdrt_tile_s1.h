@@ -155,9 +155,14 @@ constexpr int WIN = UK + NTAP - 1;        // 22 values feed the 17-tap convoluti
 //     halves of a tile accumulate into zeroed cells with LDS atomics: two contributions commute exactly (0 + a + b = 0 + b + a),
 //     so the result does not depend on their order.
 // Lane l of a wave holds row i = l & 15, reduction index kq = l >> 4 of the A operand, column l & 15 of the B operand.
+// rows of the A x / g region Zh; leading zeros of a part of the generator table; first row of the imaginary part in Zh
+__host__ __device__ inline int s1_zrows(const DevProblem &P) { return P.toepA == 2 ? P.zrows : 16 * P.blk[0].tilesA; }
+template <int TA> __device__ __forceinline__ constexpr int toep_pad() { return TA == 2 ? 16 : 8; }
+template <int TA> __device__ __forceinline__ int toep_im_row(int nf) { return TA == 2 ? (nf + 3) & ~3 : nf; }
+
 __device__ __forceinline__ const double *s1_toep_table(const DevProblem &P, const double *smem)
 {
-    return smem + (size_t)NC * (P.XR + 16 * P.blk[0].tilesA) + (size_t)2 * NC * RW;
+    return smem + (size_t)NC * (P.XR + s1_zrows(P)) + (size_t)2 * NC * RW;
 }
 
 // FWD: Os = Zh, rows part * nf + n of (A_part x)[n], Bs = Xs (x, zero from row K on); else Os = Xs, rows k of A^T g, Bs = Zh (g).
@@ -342,6 +347,264 @@ __device__ __forceinline__ void toep_zero_split(int nf, int K, double *Os, int t
     }
 }
 
+// ---- the same for any shape (DevProblem::toepA == 2: nf, K >= 16) ---------------------------------------------------------------
+// What differs from toep_gemm:
+//   * a part's rows beyond its whole tiles are one more (partial) tile when there are more than two of them (two or fewer are the
+//     VALU dot products of the caller, as there); the rows of a partial tile beyond nf (forward) / K (backward) are not stored;
+//   * the imaginary rows of Zh start at nf rounded up to four, with zeros in between and behind: the backward reduction is
+//     ceil(nf / 4) whole chunks per part, whatever nf;
+//   * a reduction is cut into blocks of at most five quads of equal length (immediate offsets from one pointer set per block,
+//     as there) plus up to three single chunks, a step of their own; whatever a step is, what follows it is requested by the same
+//     instructions behind the first MFMA of its last quad;
+//   * T tiles on eight waves: rounds of eight whole tiles; the R tiles beyond them as halves of the reduction range (R <= 4),
+//     four whole tiles and the others as halves (R = 5, 6), whole (R = 7).  Halves add up in zeroed cells as there.
+struct ToepSched { int base, R, mode, npiece; };     // mode 0: whole tiles only, 1: the R tiles in halves, 2: four whole + (R - 4) in halves
+__host__ __device__ inline ToepSched toep_sched(int T, bool can_halve)
+{
+    ToepSched sc;
+    sc.base = T & ~7; sc.R = T - sc.base;
+    sc.mode = (sc.R == 0 || !can_halve || sc.R == 7) ? 0 : (sc.R <= 4 ? 1 : 2);
+    sc.npiece = sc.base + (sc.mode == 0 ? sc.R : (sc.mode == 1 ? 2 * sc.R : 2 * sc.R - 4));
+    return sc;
+}
+// tiles of m rows (of one part going forward): two or fewer rows beyond the whole tiles are not a tile
+__host__ __device__ inline int toep_gen_tiles(int m) { return (m & 15) <= 2 ? (m >> 4) : ((m + 15) >> 4); }
+__host__ __device__ inline int toep_gen_odd(int m) { return (m & 15) <= 2 ? (m & 15) : 0; }
+
+// The runs of wave `wave` through one GEMM, worked out on the host at bdrt_problem_create (the schedule depends on the shape only;
+// walking it on the device cost ~200 scalar instructions per step in front of the step's first MFMA).  A run = the reduction range
+// of one part for one tile (or half of it): whole quads and, behind them, the range's single chunks.  Two words per run:
+//   w0 = table offset of the A operand (16 bits) | first quad << 16 (B operand rows, 8 bits) | kind << 24 | imaginary part << 30
+//        kind 0: a whole tile's run (forward: one per tile; backward: two, real and imaginary -- or one of them when two waves share
+//        the tile), 1 / 2: first / second half of the quads of a forward tile that two waves share (the second with the single chunks)
+//   w1 = first output row (12 bits) | rows of the tile that exist << 12 (5 bits) | shared with another wave << 21 | valid << 24
+// A wave's whole tiles come first, then at most one shared one.  The list ends with a run that is not valid and repeats the first
+// one's addresses (requested, never used).
+constexpr int TOEP_STEPS = 8;                         // runs per wave and GEMM, with the end mark
+constexpr int TOEP_STEP_WORDS = 2 * 8 * TOEP_STEPS * 2;    // both GEMMs, eight waves
+inline int toep_gen_steps(bool fwd, int nf, int K, int tlen, int wave, unsigned *out)
+{
+    const int PAD = 16;
+    const int nfi = (nf + 3) & ~3;
+    const int TPP = fwd ? toep_gen_tiles(nf) : 0;
+    const int T = fwd ? 2 * TPP : toep_gen_tiles(K);
+    const int nch = fwd ? (K + 3) >> 2 : nfi >> 2;           // chunks of four reduction indices (per part going backward)
+    const int nq = nch >> 2;
+    const int qsplit = (nq + 1) >> 1;
+    const int lim = fwd ? nf : K;
+    if (nq < 2 || nq > 12) return -1;
+    const ToepSched sc = toep_sched(T, fwd ? nq >= 4 : true);           // (a run has two quads or more)
+    int n = 0;
+    bool shared_seen = false;
+    auto emit = [&](int part, int n0, int q0, int kind, int shared) {
+        const int aoff = fwd ? part * tlen + PAD + n0 + (K - 1) - 16 * q0 : part * tlen + PAD - n0 + (K - 1);
+        const int orow = fwd ? part * nfi + n0 : n0;
+        int room = lim - n0; room = room > 16 ? 16 : room;
+        if (aoff < 0 || aoff > 65535 || q0 > 255 || orow > 4095 || n >= TOEP_STEPS - 1) return -1;
+        out[2 * n] = (unsigned)aoff | (unsigned)q0 << 16 | (unsigned)kind << 24 | (unsigned)(fwd ? 0 : part) << 30;
+        out[2 * n + 1] = (unsigned)orow | (unsigned)room << 12 | (unsigned)shared << 21 | 1u << 24;
+        ++n;
+        return 0;
+    };
+    for (int s = wave; s < sc.npiece; s += 8) {
+        int t = s, half = -1;
+        if (s >= sc.base) {
+            const int j = s - sc.base;
+            if (sc.mode == 1) { t = sc.base + (j >> 1); half = j & 1; }
+            else if (sc.mode == 2 && j >= 4) { t = sc.base + 4 + ((j - 4) >> 1); half = (j - 4) & 1; }
+        }
+        if (shared_seen) return -1;                           // (whole tiles first, at most one shared tile)
+        if (half >= 0) shared_seen = true;
+        if (fwd) {
+            const int part = t >= TPP ? 1 : 0, n0 = 16 * (t - part * TPP);
+            if (emit(part, n0, half == 1 ? qsplit : 0, half + 1, half >= 0 ? 1 : 0)) return -1;
+        } else if (half < 0) {
+            if (emit(0, 16 * t, 0, 0, 0) || emit(1, 16 * t, 0, 0, 0)) return -1;
+        } else if (emit(half, 16 * t, 0, 0, 1)) return -1;
+    }
+    const int runs = n;
+    if (runs == 0) { out[0] = (unsigned)(PAD + K - 1); out[1] = 0; }
+    else { out[2 * n] = out[0]; out[2 * n + 1] = out[1] & ~(1u << 24); }
+    ++n;
+    for (; n < TOEP_STEPS; ++n) { out[2 * n] = out[2 * runs]; out[2 * n + 1] = out[2 * runs + 1]; }
+    return runs;
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void toep_static_for(F &&f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>()); toep_static_for<I + 1, N>(f); }
+}
+
+// Tt: the generator table, with the run lists behind it (s1_toep_init).  A run is straight-line code for its number of quads (the
+// same for every whole tile of a call: one switch in front of the loops) -- no block loop inside a run, one place in the code for
+// every load, so that the operand buffers and the accumulators stay where they are from run to run.  (A version that walked
+// blocks of two to five quads through one chain of code with entry points moved sixteen to twenty-four registers per step, and
+// a VALU instruction costs a whole MFMA slot while the SIMD's other wave streams MFMAs.)
+template <bool FWD>
+__device__ __forceinline__ void toep_gemm_gen(int nf, int K, int tlen, const double *Tt, const double *Bs, double *Os, int wave, int lane)
+{
+    typedef const __attribute__((address_space(3))) double *lds_cptr;
+    typedef const __attribute__((address_space(3))) unsigned *lds_uptr;
+    constexpr int BIAS = FWD ? 16 * 12 + 12 : 0;          // keeps the immediate offsets of the A operand non-negative up to quad 12
+    const int i = lane & 15, kq = lane >> 4, col = i;
+    wave = __builtin_amdgcn_readfirstlane(wave);
+    const int nfi = (nf + 3) & ~3;
+    const int nch = FWD ? (K + 3) >> 2 : nfi >> 2;
+    const int nq = nch >> 2, nr = nch & 3;
+    // lane j holds run j of this wave
+    const lds_uptr stp = (lds_uptr)(Tt + 2 * tlen) + ((FWD ? 0 : 8) + wave) * (2 * TOEP_STEPS) + 2 * (lane & (TOEP_STEPS - 1));
+    const unsigned w0v = stp[0], w1v = stp[1];
+
+    // ---- lane constants (see toep_gemm) ----
+    const lds_cptr aL = (lds_cptr)(Tt + (FWD ? i - kq - BIAS : kq - i));
+    lds_cptr bL0 = (lds_cptr)(Bs + swz(kq, col)), bL1 = (lds_cptr)(Bs + swz(4 + kq, col)), bL2 = (lds_cptr)(Bs + swz(8 + kq, col)),
+             bL3 = (lds_cptr)(Bs + swz(12 + kq, col));
+    const int dI0 = FWD ? 0 : swz(nfi + kq, col) - swz(kq, col), dI1 = FWD ? 0 : swz(nfi + 4 + kq, col) - swz(4 + kq, col),
+              dI2 = FWD ? 0 : swz(nfi + 8 + kq, col) - swz(8 + kq, col), dI3 = FWD ? 0 : swz(nfi + 12 + kq, col) - swz(12 + kq, col);
+
+    lds_cptr a, b0, b1, b2, b3;
+    double A0[4], B0[4], A1[4], B1[4], A2[4], B2[4];
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    // quad r behind the run's pointers
+    auto ld = [&](double (&A)[4], double (&B)[4], auto Rr) {
+        constexpr int r = decltype(Rr)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A[j] = FWD ? a[BIAS - 16 * r - 4 * j] : a[16 * r + 4 * j];
+        B[0] = b0[16 * NC * r]; B[1] = b1[16 * NC * r]; B[2] = b2[16 * NC * r]; B[3] = b3[16 * NC * r];
+    };
+    // the run's pointers and its first quad into (A2, B2)
+    auto prefetch = [&](unsigned w0) {
+        const int aoff = (int)(w0 & 0xffffu), o = 16 * NC * (int)((w0 >> 16) & 0xffu);
+        a = aL + aoff;
+        if (FWD) { b0 = bL0 + o; b1 = bL1 + o; b2 = bL2 + o; b3 = bL3 + o; }
+        else {
+            const bool im = (w0 >> 30) != 0;
+            b0 = bL0 + (im ? dI0 : 0); b1 = bL1 + (im ? dI1 : 0); b2 = bL2 + (im ? dI2 : 0); b3 = bL3 + (im ? dI3 : 0);
+        }
+        ld(A2, B2, std::integral_constant<int, 0>());
+    };
+    // a run of L quads and m single chunks; FIRST: the tile's first run (nothing accumulated yet); nw0: the run that follows.
+    // Quad r + 1 is requested behind the first MFMA of quad r; behind the first MFMA of the last quad: the single chunks into the
+    // buffer that quad does not use (whether there are any or not: no load under a condition) and the next run's first quad.
+    auto run = [&](auto Lc, auto Fc, unsigned nw0, int m) {
+        constexpr int L = decltype(Lc)::value;
+        constexpr bool FIRST = decltype(Fc)::value;
+        toep_static_for<0, L>([&](auto Rc) {
+            constexpr int r = decltype(Rc)::value;
+            auto quad = [&](const double (&A)[4], const double (&B)[4]) {
+                const d4 zero = {0.0, 0.0, 0.0, 0.0};
+                acc0 = mfma_f64(A[0], B[0], (FIRST && r == 0) ? zero : acc0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (((r + 1) & 1) != 0) ld(A0, B0, std::integral_constant<int, r + 1>());
+                else ld(A1, B1, std::integral_constant<int, r + 1>());
+                if constexpr (r == L - 1) prefetch(nw0);
+                __builtin_amdgcn_sched_barrier(0);
+                acc1 = mfma_f64(A[1], B[1], (FIRST && r == 0) ? zero : acc1);
+                acc0 = mfma_f64(A[2], B[2], acc0);
+                acc1 = mfma_f64(A[3], B[3], acc1);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if constexpr (r == 0) quad(A2, B2);
+            else if constexpr ((r & 1) != 0) quad(A0, B0);
+            else quad(A1, B1);
+        });
+        auto single = [&](const double (&A)[4], const double (&B)[4]) {
+            if (m > 0) acc0 = mfma_f64(A[0], B[0], acc0);
+            if (m > 1) acc1 = mfma_f64(A[1], B[1], acc1);
+            if (m > 2) acc0 = mfma_f64(A[2], B[2], acc0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr ((L & 1) != 0) single(A0, B0); else single(A1, B1);
+    };
+    auto store = [&](unsigned c1) {
+        const d4 sum = acc0 + acc1;
+        const int orow = (int)(c1 & 0xfffu), room = (int)((c1 >> 12) & 0x1fu);
+        const bool shared = ((c1 >> 21) & 1u) != 0;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            if (kq + 4 * rr < room) {
+                double *o = Os + swz(orow + kq + 4 * rr, col);
+                if (!shared) *o = sum[rr];
+                else __hip_atomic_fetch_add(o, sum[rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
+    typedef std::true_type Tr;
+    typedef std::false_type Fa;
+
+    unsigned c0 = __builtin_amdgcn_readlane(w0v, 0), c1 = __builtin_amdgcn_readlane(w1v, 0);
+    if (!((c1 >> 24) & 1u)) return;
+    prefetch(c0);
+    // the loops for whole tiles of L quads, then the shared tile if the wave has one
+    auto body = [&](auto Lc) {
+        constexpr int L = decltype(Lc)::value;
+        int st = 1;
+        if (FWD) {
+            while (((c1 >> 24) & 1u) && ((c0 >> 24) & 3u) == 0) {
+                const unsigned n0w = __builtin_amdgcn_readlane(w0v, st), n1w = __builtin_amdgcn_readlane(w1v, st);
+                ++st;
+                run(Lc, Tr(), n0w, nr);
+                store(c1);
+                c0 = n0w; c1 = n1w;
+            }
+            if ((c1 >> 24) & 1u) {
+                const unsigned n0w = __builtin_amdgcn_readlane(w0v, st);
+                if (((c0 >> 24) & 3u) == 1) run(std::integral_constant<int, (L + 1) / 2 >= 2 ? (L + 1) / 2 : 2>(), Tr(), n0w, 0);
+                else run(std::integral_constant<int, L / 2 >= 2 ? L / 2 : 2>(), Tr(), n0w, nr);
+                store(c1);
+            }
+        } else {
+            while (((c1 >> 24) & 1u) && !((c1 >> 21) & 1u)) {
+                const unsigned m0w = __builtin_amdgcn_readlane(w0v, st);
+                const unsigned n0w = __builtin_amdgcn_readlane(w0v, st + 1), n1w = __builtin_amdgcn_readlane(w1v, st + 1);
+                st += 2;
+                run(Lc, Tr(), m0w, nr);                    // real part; requests the imaginary part's first quad
+                run(Lc, Fa(), n0w, nr);
+                store(c1);
+                c0 = n0w; c1 = n1w;
+            }
+            if ((c1 >> 24) & 1u) {
+                const unsigned n0w = __builtin_amdgcn_readlane(w0v, st);
+                run(Lc, Tr(), n0w, nr);
+                store(c1);
+            }
+        }
+    };
+    switch (nq) {
+    case 2: body(std::integral_constant<int, 2>()); break;
+    case 3: body(std::integral_constant<int, 3>()); break;
+    case 4: body(std::integral_constant<int, 4>()); break;
+    case 5: body(std::integral_constant<int, 5>()); break;
+    case 6: body(std::integral_constant<int, 6>()); break;
+    case 7: body(std::integral_constant<int, 7>()); break;
+    case 8: body(std::integral_constant<int, 8>()); break;
+    case 9: if constexpr (FWD) body(std::integral_constant<int, 9>()); break;
+    case 10: if constexpr (FWD) body(std::integral_constant<int, 10>()); break;
+    case 11: if constexpr (FWD) body(std::integral_constant<int, 11>()); break;
+    case 12: if constexpr (FWD) body(std::integral_constant<int, 12>()); break;
+    default: break;
+    }
+}
+
+// the output cells of the tiles that two waves share (toep_gemm_gen's schedule): zero before the GEMM, as toep_zero_split
+template <bool FWD>
+__device__ __forceinline__ void toep_zero_split_gen(int nf, int K, double *Os, int tid)
+{
+    const int nfi = (nf + 3) & ~3;
+    const int TPP = FWD ? toep_gen_tiles(nf) : 0;
+    const int T = FWD ? 2 * TPP : toep_gen_tiles(K);
+    const ToepSched sc = toep_sched(T, FWD ? (((K + 3) >> 2) >> 2) >= 4 : true);
+    if (sc.mode == 0) return;
+    const int first = sc.mode == 1 ? sc.base : sc.base + 4, cnt = sc.mode == 1 ? sc.R : sc.R - 4;
+    for (int e = tid; e < cnt * 256; e += NT) {
+        const int t = first + (e >> 8), r = (e >> 4) & 15;
+        const int part = (FWD && t >= TPP) ? 1 : 0;
+        const int n = FWD ? 16 * (t - part * TPP) + r : 16 * t + r;
+        if (n < (FWD ? nf : K)) Os[(FWD ? part * nfi + n : n) * NC + (e & 15)] = 0.0;
+    }
+}
+
 // once per kernel, all NT threads, ends with a barrier: the generator table, and zeros in the rows of Zh behind the 2 nf
 // rows of g that the backward GEMM's last chunk multiplies for its idle lanes
 __device__ __forceinline__ void s1_toep_init(const DevProblem &P, double *smem)
@@ -349,12 +612,17 @@ __device__ __forceinline__ void s1_toep_init(const DevProblem &P, double *smem)
     const DevBlock &B = P.blk[0];
     double *Tt = const_cast<double *>(s1_toep_table(P, smem));
     double *Zh = smem + (size_t)P.XR * NC;
-    const int glen = P.nf + B.K - 1, tlen = P.tlen;
+    const int glen = P.nf + B.K - 1, tlen = P.tlen, pad = P.toepA == 2 ? 16 : 8;
     for (int e = threadIdx.x; e < 2 * tlen; e += NT) {
-        const int part = e >= tlen ? 1 : 0, j = e - part * tlen - 8;
+        const int part = e >= tlen ? 1 : 0, j = e - part * tlen - pad;
         Tt[e] = (j >= 0 && j < glen) ? B.tg[(size_t)part * glen + j] : 0.0;
     }
-    for (int e = 2 * P.nf * NC + threadIdx.x; e < 16 * B.tilesA * NC; e += NT) Zh[e] = 0.0;
+    if (P.toepA == 2) {
+        unsigned *st = (unsigned *)(Tt + 2 * tlen);
+        for (int e = threadIdx.x; e < TOEP_STEP_WORDS; e += NT) st[e] = P.tsteps[e];
+    }
+    // (toepA == 2: all of Zh -- the rows between the parts and behind them stay zero for good)
+    for (int e = (P.toepA == 2 ? 0 : 2 * P.nf * NC) + threadIdx.x; e < s1_zrows(P) * NC; e += NT) Zh[e] = 0.0;
     __syncthreads();
 }
 
@@ -362,11 +630,10 @@ __device__ __forceinline__ void s1_toep_init(const DevProblem &P, double *smem)
 __device__ __forceinline__ double *s1_grad_row(const DevProblem &P, double *smem, int c);
 
 
-// LDS: Xs [XR rows][16] | Zh [16*tilesA rows][16] | private rows [16 chains][2 RW] | (toepA) generator table [2][tlen]
+// LDS: Xs [XR rows][16] | Zh [16*tilesA rows][16] | private rows [16 chains][2 RW] | (toepA) generator table [2][tlen] | (toepA == 2) step lists
 __host__ __device__ inline size_t s1_lds_doubles(const DevProblem &P)
 {
-    const DevBlock &B = P.blk[0];
-    return (size_t)NC * (P.XR + 16 * B.tilesA) + (size_t)2 * NC * RW + (P.toepA ? (size_t)2 * P.tlen : 0);
+    return (size_t)NC * (P.XR + s1_zrows(P)) + (size_t)2 * NC * RW + (P.toepA ? (size_t)2 * P.tlen : 0) + (P.toepA == 2 ? (size_t)TOEP_STEP_WORDS / 2 : 0);
 }
 
 // Two thread mappings of a chain's K-vectors inside its half-wave:
@@ -388,8 +655,8 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // issue the global loads of the state it needs next, so that their latency hides behind the MFMA work.
 // `after_x_ready` runs right after the first barrier (X of all 16 chains published): the sampler reads the chains' activity
 // flags there -- every wave has finished its previous round by then -- instead of voting at a barrier of its own.
-// TA: DevProblem::toepA -- the caller has run s1_toep_init once in this kernel.
-template <bool LDSIO, int LPC = 32, class Hook = NoHook, class Hook1 = NoHook, bool TA = false>
+// TA: DevProblem::toepA (0, 1: toep_gemm, 2: toep_gemm_gen) -- the caller has run s1_toep_init once in this kernel.
+template <bool LDSIO, int LPC = 32, class Hook = NoHook, class Hook1 = NoHook, int TA = 0>
 __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, double *smem, Hook before_backward = Hook(),
                                          Hook1 after_x_ready = Hook1())
 {
@@ -415,7 +682,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
 
     double *Xs = smem;
     double *Zh = Xs + (size_t)P.XR * NC;
-    double *xrow = Zh + (size_t)16 * B.tilesA * NC + (size_t)c * (2 * RW);   // the chain's private row: 2 RW doubles
+    double *xrow = Zh + (size_t)(TA == 2 ? P.zrows : 16 * B.tilesA) * NC + (size_t)c * (2 * RW);   // the chain's private row: 2 RW doubles
     double *wrow = xrow + RW;
 
     const double *th = io.theta + (long)cc * io.t_sc;
@@ -481,20 +748,22 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     static_assert(!TA || LPC == 32, "the Toeplitz-A GEMMs are written for 512 threads");
     const double *Tt = TA ? s1_toep_table(P, smem) : nullptr;
     const int tlen = TA ? P.tlen : 0;
+    constexpr int TPAD = toep_pad<TA>();
+    const int nfi = toep_im_row<TA>(nf);                   // first row of A_im x in Zh
     if (TA) {
         // the rows of A_re x and A_im x beyond the full tiles (nf % 16 <= 2 of each part): dot products while x is in registers
-        const int r16 = nf & 15, n0 = nf - r16;
+        const int r16 = TA == 2 ? toep_gen_odd(nf) : (nf & 15), n0 = nf - r16;
         for (int j = 0; j < r16; ++j) {
             double sr = 0.0, si = 0.0;
 #pragma unroll
             for (int u = 0; u < UKV; ++u) {
-                const int idx = max(8 + n0 + j + (K - 1) - (l32 + LPC * u), 0);     // (x_ is zero from K on)
+                const int idx = max(TPAD + n0 + j + (K - 1) - (l32 + LPC * u), 0);     // (x_ is zero from K on)
                 sr = fma(Tt[idx], x_[u], sr); si = fma(Tt[tlen + idx], x_[u], si);
             }
             sr = hsum<LPC>(sr); si = hsum<LPC>(si);
-            if (l32 == 0) { Zh[swz(n0 + j, c)] = sr; Zh[swz(nf + n0 + j, c)] = si; }
+            if (l32 == 0) { Zh[swz(n0 + j, c)] = sr; Zh[swz(nfi + n0 + j, c)] = si; }
         }
-        toep_zero_split<true>(nf, K, Zh, tid);
+        if (TA == 2) toep_zero_split_gen<true>(nf, K, Zh, tid); else toep_zero_split<true>(nf, K, Zh, tid);
     }
     const double d0 = __shfl(sraw, hb | 6), d1 = __shfl(sraw, hb | 7), d2 = __shfl(sraw, hb | 8);
     // priors of the 9 scalars (std_normal on the six raws, inv_gamma(5,5) on the d's) + log-Jacobian: lane j owns scalar j
@@ -520,7 +789,8 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         BDRT_S1_PROF(1);
         BDRT_S1_TRACE(3);
         if (!(dbg & 1)) {
-            if (TA) toep_gemm<true>(nf, K, tlen, Tt, Xs, Zh, wave, lane);
+            if (TA == 2) toep_gemm_gen<true>(nf, K, tlen, Tt, Xs, Zh, wave, lane);
+            else if (TA) toep_gemm<true>(nf, K, tlen, Tt, Xs, Zh, wave, lane);
             else gemm_sw<NWV, GPFV>(B.Af, B.tilesA, B.kpairs, Xs, Zh, wave, lane);                // Zh = A x  (pad rows come out as exact zeros)
         }
         continue;
@@ -665,16 +935,16 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         const double ap2 = a_p * a_p, ar2 = a_r * a_r, ai2 = a_i * a_i;
         double sR = 0, sL = 0, sH = 0, sHz2 = 0, sHzr2 = 0, sHzi2 = 0;
         // TA: the rows k >= 16 (K / 16) of A^T g (K % 16 <= 2 of them) are dot products with g while it is in registers
-        const int rk = TA ? (K & 15) : 0;
+        const int rk = TA == 2 ? toep_gen_odd(K) : (TA ? (K & 15) : 0);
         double lk0 = 0.0, lk1 = 0.0;
-        if (TA) toep_zero_split<false>(nf, K, Xs, tid);
+        if (TA == 2) toep_zero_split_gen<false>(nf, K, Xs, tid); else if (TA) toep_zero_split<false>(nf, K, Xs, tid);
 #pragma unroll
         for (int v = 0; v < UNV; ++v) {
             const int n = l32 + LPC * v;
             if (n >= nf) continue;
             const double wn = wn_[v];
             const double zr = Zh[swz(n, c)] + Rinf;
-            const double zi = Zh[swz(nf + n, c)] + induc * wn;
+            const double zi = Zh[swz(nfi + n, c)] + induc * wn;
             // outlier error model (Series_*_outliers_modelcode.txt): 2 Nf extra parameters, read where they are needed
             double so_re = 0.0, so_im = 0.0, r0 = 0.0, r1 = 0.0, t0 = 0.0, t1 = 0.0;
             if (omode) {
@@ -696,10 +966,10 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             const double gzr = e_re * w_re + 2.0 * zr * (h_re * (ap2 + ar2) + h_im * ar2);
             const double gzi = e_im * w_im + 2.0 * zi * (h_im * (ap2 + ai2) + h_re * ai2);
             Zh[swz(n, c)] = gzr;
-            Zh[swz(nf + n, c)] = gzi;
+            Zh[swz(nfi + n, c)] = gzi;
             if (TA && rk > 0) {            // A_part[n][K - rk + j] = tg[part][n + rk - 1 - j]
-                lk0 = fma(Tt[8 + n + rk - 1], gzr, fma(Tt[tlen + 8 + n + rk - 1], gzi, lk0));
-                if (rk > 1) lk1 = fma(Tt[8 + n + rk - 2], gzr, fma(Tt[tlen + 8 + n + rk - 2], gzi, lk1));
+                lk0 = fma(Tt[TPAD + n + rk - 1], gzr, fma(Tt[tlen + TPAD + n + rk - 1], gzi, lk0));
+                if (rk > 1) lk1 = fma(Tt[TPAD + n + rk - 2], gzr, fma(Tt[tlen + TPAD + n + rk - 2], gzi, lk1));
             }
             sR += gzr;
             sL += gzi * wn;
@@ -760,7 +1030,8 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     BDRT_S1_PROF(4);
     before_backward();
     if (!(dbg & 2)) {
-        if (TA) toep_gemm<false>(nf, K, tlen, Tt, Zh, Xs, wave, lane);
+        if (TA == 2) toep_gemm_gen<false>(nf, K, tlen, Tt, Zh, Xs, wave, lane);
+        else if (TA) toep_gemm<false>(nf, K, tlen, Tt, Zh, Xs, wave, lane);
         else gemm_sw<NWV, GPFV>(B.BkA, B.tilesK, B.rpairsA, Zh, Xs, wave, lane);                    // Xs = A^T g_Zhat
     }
     BDRT_S1_TRACE(9);
@@ -801,7 +1072,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
 
 __device__ __forceinline__ double *s1_grad_row(const DevProblem &P, double *smem, int c)
 {
-    return smem + (size_t)NC * (P.XR + 16 * P.blk[0].tilesA) + (size_t)c * (2 * RW);
+    return smem + (size_t)NC * (P.XR + s1_zrows(P)) + (size_t)c * (2 * RW);
 }
 
 }  // namespace bdrt
