@@ -281,7 +281,7 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
             D.toepA = 1;
             D.tlen = (8 + nf + D.blk[0].K - 1 + 8 + 1) & ~1;
             // (the sampler's theta rows, bdrt_nuts.hip::nuts_lds_bytes; with outlier parameters its state stays in HBM)
-            const size_t nj = D.outlier_mode ? 0 : (D.D <= 32 * 11 ? 11 : 16);
+            const size_t nj = D.outlier_mode ? 0 : s1_nj(D.D);
             if ((s1_lds_doubles(D) + (size_t)NC * 32 * nj) * sizeof(double) + SAMPLER_LDS_RESERVE > 160 * 1024) { D.toepA = 0; D.tlen = 0; }
         }
         // ... and on every other shape (partial tiles, any reduction length: bdrt_tile_s1.h::toep_gemm_gen; BDRT_TOEP_GEN=1: on the
@@ -293,7 +293,7 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
             D.toepA = 2;
             D.tlen = (16 + nf + D.blk[0].K - 1 + 16 + 1) & ~1;
             D.zrows = std::max(2 * ((nf + 3) & ~3), 16 * D.blk[0].tilesA);     // (never below what the other S1 instantiations lay out)
-            const size_t nj = D.outlier_mode ? 0 : (D.D <= 32 * 11 ? 11 : 16);
+            const size_t nj = D.outlier_mode ? 0 : s1_nj(D.D);
             std::vector<unsigned> steps(TOEP_STEP_WORDS);
             bool ok = true;
             for (int dir = 0; dir < 2 && ok; ++dir)
@@ -367,7 +367,7 @@ static int set_Z(Problem &P, const double *Z, int n_spectra)
 }
 
 // MODE 0: dense L path, 1: structured L path (generic tile), 2: fast S1 tile, 3: general half-wave tile, 4: S1 tile with the A operands from the LDS table, 6: the same on any shape (toepA == 2)
-template <int MODE>
+template <int MODE, int KU = 6>
 __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restrict__ Pp, const double *theta, const int *spec, int B,
                                                        int jacobian, double *lp, double *grad, double *params,
                                                        double *Zhat, double *sig)
@@ -388,10 +388,10 @@ __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restr
     io.sigma_tot = sig ? sig + (size_t)c0 * 2 * P.nf : nullptr;
     io.params = params ? params + (size_t)c0 * P.D : nullptr;
     io.prof = nullptr;
-    if (MODE == 4) { s1_toep_init(P, smem); logp_grad_tile_s1<false, 32, NoHook, NoHook, 1>(P, io, smem); }
-    else if (MODE == 6) { s1_toep_init(P, smem); logp_grad_tile_s1<false, 32, NoHook, NoHook, 2>(P, io, smem); }
+    if (MODE == 4) { s1_toep_init(P, smem); logp_grad_tile_s1<false, 32, NoHook, NoHook, 1, KU>(P, io, smem); }
+    else if (MODE == 6) { s1_toep_init(P, smem); logp_grad_tile_s1<false, 32, NoHook, NoHook, 2, KU>(P, io, smem); }
     else if (MODE == 3) logp_grad_tile_hw(P, io, smem);
-    else if (MODE == 2) logp_grad_tile_s1<false>(P, io, smem);
+    else if (MODE == 2) logp_grad_tile_s1<false, 32, NoHook, NoHook, 0, KU>(P, io, smem);
     else if (MODE == 1) logp_grad_tile<true>(P, io, smem);
     else logp_grad_tile<false>(P, io, smem);
 }
@@ -435,11 +435,13 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
     }
     static LdsAttrCache attr_cache;
     BDRT_HIP(attr_cache.ensure(p->lds_bytes, [&]() {
-        const void *fns[7] = {(const void *)logp_grad_kernel<0>, (const void *)logp_grad_kernel<1>, (const void *)logp_grad_kernel<2>,
-                              (const void *)logp_grad_kernel_wide, (const void *)logp_grad_kernel<3>, (const void *)logp_grad_kernel<4>,
-                              (const void *)logp_grad_kernel<6>};
+        const void *fns[15] = {(const void *)logp_grad_kernel<0>, (const void *)logp_grad_kernel<1>, (const void *)logp_grad_kernel<2>,
+                               (const void *)logp_grad_kernel_wide, (const void *)logp_grad_kernel<3>, (const void *)logp_grad_kernel<4>,
+                               (const void *)logp_grad_kernel<6>, (const void *)logp_grad_kernel<2, 2>, (const void *)logp_grad_kernel<2, 3>,
+                               (const void *)logp_grad_kernel<2, 4>, (const void *)logp_grad_kernel<4, 3>, (const void *)logp_grad_kernel<6, 2>,
+                               (const void *)logp_grad_kernel<6, 3>, (const void *)logp_grad_kernel<6, 4>, (const void *)logp_grad_kernel<4, 6>};
         hipError_t e = hipSuccess;
-        for (int i = 0; i < 7 && e == hipSuccess; ++i)
+        for (int i = 0; i < 15 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
         return e;
     }));
@@ -451,15 +453,18 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
     else if (p->dev.fast_hw)
         hipLaunchKernelGGL(logp_grad_kernel<3>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
                            d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
-    else if (p->dev.fast_s1 && p->dev.toepA == 2)
-        hipLaunchKernelGGL(logp_grad_kernel<6>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
-                           d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
-    else if (p->dev.fast_s1 && p->dev.toepA)
-        hipLaunchKernelGGL(logp_grad_kernel<4>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
-                           d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
-    else if (p->dev.fast_s1)
-        hipLaunchKernelGGL(logp_grad_kernel<2>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
-                           d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
+    else if (p->dev.fast_s1) {
+        // the instantiation by the basis length (BDRT_S1_KU=6: the one for K <= 192 whatever K is)
+        static const bool ku6 = getenv("BDRT_S1_KU") && atoi(getenv("BDRT_S1_KU")) == 6;
+        const int ku = ku6 ? 6 : s1_ku(p->dev.blk[0].K), ta = p->dev.toepA;
+#define BDRT_S1_LAUNCH(MODE_, KU_)                                                                                                         \
+        hipLaunchKernelGGL((logp_grad_kernel<MODE_, KU_>), dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev, d_theta, \
+                           d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig)
+        if (ta == 2) { if (ku == 2) BDRT_S1_LAUNCH(6, 2); else if (ku == 3) BDRT_S1_LAUNCH(6, 3); else if (ku == 4) BDRT_S1_LAUNCH(6, 4); else BDRT_S1_LAUNCH(6, 6); }
+        else if (ta == 1) { if (ku == 3) BDRT_S1_LAUNCH(4, 3); else BDRT_S1_LAUNCH(4, 6); }
+        else { if (ku == 2) BDRT_S1_LAUNCH(2, 2); else if (ku == 3) BDRT_S1_LAUNCH(2, 3); else if (ku == 4) BDRT_S1_LAUNCH(2, 4); else BDRT_S1_LAUNCH(2, 6); }
+#undef BDRT_S1_LAUNCH
+    }
     else if (p->dev.toep_all)
         hipLaunchKernelGGL(logp_grad_kernel<1>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
                            d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);

@@ -238,7 +238,9 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             // (Measured and dropped: touching one dword per line of the checkpoint rows that this leaf's merges of levels 1..3 will read,
             // so that they wait in L2 by stage D: 0.767 -> 0.751, conditional or not.)
             auto early_state = [&]() { if constexpr (EARLY) load_state(); };
-            logp_grad_tile_s1<true, 32, decltype(early_state), decltype(read_flags), TA>(P, io, smem, early_state, read_flags);
+            // (D = 2 K + 9 here: K <= 59 / 91 / 107 for 4 / 6 / 7 elements per lane)
+            constexpr int KU = NJ <= 4 ? 2 : (NJ <= 6 ? 3 : (NJ <= 7 ? 4 : 6));
+            logp_grad_tile_s1<true, 32, decltype(early_state), decltype(read_flags), TA, KU>(P, io, smem, early_state, read_flags);
             if constexpr (!EARLY) load_state();
         }
         else if (MODE == 3) { logp_grad_tile_s1<false>(P, io, smem); load_state(); }
@@ -1582,7 +1584,7 @@ static_assert((size_t)3 * NC * sizeof(double) + NC * sizeof(ChainState) + 3 * NC
               "bdrt_problem_create reserves SAMPLER_LDS_RESERVE bytes for what the sampler keeps beside the tile region");
 static size_t nuts_lds_bytes(const DevProblem &P, bool s1)
 {
-    const int nj = P.D <= 32 * 11 ? 11 : 16;
+    const int nj = s1_nj(P.D);
     const size_t tile = s1 ? s1_lds_doubles(P) + (size_t)NC * 32 * nj : lds_doubles(P);   // s1: + theta rows
     return (tile + (size_t)3 * NC) * sizeof(double) + NC * sizeof(ChainState) + 3 * NC * sizeof(int) + 16;
 }
@@ -1835,7 +1837,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         if (spec && (spec[u] < 0 || spec[u] >= P.dev.n_spectra)) return fail("bdrt_sampler_create: spectrum index out of range");
 
     // row stride of the state vectors = 32*NJ of the kernel instantiation; the solo kernel keeps [unit][row][ds] with one column
-    const int DS = S.solo ? S.geom.DSS : (S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : (S.D <= 32 * 27 ? 32 * 27 : 32 * 32)));
+    const int DS = S.solo ? S.geom.DSS : (S.use_s1 ? 32 * s1_nj(S.D) : (S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : (S.D <= 32 * 27 ? 32 * 27 : 32 * 32))));
     if (S.D > (S.big ? 1024 : 32 * 27)) {
         set_error("bdrt_sampler_create: D = %d > %d not supported", S.D, S.big ? 1024 : 864); bdrt_sampler_destroy(s); return nullptr;
     }
@@ -1925,7 +1927,10 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     static LdsAttrCache attr_cache;
     const hipError_t ae = attr_cache.ensure(S.lds_bytes, [&]() {
-        const void *fns[17] = {(const void *)nuts_kernel<11, 2, 2>, (const void *)nuts_kernel<16, 2, 2>,
+        const void *fns[24] = {(const void *)nuts_kernel<4, 2, 2>, (const void *)nuts_kernel<6, 2, 2>, (const void *)nuts_kernel<7, 2, 2>,
+                               (const void *)nuts_kernel<4, 2, 0>, (const void *)nuts_kernel<6, 2, 0>, (const void *)nuts_kernel<7, 2, 0>,
+                               (const void *)nuts_kernel<6, 2, 1>,
+                               (const void *)nuts_kernel<11, 2, 2>, (const void *)nuts_kernel<16, 2, 2>,
                                (const void *)nuts_kernel<11, 2, 1>, (const void *)nuts_kernel<16, 2, 1>,
                                (const void *)nuts_kernel<11, 1>, (const void *)nuts_kernel<11, 0>,
                                (const void *)nuts_kernel<16, 1>, (const void *)nuts_kernel<16, 0>,
@@ -1938,7 +1943,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
             e = hipFuncSetAttribute((const void *)nuts_solo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)nuts_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
-        for (int i = 0; i < 17 && e == hipSuccess; ++i)
+        for (int i = 0; i < 24 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         return e;
     });
@@ -2012,18 +2017,16 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             else
                 hipLaunchKernelGGL(nuts_solo_kernel<2>, dim3(S.n_solo), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
         }
-        else if (S.use_s1 && S.prob->dev.toepA == 2 && S.D <= 32 * 11)
-            hipLaunchKernelGGL((nuts_kernel<11, 2, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
-        else if (S.use_s1 && S.prob->dev.toepA == 2)
-            hipLaunchKernelGGL((nuts_kernel<16, 2, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
-        else if (S.use_s1 && S.prob->dev.toepA && S.D <= 32 * 11)
-            hipLaunchKernelGGL((nuts_kernel<11, 2, 1>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
-        else if (S.use_s1 && S.prob->dev.toepA)
-            hipLaunchKernelGGL((nuts_kernel<16, 2, 1>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
-        else if (S.use_s1 && S.D <= 32 * 11)
-            hipLaunchKernelGGL((nuts_kernel<11, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
-        else if (S.use_s1)
-            hipLaunchKernelGGL((nuts_kernel<16, 2>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
+        else if (S.use_s1) {
+            const int nj = S.args.ds / 32, ta = S.prob->dev.toepA;
+#define BDRT_S1_NUTS(NJ_, TA_) hipLaunchKernelGGL((nuts_kernel<NJ_, 2, TA_>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args)
+            if (nj == 4) { if (ta == 2) BDRT_S1_NUTS(4, 2); else BDRT_S1_NUTS(4, 0); }
+            else if (nj == 6) { if (ta == 2) BDRT_S1_NUTS(6, 2); else if (ta == 1) BDRT_S1_NUTS(6, 1); else BDRT_S1_NUTS(6, 0); }
+            else if (nj == 7) { if (ta == 2) BDRT_S1_NUTS(7, 2); else BDRT_S1_NUTS(7, 0); }
+            else if (nj == 11) { if (ta == 2) BDRT_S1_NUTS(11, 2); else if (ta == 1) BDRT_S1_NUTS(11, 1); else BDRT_S1_NUTS(11, 0); }
+            else { if (ta == 2) BDRT_S1_NUTS(16, 2); else if (ta == 1) BDRT_S1_NUTS(16, 1); else BDRT_S1_NUTS(16, 0); }
+#undef BDRT_S1_NUTS
+        }
         else if (S.s1_hbm && S.D <= 32 * 11)
             hipLaunchKernelGGL((nuts_kernel<11, 3>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
         else if (S.s1_hbm)

@@ -156,6 +156,10 @@ constexpr int WIN = UK + NTAP - 1;        // 22 values feed the 17-tap convoluti
 //     so the result does not depend on their order.
 // Lane l of a wave holds row i = l & 15, reduction index kq = l >> 4 of the A operand, column l & 15 of the B operand.
 // rows of the A x / g region Zh; leading zeros of a part of the generator table; first row of the imaginary part in Zh
+// the instantiation for K basis functions; the sampler's elements per lane for D parameters (D = 2 K + 9 without outlier
+// parameters: s1_ku(K) <= the KU that goes with s1_nj(D), bdrt_nuts.hip)
+__host__ __device__ inline int s1_ku(int K) { return K <= 64 ? 2 : (K <= 96 ? 3 : (K <= 128 ? 4 : 6)); }
+__host__ __device__ inline int s1_nj(int D) { return D <= 32 * 4 ? 4 : (D <= 32 * 6 ? 6 : (D <= 32 * 7 ? 7 : (D <= 32 * 11 ? 11 : 16))); }
 __host__ __device__ inline int s1_zrows(const DevProblem &P) { return P.toepA == 2 ? P.zrows : 16 * P.blk[0].tilesA; }
 template <int TA> __device__ __forceinline__ constexpr int toep_pad() { return TA == 2 ? 16 : 8; }
 template <int TA> __device__ __forceinline__ int toep_im_row(int nf) { return TA == 2 ? (nf + 3) & ~3 : nf; }
@@ -656,7 +660,9 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `after_x_ready` runs right after the first barrier (X of all 16 chains published): the sampler reads the chains' activity
 // flags there -- every wave has finished its previous round by then -- instead of voting at a barrier of its own.
 // TA: DevProblem::toepA (0, 1: toep_gemm, 2: toep_gemm_gen) -- the caller has run s1_toep_init once in this kernel.
-template <bool LDSIO, int LPC = 32, class Hook = NoHook, class Hook1 = NoHook, int TA = 0>
+// KU: basis functions per lane of a half-wave, K <= 32 KU (2, 3, 4 or 6): every per-lane loop over k is unrolled KU (LPC = 64: KU / 2)
+// times whatever K is, so a short basis pays for a long one unless the caller picks the instantiation by K (s1_ku)
+template <bool LDSIO, int LPC = 32, class Hook = NoHook, class Hook1 = NoHook, int TA = 0, int KU = 6>
 __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, double *smem, Hook before_backward = Hook(),
                                          Hook1 after_x_ready = Hook1())
 {
@@ -667,7 +673,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     __asm__ volatile("" : "+v"(tid));
     // LPC lanes own one chain: 32 (half-wave, 512 threads, 2 waves per SIMD) or 64 (wave, 1024 threads, 4 waves per SIMD,
     // half the per-lane work and registers)
-    constexpr int UKV = 192 / LPC, UNV = 128 / LPC, WINV = UKV + NTAP - 1, NWV = 16 * LPC / 64;     // K <= 192, Nf <= 128
+    constexpr int UKV = 32 * KU / LPC, UNV = 128 / LPC, WINV = UKV + NTAP - 1, NWV = 16 * LPC / 64;     // K <= 32 KU, Nf <= 128
     constexpr int GPFV = LPC == 32 ? 7 : 3;
     const int lane = tid & 63, wave = tid >> 6;
     const int c = tid / LPC;                               // chain owned by this group of LPC lanes
