@@ -390,7 +390,7 @@ __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restr
     io.prof = nullptr;
     if (MODE == 4) { s1_toep_init(P, smem); logp_grad_tile_s1<false, 32, NoHook, NoHook, 1, KU>(P, io, smem); }
     else if (MODE == 6) { s1_toep_init(P, smem); logp_grad_tile_s1<false, 32, NoHook, NoHook, 2, KU>(P, io, smem); }
-    else if (MODE == 3) logp_grad_tile_hw(P, io, smem);
+    else if (MODE == 3) logp_grad_tile_hw<KU>(P, io, smem);
     else if (MODE == 2) logp_grad_tile_s1<false, 32, NoHook, NoHook, 0, KU>(P, io, smem);
     else if (MODE == 1) logp_grad_tile<true>(P, io, smem);
     else logp_grad_tile<false>(P, io, smem);
@@ -435,13 +435,14 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
     }
     static LdsAttrCache attr_cache;
     BDRT_HIP(attr_cache.ensure(p->lds_bytes, [&]() {
-        const void *fns[15] = {(const void *)logp_grad_kernel<0>, (const void *)logp_grad_kernel<1>, (const void *)logp_grad_kernel<2>,
+        const void *fns[17] = {(const void *)logp_grad_kernel<0>, (const void *)logp_grad_kernel<1>, (const void *)logp_grad_kernel<2>,
                                (const void *)logp_grad_kernel_wide, (const void *)logp_grad_kernel<3>, (const void *)logp_grad_kernel<4>,
                                (const void *)logp_grad_kernel<6>, (const void *)logp_grad_kernel<2, 2>, (const void *)logp_grad_kernel<2, 3>,
                                (const void *)logp_grad_kernel<2, 4>, (const void *)logp_grad_kernel<4, 3>, (const void *)logp_grad_kernel<6, 2>,
-                               (const void *)logp_grad_kernel<6, 3>, (const void *)logp_grad_kernel<6, 4>, (const void *)logp_grad_kernel<4, 6>};
+                               (const void *)logp_grad_kernel<6, 3>, (const void *)logp_grad_kernel<6, 4>, (const void *)logp_grad_kernel<3, 2>,
+                               (const void *)logp_grad_kernel<3, 3>, (const void *)logp_grad_kernel<3, 4>};
         hipError_t e = hipSuccess;
-        for (int i = 0; i < 15 && e == hipSuccess; ++i)
+        for (int i = 0; i < 17 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
         return e;
     }));
@@ -450,9 +451,15 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
     if (p->dev.fast_s1 && wide && p->dev.nf <= 128)
         hipLaunchKernelGGL(logp_grad_kernel_wide, dim3(grid), dim3(1024), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
                            d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
-    else if (p->dev.fast_hw)
-        hipLaunchKernelGGL(logp_grad_kernel<3>, dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
-                           d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
+    else if (p->dev.fast_hw) {
+        static const bool ku6 = getenv("BDRT_S1_KU") && atoi(getenv("BDRT_S1_KU")) == 6;
+        const int ku = ku6 ? 6 : s1_ku(hw_kmax(p->dev));
+#define BDRT_HW_LAUNCH(KU_)                                                                                                             \
+        hipLaunchKernelGGL((logp_grad_kernel<3, KU_>), dim3(grid), dim3(NT), p->lds_bytes, stream, (const DevProblem *)p->d_dev, d_theta, \
+                           d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig)
+        if (ku == 2) BDRT_HW_LAUNCH(2); else if (ku == 3) BDRT_HW_LAUNCH(3); else if (ku == 4) BDRT_HW_LAUNCH(4); else BDRT_HW_LAUNCH(6);
+#undef BDRT_HW_LAUNCH
+    }
     else if (p->dev.fast_s1) {
         // the instantiation by the basis length (BDRT_S1_KU=6: the one for K <= 192 whatever K is)
         static const bool ku6 = getenv("BDRT_S1_KU") && atoi(getenv("BDRT_S1_KU")) == 6;

@@ -116,8 +116,10 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     double *V = a.vecs + (size_t)wg * V_COUNT * NC * DS;
     auto row = [&](int v) -> double * { return V + ((size_t)v * NC + c) * DS; };   // this chain's row of vector v
 
-    static_assert(!TA || MODE == 2, "the generator table belongs to the S1 tile");
-    if (TA) s1_toep_init(P, smem);
+    // (MODE 3 / 4: TA carries the basis functions per lane of the evaluator's instantiation, 0 = 6)
+    static_assert(!TA || MODE >= 2, "the generator table belongs to the S1 tile");
+    constexpr int KUX = TA == 0 ? 6 : TA;
+    if (TA && MODE == 2) s1_toep_init(P, smem);
     if (tid < NC) {
         const int u = su[col_slot(tid)];
         if (u >= 0) sts[tid] = a.states[u];
@@ -243,8 +245,8 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             logp_grad_tile_s1<true, 32, decltype(early_state), decltype(read_flags), TA, KU>(P, io, smem, early_state, read_flags);
             if constexpr (!EARLY) load_state();
         }
-        else if (MODE == 3) { logp_grad_tile_s1<false>(P, io, smem); load_state(); }
-        else if (MODE == 4) { logp_grad_tile_hw(P, io, smem); load_state(); }
+        else if (MODE == 3) { logp_grad_tile_s1<false, 32, NoHook, NoHook, 0, KUX>(P, io, smem); load_state(); }
+        else if (MODE == 4) { logp_grad_tile_hw<KUX>(P, io, smem); load_state(); }
         else { logp_grad_tile<MODE == 1>(P, io, smem); load_state(); }
         if (io.prof && tid == 0) tnp = clock64();
         BDRT_WAVE_PROF(17);
@@ -1927,7 +1929,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     static LdsAttrCache attr_cache;
     const hipError_t ae = attr_cache.ensure(S.lds_bytes, [&]() {
-        const void *fns[24] = {(const void *)nuts_kernel<4, 2, 2>, (const void *)nuts_kernel<6, 2, 2>, (const void *)nuts_kernel<7, 2, 2>,
+        const void *fns[34] = {(const void *)nuts_kernel<4, 2, 2>, (const void *)nuts_kernel<6, 2, 2>, (const void *)nuts_kernel<7, 2, 2>,
                                (const void *)nuts_kernel<4, 2, 0>, (const void *)nuts_kernel<6, 2, 0>, (const void *)nuts_kernel<7, 2, 0>,
                                (const void *)nuts_kernel<6, 2, 1>,
                                (const void *)nuts_kernel<11, 2, 2>, (const void *)nuts_kernel<16, 2, 2>,
@@ -1937,13 +1939,17 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
                                (const void *)nuts_kernel<27, 1>, (const void *)nuts_kernel<27, 0>,
                                (const void *)nuts_kernel<11, 2>, (const void *)nuts_kernel<16, 2>,
                                (const void *)nuts_kernel<11, 3>, (const void *)nuts_kernel<16, 3>,
-                               (const void *)nuts_kernel<11, 4>, (const void *)nuts_kernel<16, 4>, (const void *)nuts_kernel<27, 4>};
+                               (const void *)nuts_kernel<11, 4>, (const void *)nuts_kernel<16, 4>, (const void *)nuts_kernel<27, 4>,
+                               (const void *)nuts_kernel<11, 3, 3>, (const void *)nuts_kernel<16, 3, 3>, (const void *)nuts_kernel<11, 3, 4>,
+                               (const void *)nuts_kernel<16, 3, 4>, (const void *)nuts_kernel<11, 4, 3>, (const void *)nuts_kernel<16, 4, 3>,
+                               (const void *)nuts_kernel<27, 4, 3>, (const void *)nuts_kernel<11, 4, 4>, (const void *)nuts_kernel<16, 4, 4>,
+                               (const void *)nuts_kernel<27, 4, 4>};
         hipError_t e = hipFuncSetAttribute((const void *)nuts_solo_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)nuts_solo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)nuts_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
-        for (int i = 0; i < 24 && e == hipSuccess; ++i)
+        for (int i = 0; i < 34 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         return e;
     });
@@ -2027,16 +2033,21 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             else { if (ta == 2) BDRT_S1_NUTS(16, 2); else if (ta == 1) BDRT_S1_NUTS(16, 1); else BDRT_S1_NUTS(16, 0); }
 #undef BDRT_S1_NUTS
         }
-        else if (S.s1_hbm && S.D <= 32 * 11)
-            hipLaunchKernelGGL((nuts_kernel<11, 3>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
-        else if (S.s1_hbm)
-            hipLaunchKernelGGL((nuts_kernel<16, 3>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
-        else if (S.hw && S.D <= 32 * 11)
-            hipLaunchKernelGGL((nuts_kernel<11, 4>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
-        else if (S.hw && S.D <= 32 * 16)
-            hipLaunchKernelGGL((nuts_kernel<16, 4>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
-        else if (S.hw)
-            hipLaunchKernelGGL((nuts_kernel<27, 4>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
+        else if (S.s1_hbm || S.hw) {
+            // the evaluator's instantiation by the longest basis (3, 4 or 6 basis functions per lane)
+            const int kmax = S.hw ? hw_kmax(S.prob->dev) : S.prob->dev.blk[0].K;
+            static const bool ku6 = getenv("BDRT_S1_KU") && atoi(getenv("BDRT_S1_KU")) == 6;     // (measurements: the K <= 192 instantiation)
+            const int ku = ku6 ? 0 : (kmax <= 96 ? 3 : (kmax <= 128 ? 4 : 0));
+            const int nj = S.D <= 32 * 11 ? 11 : (S.D <= 32 * 16 ? 16 : 27);
+#define BDRT_X_NUTS(NJ_, MODE_, KU_) hipLaunchKernelGGL((nuts_kernel<NJ_, MODE_, KU_>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args)
+#define BDRT_X_KU(NJ_, MODE_) do { if (ku == 3) BDRT_X_NUTS(NJ_, MODE_, 3); else if (ku == 4) BDRT_X_NUTS(NJ_, MODE_, 4); else BDRT_X_NUTS(NJ_, MODE_, 0); } while (0)
+            if (S.s1_hbm) { if (nj == 11) BDRT_X_KU(11, 3); else BDRT_X_KU(16, 3); }
+            else if (nj == 11) BDRT_X_KU(11, 4);
+            else if (nj == 16) BDRT_X_KU(16, 4);
+            else BDRT_X_KU(27, 4);
+#undef BDRT_X_KU
+#undef BDRT_X_NUTS
+        }
         else if (S.D <= 32 * 11) BDRT_LAUNCH_NUTS(11);
         else if (S.D <= 32 * 16) BDRT_LAUNCH_NUTS(16);
         else BDRT_LAUNCH_NUTS(27);

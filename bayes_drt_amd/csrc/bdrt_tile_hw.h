@@ -21,12 +21,22 @@ __host__ __device__ inline size_t hw_lds_doubles(const DevProblem &P)
     return (size_t)NC * (P.XR + 16 * P.blk[0].tilesA * (1 + P.npar)) + (size_t)2 * NC * RW;
 }
 
-// All threads of the workgroup must call.  Ends with a __syncthreads().
+// the longest basis of the problem's blocks (what picks the instantiation: bdrt_tile_s1.h::s1_ku)
+__host__ __device__ inline int hw_kmax(const DevProblem &P)
+{
+    int k = 0;
+    for (int b = 0; b < P.nblocks; ++b) k = P.blk[b].K > k ? P.blk[b].K : k;
+    return k;
+}
+
+// All threads of the workgroup must call.  Ends with a __syncthreads().  KU: basis functions per lane (every block's K <= 32 KU),
+// as in logp_grad_tile_s1.
+template <int KU = 6>
 __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, double *smem)
 {
     int tid = threadIdx.x;
     __asm__ volatile("" : "+v"(tid));                      // see bdrt_tile_s1.h: keeps index arithmetic out of the caller's loop
-    constexpr int LPC = 32, UKV = 6, UNV = 4, WINV = UKV + NTAP - 1, NWV = 8, GPFV = 7;      // K <= 192, Nf <= 128
+    constexpr int LPC = 32, UKV = KU, UNV = 4, WINV = UKV + NTAP - 1, NWV = 8, GPFV = 7;      // K <= 32 KU, Nf <= 128
     const int lane = tid & 63, wave = tid >> 6;
     const int c = tid / LPC;
     const int l32 = tid % LPC, hb = lane & 32;

@@ -14,6 +14,8 @@ f, Z = d['data_freq'], d['data_Z'].copy()
 for i in (10, 40, 70):
     Z[i] *= 1.5
 bf = np.logspace(10, -6, 161)
+if '--default-basis' in sys.argv:            # the package default: the basis on the measurement frequencies (K = 81 per distribution)
+    bf = None
 dists = {'DRT': {'kernel': 'DRT'},
          'TP-DDT': {'kernel': 'DDT', 'symmetry': 'planar', 'bc': 'transmissive', 'dist_type': 'parallel', 'x_scale': 0.8}}
 if '--series-outliers' in sys.argv:          # single DRT with the outlier error model: D = 2*161 + 9 + 2*81 = 493
