@@ -103,7 +103,7 @@ int bdrt_num_params(const bdrt_problem *p);               /* D: length of the un
 /* diagnostics: which 16-column tile evaluator bdrt_logp_grad / the sampler use for this problem.  0 dense L (MFMA), 1 banded
  * Toeplitz L (generic tile), 2 one-block fast tile with the A fragments streamed from L2, 3 general half-wave tile (several
  * blocks), 4 one-block fast tile with the A operands from an LDS-resident Toeplitz generator table (A_re, A_im exactly
- * Toeplitz, nf = 80..82, K = 80..82 or 160..162; env BDRT_STREAM_A=1 at bdrt_problem_create forces 2), 5 a problem beyond the
+ * Toeplitz -- equal log spacing of the frequencies and of tau --, nf, K >= 32; env BDRT_STREAM_A=1 at bdrt_problem_create forces 2), 5 a problem beyond the
  * LDS budget of all of these (more than 128 frequencies, ~200 basis functions per distribution ...): the streamed evaluator, one
  * workgroup per point, vectors in an HBM workspace -- slow but working, the reference takes any grid (inversion.py:2127-2209);
  * env BDRT_BIG=1 at bdrt_problem_create forces it */
