@@ -819,8 +819,8 @@ class Inverter:
     def _map_extra_starts(self, n_starts, init_from_ridge, model_str, frequencies, Z, nonneg, outliers, inductance_scale, ridge_kw):
         """Further MAP starting points next to the designated one (see `fit`).  The hierarchical posterior has poor local
         maxima -- everything explained as noise, or a huge Z_hat with a proportionally huge error -- that a single random
-        start reaches on sparse or outlier-ridden spectra; the extra starts cost no wall time, the batch runs in
-        lock-step on the GPU."""
+        start reaches on sparse or outlier-ridden spectra; the starts run as one batch in lock-step on the GPU, the
+        ridge candidate costs its (shortened) ridge solve."""
         if n_starts is None and os.environ.get('BDRT_MAP_SINGLE_START'):
             n_starts = 1
         if n_starts == 1:
@@ -834,8 +834,13 @@ class Inverter:
             # Bayesian fit would not touch: put them back
             saved = {k: getattr(self, k) for k in self._RIDGE_SIDE_EFFECTS if hasattr(self, k)}
             try:
-                extra.append(self._get_init_from_ridge(frequencies, Z, 'optimize', nonneg=nonneg, outliers=outliers,
-                                                       inductance_scale=inductance_scale, ridge_kw=ridge_kw))
+                # (three hyper-lambda iterations, not the twenty of a ridge fit in its own right: this is a starting point, and
+                #  the full ridge solve -- 19 ms at K = 81, 57 ms at K = 161, one workgroup -- was 40 % of the whole MAP fit)
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    extra.append(self._get_init_from_ridge(frequencies, Z, 'optimize', nonneg=nonneg, outliers=outliers,
+                                                           inductance_scale=inductance_scale,
+                                                           ridge_kw=dict({'max_iter': int(os.environ.get('BDRT_RIDGE_START_ITER', 3))}, **ridge_kw)))
             except Exception as e:                       # the ridge candidate is optional: the random start remains
                 warnings.warn('ridge starting point not available (%s): MAP from the random start only' % e)
             finally:
