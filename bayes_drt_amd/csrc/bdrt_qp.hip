@@ -16,6 +16,8 @@
 // nature: one wavefront does them with wave-level synchronisation only (a barrier per unknown would cost more than the
 // arithmetic).
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -24,6 +26,14 @@
 namespace bdrt {
 
 constexpr int QP_NT = 512;
+// BDRT_QP_PROF=1: core-clock cycles of workgroup 0's phases (form KKT, factor, triangular solves, everything else), printed per call
+__device__ long long g_qp_prof[8];
+__device__ int g_qp_prof_on;
+struct QpProf {
+    long long t; bool on;
+    __device__ QpProf() : t(0), on(g_qp_prof_on && blockIdx.x == 0 && threadIdx.x == 0) { if (on) t = clock64(); }
+    __device__ void mark(int k) { if (on) { const long long n = clock64(); g_qp_prof[k] += n - t; t = n; } }
+};
 constexpr int QP_NVEC = 14;          // x, s, z, rd, rhs, dx, ds, dz, dsa, dza, Px, lo, bounded, rz
 
 __device__ __forceinline__ void qp_wave_sync()
@@ -68,56 +78,199 @@ __device__ inline double block_min(double v, double *red)
 }
 
 // column-major packed lower triangle: element (i, j), i >= j
-__device__ __forceinline__ size_t cidx(int i, int j, int n) { return (size_t)j * n - (size_t)j * (j - 1) / 2 + (i - j); }
+__device__ __forceinline__ int cidx(int i, int j, int n) { return j * n - ((j * (j - 1)) >> 1) + (i - j); }      // (n < 46 000: 32-bit index arithmetic)
 
 // In-place Cholesky of the packed lower triangle; diag[j] receives L(j,j) (M(j,j) keeps the pivot).  Returns false
-// (uniformly) when a pivot is not positive.  All threads of the workgroup must call.
-__device__ inline bool chol_packed(double *M, double *diag, int n)
+// (uniformly) when a pivot is not positive.  All threads of the workgroup must call.  Right-looking in blocks of 16 columns
+// (round 4; round 2's form updated the whole trailing triangle after every column -- two workgroup barriers and a pass over up to
+// n^2 / 2 LDS cells per column: 570 k cycles at n = 163, 60 % of an interior-point iteration):
+//   (a) the 16 x 16 diagonal block by wavefront 0 on a register copy, lane r = row r; the scaled column reaches the other lanes
+//       through a 16-double LDS buffer (one round trip per column);
+//   (b) the rows below by forward substitution against the block, one row per thread;
+//   (c) the trailing triangle on v_mfma_f64_16x16x4 tiles, operands and accumulators straight from the packed triangle.
+// Three barriers per block.  `scr`: 32 doubles of scratch.
+// LDSM: M is in LDS -- addressed as such (through a generic pointer every access is a flat load: several times the latency)
+template <bool LDSM>
+__device__ __noinline__ bool chol_packed(double *M, double *diag, int n, double *scr)
 {
-    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-    for (int j = 0; j < n; ++j) {
-        const double d = M[cidx(j, j, n)];
-        if (!(d > 0.0) || !isfinite(d)) return false;                 // same value in every thread
-        const double dj = sqrt(d), inv = 1.0 / dj;
-        double *colj = M + cidx(j, j, n);                             // colj[i - j] = M(i, j)
-        for (int i = j + 1 + tid; i < n; i += QP_NT) colj[i - j] *= inv;
-        if (tid == 0) diag[j] = dj;
-        __syncthreads();
-        for (int k = j + 1 + ty; k < n; k += QP_NT / 32) {
-            const double lkj = colj[k - j];
-            double *colk = M + cidx(k, k, n);
-            for (int i = k + tx; i < n; i += 32) colk[i - k] -= colj[i - j] * lkj;
+    typedef __attribute__((address_space(3))) double *lds_dptr;
+    auto LD = [&](int idx) -> double { if constexpr (LDSM) return ((lds_dptr)M)[idx]; else return M[idx]; };
+    auto ST = [&](int idx, double val) { if constexpr (LDSM) ((lds_dptr)M)[idx] = val; else M[idx] = val; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_bad;
+    __shared__ double s_inv[16];
+    __shared__ double s_tile[16 * 17];
+    int *bad = &s_bad;
+    if (tid == 0) *bad = 0;
+    __syncthreads();
+    QpProf pq;
+    for (int j0 = 0; j0 < n; j0 += 16) {
+        const int jb = min(16, n - j0), m = n - j0 - jb;
+        pq.mark(7);
+        // (a) the block in a 16 x 17 LDS tile, thread (r, k) of the first 256 owns element (r, k), k <= r.  Column c: every thread
+        //     reads the pivot and its two column-c entries as they stand, scales them itself (the columns stay unscaled in the
+        //     tile until the end: nobody writes what another thread reads in the same step) and updates its own element --
+        //     one barrier per column.
+        {
+            const int r = tid >> 4, k = tid & 15;
+            const bool mine = tid < 256 && r < jb && k <= r;
+            if (mine) s_tile[r * 17 + k] = LD(cidx(j0 + r, j0 + k, n));
+            __syncthreads();
+            bool ok = true;
+            double mineval = mine ? s_tile[r * 17 + k] : 0.0;
+            for (int c = 0; c < jb; ++c) {
+                const double d = s_tile[c * 17 + c];
+                ok = ok && d > 0.0 && isfinite(d);
+                // 1 / sqrt(d): hardware estimate + two Newton steps
+                double inv = __builtin_amdgcn_rsq(d);
+                inv = inv * (1.5 - 0.5 * d * inv * inv);
+                inv = inv * (1.5 - 0.5 * d * inv * inv);
+                if (tid == c) { diag[j0 + c] = d * inv; s_inv[c] = inv; }
+                if (mine && k > c) {
+                    const double lr = s_tile[r * 17 + c] * inv, lk = s_tile[k * 17 + c] * inv;
+                    mineval -= lr * lk;
+                    s_tile[r * 17 + k] = mineval;
+                }
+                __syncthreads();
+            }
+            if (!ok) { if (tid == 0) *bad = 1; }
+            else if (mine) ST(cidx(j0 + r, j0 + k, n), k < r ? mineval * s_inv[k] : mineval);     // (the diagonal keeps the pivot)
         }
         __syncthreads();
+        pq.mark(5);
+        if (*bad) return false;
+        if (m > 0) {
+            // (b) x_c = (a_c - sum_{k < c} x_k L(c, k)) / L(c, c), one row per thread (jb = 16 here)
+            for (int i = j0 + 16 + tid; i < n; i += QP_NT) {
+                double x[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) x[c] = LD(cidx(i, j0 + c, n));
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    double t = x[c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) t -= x[k] * LD(cidx(j0 + c, j0 + k, n));
+                    x[c] = t * s_inv[c];
+                    __builtin_amdgcn_sched_barrier(0);      // one row of the block at a time (else all 120 operands are requested up front)
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) ST(cidx(i, j0 + c, n), x[c]);
+            }
+            __syncthreads();
+            pq.mark(6);
+            // (c) C(i, k) -= sum_c X(i, c) X(k, c) on the tiles of the lower triangle of the trailing part
+            const int r0 = j0 + 16, mb = (m + 15) >> 4, ntile = mb * (mb + 1) / 2;
+            const int col = lane & 15, kq = lane >> 4;
+            for (int t = wave; t < ntile; t += QP_NT / 64) {
+                int I = (int)((__fsqrt_rn((float)(8 * t + 1)) - 1.0f) * 0.5f);
+                while ((I + 1) * (I + 2) / 2 <= t) ++I;
+                while (I * (I + 1) / 2 > t) --I;
+                const int Jc = t - I * (I + 1) / 2;
+                const int R0 = r0 + 16 * I, C0 = r0 + 16 * Jc;
+                const int ia = R0 + col, ib = C0 + col;                     // operand rows of this lane
+                double xa[4], xb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xa[u] = ia < n ? LD(cidx(ia, j0 + 4 * u + kq, n)) : 0.0;
+                    xb[u] = ib < n ? LD(cidx(ib, j0 + 4 * u + kq, n)) : 0.0;
+                }
+                d4 acc;
+                bool own[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int ri = R0 + kq + 4 * rr, ci = C0 + col;
+                    own[rr] = ri < n && ci <= ri;
+                    acc[rr] = own[rr] ? LD(cidx(ri, ci, n)) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = mfma_f64(-xa[u], xb[u], acc);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    if (own[rr]) ST(cidx(R0 + kq + 4 * rr, C0 + col, n), acc[rr]);
+            }
+            __syncthreads();
+        }
     }
     return true;
 }
 
-// v <- (L L^T)^-1 v by wavefront 0 (L strictly-lower part in M, diagonal in diag); ends with a workgroup barrier
-__device__ inline void chol_solve_wave(const double *M, const double *diag, int n, double *v)
+// v <- (L L^T)^-1 v (L strictly-lower part in M, diagonal in diag); ends with a workgroup barrier.  Blocked by 16 unknowns:
+// the 16 x 16 triangle of a block by 16 lanes of wavefront 0 with the block's right-hand side in registers (the unknown just found
+// goes to the other lanes through v_readlane), the rest of the right-hand side by the whole workgroup -- forward one row per
+// thread, backward 32 threads per column.  (Round 2's form did both substitutions with one wavefront, two wave-level exchanges and a
+// division per unknown: about 40 % of an interior-point iteration at n = 163.)  rd: 1 / diag, scratch of n doubles; tb: 16 doubles.
+template <bool LDSM>
+__device__ __noinline__ void chol_solve_blocked(const double *M, const double *diag, int n, double *v, double *rd, double *tb)
 {
+    typedef const __attribute__((address_space(3))) double *lds_cdptr;
+    auto LD = [&](int idx) -> double { if constexpr (LDSM) return ((lds_cdptr)M)[idx]; else return M[idx]; };
     const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < 64) {
-        for (int j = 0; j < n; ++j) {                                 // forward: L y = v (column oriented)
-            qp_wave_sync();
-            const double yj = v[j] / diag[j];
-            qp_wave_sync();
-            if (lane == 0) v[j] = yj;
-            const double *colj = M + cidx(j, j, n);
-            for (int i = j + 1 + lane; i < n; i += 64) v[i] -= colj[i - j] * yj;
-        }
-        for (int j = n - 1; j >= 0; --j) {                            // backward: L^T x = y (dot with column j)
-            qp_wave_sync();
-            const double *colj = M + cidx(j, j, n);
-            double t = 0.0;
-            for (int i = j + 1 + lane; i < n; i += 64) t += colj[i - j] * v[i];
-            t = wave_sum64(t);
-            const double xj = (v[j] - t) / diag[j];
-            qp_wave_sync();
-            if (lane == 0) v[j] = xj;
-        }
-    }
+    for (int i = tid; i < n; i += QP_NT) rd[i] = 1.0 / diag[i];
     __syncthreads();
+    const int nb = (n + 15) / 16;
+    auto bcast = [](double y, int c) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y), c), __builtin_amdgcn_readlane(__double2loint(y), c)); };
+    for (int J = 0; J < nb; ++J) {                                      // forward: L y = v
+        const int j0 = 16 * J, jb = min(16, n - j0);
+        if (tid < 64) {
+            // lane r: row j0 + r of the block's triangle in registers (zeros outside it), its own reciprocal pivot
+            const int r = lane & 15, i = j0 + r;
+            const bool in = r < jb;
+            double Lr[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Lr[c] = (in && c < r) ? LD(cidx(i, j0 + c, n)) : 0.0;
+            const double rdo = in ? rd[i] : 1.0;
+            double t = in ? v[i] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const double yc = bcast(t * rdo, c);
+                t = r == c ? yc : t - Lr[c] * yc;
+            }
+            if (lane < jb) v[i] = t;
+        }
+        __syncthreads();
+        for (int i = j0 + jb + tid; i < n; i += QP_NT) {
+            // (jb = 16 here: only the last block is shorter, and nothing lies below it; all sixteen requests go out together)
+            double Lrow[16], yv[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { Lrow[c] = LD(cidx(i, j0 + c, n)); yv[c] = v[j0 + c]; }
+            double t = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t += Lrow[c] * yv[c];
+            v[i] -= t;
+        }
+        __syncthreads();
+    }
+    for (int J = nb - 1; J >= 0; --J) {                                 // backward: L^T x = y
+        const int j0 = 16 * J, jb = min(16, n - j0);
+        {
+            const int c = tid >> 5, l32 = tid & 31;                     // 32 threads per column of the block
+            double t = 0.0;
+            if (c < jb) {
+                const int cj = cidx(j0 + c, j0 + c, n);                 // LD(cj + i - j) = L(i, j)
+                for (int i = j0 + jb + l32; i < n; i += 32) t += LD(cj + i - (j0 + c)) * v[i];
+            }
+            t += __shfl_xor(t, 16); t += __shfl_xor(t, 8); t += __shfl_xor(t, 4); t += __shfl_xor(t, 2); t += __shfl_xor(t, 1);
+            if (l32 == 0 && c < 16) tb[c] = t;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lane r: column j0 + r of the block's triangle (row r of its transpose)
+            const int r = lane & 15, j = j0 + r;
+            const bool in = r < jb;
+            double Lc[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Lc[c] = (in && c > r && c < jb) ? LD(cidx(j0 + c, j, n)) : 0.0;
+            const double rdo = in ? rd[j] : 1.0;
+            double u = in ? v[j] - tb[r] : 0.0;
+#pragma unroll
+            for (int c = 15; c >= 0; --c) {
+                const double xc = bcast(u * rdo, c);
+                u = r == c ? xc : u - Lc[c] * xc;
+            }
+            if (lane < jb) v[j] = u;
+        }
+        __syncthreads();
+    }
 }
 
 // One box-constrained QP by the calling workgroup: P [n x n] and q [n] in global memory, the solution is left in sh[0..n)
@@ -167,11 +320,13 @@ __device__ inline int qp_box_solve(const double *__restrict__ P, const double *_
         __syncthreads();
     };
     // factor sym(P) + diag(dgv[i]) (+ reg I when only semi-definite); dgv: unit = 1 on bounded variables, else z/s
+    QpProf pf;
     auto factor = [&](bool unit) -> bool {
         double reg = 0.0;
         bool ok = false;
         while (true) {
             __syncthreads();
+            pf.mark(3);
             for (int j = wave; j < n; j += QP_NT / 64) {              // one wavefront per column of the lower triangle
                 double *colj = M + cidx(j, j, n);
                 for (int i = j + lane; i < n; i += 64) {
@@ -181,8 +336,10 @@ __device__ inline int qp_box_solve(const double *__restrict__ P, const double *_
                 }
             }
             __syncthreads();
+            pf.mark(0);
             const double m00 = M[0] - reg;
-            ok = chol_packed(M, diag, n);
+            ok = chol_packed<LDSM>(M, diag, n, red);
+            pf.mark(1);
             if (ok) break;
             reg = reg == 0.0 ? 1e-14 * (1.0 + fabs(m00)) : reg * 100.0;
             if (!(reg <= 1e6)) break;                                  // (also leaves on NaN: non-finite input must not spin here)
@@ -194,7 +351,9 @@ __device__ inline int qp_box_solve(const double *__restrict__ P, const double *_
     if (!factor(true)) { *pobj_out = 0.0; return -3; }
     for (int i = tid; i < n; i += QP_NT) x[i] = -q[i] + (bd[i] != 0.0 ? lv[i] : 0.0);
     __syncthreads();
-    chol_solve_wave(M, diag, n, x);
+    pf.mark(3);
+    chol_solve_blocked<LDSM>(M, diag, n, x, rhs, red);
+    pf.mark(2);
     {
         double nrm2 = 0.0, mn = INFINITY, mx = INFINITY, dummy = 0.0, dummy2 = 0.0;
         for (int i = tid; i < n; i += QP_NT)
@@ -257,7 +416,9 @@ __device__ inline int qp_box_solve(const double *__restrict__ P, const double *_
                 dx[i] = rhs[i];
             }
             __syncthreads();
-            chol_solve_wave(M, diag, n, dx);
+            pf.mark(3);
+            chol_solve_blocked<LDSM>(M, diag, n, dx, Px, red);
+            pf.mark(2);
             for (int i = tid; i < n; i += QP_NT) {
                 if (bd[i] != 0.0) {
                     double rc = sigma_mu - s[i] * z[i];
@@ -305,6 +466,8 @@ __device__ inline int qp_box_solve(const double *__restrict__ P, const double *_
         if (xout) xout[i] = x[i];
     }
     block_sum3(pobj, d1, d2, red);
+    pf.mark(3);
+    if (pf.on) g_qp_prof[4] += it;
     *pobj_out = pobj;
     __syncthreads();
     return status < 0 ? status : it;
@@ -490,7 +653,7 @@ int bdrt_qp_box_batch(const double *P, const double *q, const double *lo, int n,
     const int np = (n + 1) & ~1;
     const size_t vec_bytes = ((size_t)(QP_NVEC + 1) * np + 32) * sizeof(double);      // + diag, reduction scratch
     const size_t msize = (size_t)n * (n + 1) / 2;
-    const bool in_lds = vec_bytes + msize * sizeof(double) <= 160 * 1024;
+    const bool in_lds = vec_bytes + msize * sizeof(double) <= 160 * 1024 - 2560;      // (2.5 KB of static LDS in chol_packed)
     const size_t lds = in_lds ? vec_bytes + msize * sizeof(double) : vec_bytes;
     if (lds > 160 * 1024) { set_error("bdrt_qp_box_batch: n = %d too large", n); return -2; }
     double *dP = nullptr, *dq = nullptr, *dlo = nullptr, *dx = nullptr, *dobj = nullptr, *dwork = nullptr;
@@ -556,7 +719,7 @@ int bdrt_ridge(const bdrt_ridge_options *opt, int nb, int ng, const double *G, c
     const int n = opt->n, K = opt->K, np = (n + 1) & ~1, mi = opt->max_iter;
     const size_t msize = (size_t)n * (n + 1) / 2;
     const size_t vec = (size_t)(QP_NVEC + 1) * np + 32, extra = (size_t)6 * np + 32 + 2;
-    const bool in_lds = (vec + msize + extra) * sizeof(double) <= 160 * 1024;
+    const bool in_lds = (vec + msize + extra) * sizeof(double) <= 160 * 1024 - 2560;
     const size_t lds = (vec + (in_lds ? msize : 0) + extra) * sizeof(double);
     if (lds > 160 * 1024) { set_error("bdrt_ridge: n = %d too large", n); return -2; }
     std::vector<void *> owned;
@@ -610,10 +773,18 @@ int bdrt_ridge(const bdrt_ridge_options *opt, int nb, int ng, const double *G, c
             e = hipFuncSetAttribute((const void *)ridge_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         return e;
     }));
+    { const int on = getenv("BDRT_QP_PROF") ? 1 : 0; static int was = 0; if (on != was) { RG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_qp_prof_on), &on, sizeof(on))); was = on; } }
     if (in_lds) hipLaunchKernelGGL(ridge_kernel<true>, dim3(nb), dim3(QP_NT), lds, 0, a);
     else hipLaunchKernelGGL(ridge_kernel<false>, dim3(nb), dim3(QP_NT), lds, 0, a);
     RG_HIP(hipGetLastError());
     RG_HIP(hipDeviceSynchronize());
+    if (getenv("BDRT_QP_PROF")) {
+        long long h[8] = {0}, z[8] = {0};
+        RG_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_qp_prof), sizeof(h)));
+        RG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_qp_prof), z, sizeof(z)));
+        fprintf(stderr, "[bdrt qp prof] n %d, fit 0: %lld interior-point iterations; core cycles: form KKT %lld, factor %lld (diagonal blocks %lld, panels %lld, trailing %lld), triangular solves %lld, other %lld\n",
+                n, h[4], h[0], h[1], h[5], h[6], h[7], h[2], h[3]);
+    }
     RG_HIP(hipMemcpy(coef, a.coef, (size_t)nb * n * 8, hipMemcpyDeviceToHost));
     if (lam) RG_HIP(hipMemcpy(lam, a.lam, (size_t)nb * 3 * n * 8, hipMemcpyDeviceToHost));
     if (cost) RG_HIP(hipMemcpy(cost, a.cost, (size_t)nb * 8, hipMemcpyDeviceToHost));
