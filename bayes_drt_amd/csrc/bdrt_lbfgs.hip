@@ -9,6 +9,7 @@
 // evaluated on the GPU, and all fits (spectra / restarts) advance in lock-step so that one kernel launch serves
 // the whole batch (one 16-column MFMA tile per 16 fits).  The second-order polish that follows runs on the device
 // (bdrt_newton.hip): Hessian probes, blocked MFMA Cholesky, damped step and acceptance test without leaving HBM.
+#include <cstdlib>
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -39,6 +40,7 @@ void bdrt_opt_defaults(bdrt_opt_options *o)
     o->max_iter = 50000; o->history = 5; o->init_alpha = 1e-3; o->tol_obj = 1e-12; o->tol_rel_obj = 1e4;
     o->tol_grad = 1e-8; o->tol_rel_grad = 1e7; o->tol_param = 1e-8;
     o->newton_max_iter = 2000; o->lbfgs_before_newton = 0; o->newton_tol = 1e-8;
+    if (const char *e = getenv("BDRT_LBFGS_BEFORE_NEWTON")) o->lbfgs_before_newton = atoi(e);     // (measurements)
 }
 
 int bdrt_optimize(bdrt_problem *p, const double *init_theta, const int *spec, int n_fits, const bdrt_opt_options *opts,
