@@ -124,6 +124,42 @@ def test_tail_of_a_large_run_moves_to_the_one_chain_kernels(monkeypatch):
     assert abs(n1 - n0) < 0.01 * n0
 
 
+@pytest.mark.parametrize('nf,K', [(81, 101), (41, 51)])
+def test_hand_over_and_compaction_at_the_other_row_strides(nf, K, monkeypatch):
+    """The 16-chain kernel instantiated by basis length keeps its state rows with a stride of 32 x (4, 6, 7) doubles instead of
+    32 x 11: the hand-over to the one-chain layout (nuts_migrate_kernel; 2400 units) and the compaction of an oversubscribed
+    run (nuts_compact_kernel; 5120 units) at those strides, against the runs without either."""
+    import bench
+    from bayes_drt_amd.engine import Sampler
+    from bayes_drt_amd.model import Problem
+    from bayes_drt_amd._lib import NutsControl
+    for ns, warm, nd, depth in ((300, 24, 12, 6), (640, 16, 8, 5)):
+        prob = Problem(**bench.shape_problem_kwargs(nf, K, ns))
+        assert prob.evaluator() == 4
+        n_units = ns * 8
+        spec = np.repeat(np.arange(ns, dtype=np.int32), 8)
+        cid = np.tile(np.arange(8, dtype=np.int32), ns)
+        ctrl = NutsControl(); prob._lib.bdrt_nuts_defaults(C.byref(ctrl)); ctrl.max_treedepth = depth
+
+        def run():
+            with Sampler(prob, n_units, warm, nd, 77, ctrl, spec=spec, chain_ids=cid) as smp:
+                assert smp.kind() == 0
+                smp.run()
+                return smp.results() + (smp.tail_units(), smp.compactions())
+
+        monkeypatch.delenv('BDRT_TAIL_MIGRATION', raising=False); monkeypatch.delenv('BDRT_COMPACTION', raising=False)
+        d1, lp1, g1, tail1, nc1 = run()
+        monkeypatch.setenv('BDRT_TAIL_MIGRATION', '0'); monkeypatch.setenv('BDRT_COMPACTION', '0')
+        d0, lp0, g0, tail0, nc0 = run()
+        assert tail0 == 0 and nc0 == 0 and (tail1 > 0 if ns == 300 else nc1 >= 1), (ns, tail0, nc0, tail1, nc1)
+        assert np.all(np.isfinite(d1)) and np.all(np.isfinite(lp1))
+        err = np.max(np.abs(d1 - d0), axis=(1, 2)) / np.max(np.abs(d0))
+        assert np.mean(err < 1e-6) > 0.9, (ns, np.mean(err < 1e-6))
+        n1, n0 = sum(x['n_leapfrog'] for x in g1), sum(x['n_leapfrog'] for x in g0)
+        assert abs(n1 - n0) < 0.01 * n0
+        prob.close()
+
+
 def test_compaction_of_an_oversubscribed_run_is_bit_identical(monkeypatch):
     """More than 16 units per CU (3 x BASELINE config 4's shard: 1536 spectra x 8 chains = 12288 units = 768 workgroups):
     `run` re-packs the live chains into fewer full workgroups as chains finish (nuts_compact_kernel), so that the 16-column
