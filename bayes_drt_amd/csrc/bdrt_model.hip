@@ -374,26 +374,30 @@ __global__ __launch_bounds__(NT) void logp_grad_kernel(const DevProblem *__restr
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevProblem &P = *Pp;
-    const int c0 = blockIdx.x * NC;
-    TileIO io;
-    io.theta = theta + (size_t)c0 * P.D;
-    io.t_sc = P.D; io.t_sj = 1; io.t_off = nullptr;
-    io.grad = grad ? grad + (size_t)c0 * P.D : nullptr;
-    io.g_sc = P.D; io.g_sj = 1;
-    io.lp = lp ? lp + c0 : nullptr;
-    io.spec = spec ? spec + c0 : nullptr;
-    io.nvalid = min(NC, B - c0);
-    io.jacobian = jacobian;
-    io.Z_hat = Zhat ? Zhat + (size_t)c0 * 2 * P.nf : nullptr;
-    io.sigma_tot = sig ? sig + (size_t)c0 * 2 * P.nf : nullptr;
-    io.params = params ? params + (size_t)c0 * P.D : nullptr;
-    io.prof = nullptr;
-    if (MODE == 4) { s1_toep_init(P, smem); logp_grad_tile_s1<false, 32, NoHook, NoHook, 1, KU>(P, io, smem); }
-    else if (MODE == 6) { s1_toep_init(P, smem); logp_grad_tile_s1<false, 32, NoHook, NoHook, 2, KU>(P, io, smem); }
-    else if (MODE == 3) logp_grad_tile_hw<KU>(P, io, smem);
-    else if (MODE == 2) logp_grad_tile_s1<false, 32, NoHook, NoHook, 0, KU>(P, io, smem);
-    else if (MODE == 1) logp_grad_tile<true>(P, io, smem);
-    else logp_grad_tile<false>(P, io, smem);
+    // A workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the launcher asks for a few workgroups per CU at most):
+    // the generator table and the problem's scalars are set up once per workgroup, not once per sixteen points.
+    if (MODE == 4 || MODE == 6) s1_toep_init(P, smem);
+    for (int c0 = blockIdx.x * NC; c0 < B; c0 += gridDim.x * NC) {
+        TileIO io;
+        io.theta = theta + (size_t)c0 * P.D;
+        io.t_sc = P.D; io.t_sj = 1; io.t_off = nullptr;
+        io.grad = grad ? grad + (size_t)c0 * P.D : nullptr;
+        io.g_sc = P.D; io.g_sj = 1;
+        io.lp = lp ? lp + c0 : nullptr;
+        io.spec = spec ? spec + c0 : nullptr;
+        io.nvalid = min(NC, B - c0);
+        io.jacobian = jacobian;
+        io.Z_hat = Zhat ? Zhat + (size_t)c0 * 2 * P.nf : nullptr;
+        io.sigma_tot = sig ? sig + (size_t)c0 * 2 * P.nf : nullptr;
+        io.params = params ? params + (size_t)c0 * P.D : nullptr;
+        io.prof = nullptr;
+        if (MODE == 4) logp_grad_tile_s1<false, 32, NoHook, NoHook, 1, KU>(P, io, smem);
+        else if (MODE == 6) logp_grad_tile_s1<false, 32, NoHook, NoHook, 2, KU>(P, io, smem);
+        else if (MODE == 3) logp_grad_tile_hw<KU>(P, io, smem);
+        else if (MODE == 2) logp_grad_tile_s1<false, 32, NoHook, NoHook, 0, KU>(P, io, smem);
+        else if (MODE == 1) logp_grad_tile<true>(P, io, smem);
+        else logp_grad_tile<false>(P, io, smem);
+    }
 }
 
 // the S1 evaluator with a whole wavefront per chain: 1024 threads = 16 waves = 4 per SIMD (<= 128 VGPRs)
@@ -446,8 +450,16 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
         return e;
     }));
-    const int grid = cdiv(B, NC);
+    // (BDRT_EVAL_WGS_PER_CU: workgroups per CU a large batch is spread over, default 4; 0: one workgroup per tile as before)
+    static const int wgs_per_cu = getenv("BDRT_EVAL_WGS_PER_CU") ? atoi(getenv("BDRT_EVAL_WGS_PER_CU")) : 4;
+    static int cu_of[64] = {0};                                   // (per device, asked once)
+    int &n_cu = cu_of[p->device & 63];
+    if (n_cu == 0) {
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
     static const bool wide = getenv("BDRT_S1_WIDE") != nullptr;
+    const int grid = (wide || wgs_per_cu <= 0) ? cdiv(B, NC) : std::min(cdiv(B, NC), wgs_per_cu * n_cu);
     if (p->dev.fast_s1 && wide && p->dev.nf <= 128)
         hipLaunchKernelGGL(logp_grad_kernel_wide, dim3(grid), dim3(1024), p->lds_bytes, stream, (const DevProblem *)p->d_dev,
                            d_theta, d_spec, B, jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
