@@ -10,8 +10,12 @@ from bayes_drt_amd.model import Problem
 from bayes_drt_amd.engine import sample_units
 
 ns, nc, warm, nd = [int(a) for a in sys.argv[1:5]] if len(sys.argv) >= 5 else (256, 8, 150, 150)
+if len(sys.argv) >= 6:
+    K = int(sys.argv[5])                                   # another basis length on the same ten-per-decade grid (101: the package default)
 f, Z = synth_spectra(ns)
-bf = np.logspace(10, -6, K); tau = 1 / (2 * np.pi * bf); eps = 1 / np.mean(np.diff(np.log(tau)))
+ext = (K - len(f)) // 2 / 10.0
+bf = np.logspace(10, -6, K) if K == 161 else np.logspace(np.log10(f[0]) + ext, np.log10(f[0]) + ext - (K - 1) / 10.0, K)
+tau = 1 / (2 * np.pi * bf); eps = 1 / np.mean(np.diff(np.log(tau)))
 A = np.vstack([gm.construct_A(f, 'real', tau=tau, epsilon=eps), gm.construct_A(f, 'imag', tau=tau, epsilon=eps)])
 L = [gm.construct_L(bf, tau=tau, epsilon=eps, order=o) for o in (0, 1, 2)]
 prob = Problem([dict(A=A, L0=L[0], L1=L[1], L2=0.75 * L[2], nonneg=True)], Z, f, ups_alpha=1.0, ups_beta=0.1)
