@@ -188,6 +188,8 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         // Wide parameter vectors (SPEC: outlier error model, several distributions) do not fit in registers next to the
         // evaluator: they take the wide-vector path below, which streams the chain's rows from HBM.
         constexpr int NA = SPEC ? 1 : NJ;
+        // elements per lane that lie below D whatever D is: MODE 2 picks the smallest NJ of {4, 6, 7, 11, 16} with D <= 32 NJ (s1_nj)
+        constexpr int MSAFE = MODE != 2 ? 0 : (NJ == 6 ? 4 : (NJ == 7 ? 6 : (NJ == 11 ? 7 : (NJ == 16 ? 11 : 0))));
         double p_[NA], g_[NA], mi_[NA];
 #pragma unroll
         for (int m = 0; m < NA; ++m) { p_[m] = 0.0; g_[m] = 0.0; mi_[m] = 1.0; }
@@ -452,18 +454,25 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         // (Measured and dropped: the two rows of level 1 requested here as well for leaves that end in two one bits -- 44 more live
         // registers: 31 spilled, 0.766 -> 0.692; with the gradient re-read from its LDS row after stage C instead of held in registers
         // (alone: 0.761) still 15 spilled, 0.698.  Any scratch access in this loop costs more than a memory round trip saved.)
+        // No element of the passes below is guarded by `j < D`: every state row is DS = 32 NJ long and its elements from D on are
+        // zero from bdrt_sampler_create on (the inverse metric's: finite), every statement maps zeros to zeros, so the lanes
+        // beyond D add exact zeros to the sums and store zeros -- eleven `s_and_saveexec / s_cbranch_execz` pairs per pass
+        // otherwise.  Exceptions: the gradient row in LDS (MODE 2: the evaluator's transit values lie behind element D), the
+        // draws (rows of D) and the random re-initialisation.
         if (act) {
 #pragma unroll
             for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; g_[m] = G[j]; }
+            if constexpr (MODE == 2) {
+                const int lim = D - l32;
+#pragma unroll
+                for (int m = MSAFE; m < NJ; ++m) g_[m] = 32 * m < lim ? g_[m] : 0.0;
+            }
 #pragma unroll
             for (int m = 0; m < NJ; ++m) {
-                const int j = l32 + 32 * m;
-                if (j < D) {
-                    const double p = p_[m] + 0.5 * e * g_[m];
-                    p_[m] = p;                            // written to memory by stage A' / E at the end of the body
-                    kin += mi_[m] * p * p;
-                    bad_g = bad_g || !isfinite(g_[m]);
-                }
+                const double p = p_[m] + 0.5 * e * g_[m];
+                p_[m] = p;                            // written to memory by stage A' / E at the end of the body
+                kin += mi_[m] * p * p;
+                bad_g = bad_g || !isfinite(g_[m]);
             }
         }
         kin = 0.5 * half_sum(kin);
@@ -515,10 +524,8 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 #pragma unroll
                 for (int m = 0; m < NJ; ++m) {
                     const int j = l32 + 32 * m;
-                    if (j < D) {
-                        if (copyq) { THQ[j] = th_[m]; GQ[j] = g_[m]; }
-                        if (cur2s) { THS[j] = th_[m]; GS[j] = g_[m]; }
-                    }
+                    if (copyq) { THQ[j] = th_[m]; GQ[j] = g_[m]; }
+                    if (cur2s) { THS[j] = th_[m]; GS[j] = g_[m]; }
                 }
             }
         }
@@ -553,14 +560,11 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) {
-                        const int j = l32 + 32 * m;
-                        if (j < D) {
-                            const double rho = lr_[m] + rc_[m];
-                            a0 += mi_[m] * lp_[m] * rho;
-                            a1 += mi_[m] * p_[m] * rho;
-                            rc_[m] = rho;
-                            cpl_[m] = lp_[m];
-                        }
+                        const double rho = lr_[m] + rc_[m];
+                        a0 += mi_[m] * lp_[m] * rho;
+                        a1 += mi_[m] * p_[m] * rho;
+                        rc_[m] = rho;
+                        cpl_[m] = lp_[m];
                     }
                     a0 = half_sum(a0); a1 = half_sum(a1);
                     ok = ok && (a0 > 0.0) && (a1 > 0.0);
@@ -571,7 +575,8 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) {
                         const int j = l32 + 32 * m;
-                        if (j < D) { PLn[j] = cpl_[m]; if (nm > 0) RLn[j] = rc_[m]; }
+                        PLn[j] = cpl_[m];
+                        if (nm > 0) RLn[j] = rc_[m];
                     }
                 }
             }
@@ -594,13 +599,11 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) {
                         const int j = l32 + 32 * m;
-                        if (j < D) {
-                            const double rt = rt_[m] + rc_[m];
-                            RHO[j] = rt;
-                            THE[j] = th_[m]; PE[j] = p_[m]; GE[j] = g_[m];
-                            t0 += mi_[m] * po_[m] * rt;
-                            t1 += mi_[m] * p_[m] * rt;
-                        }
+                        const double rt = rt_[m] + rc_[m];
+                        RHO[j] = rt;
+                        THE[j] = th_[m]; PE[j] = p_[m]; GE[j] = g_[m];
+                        t0 += mi_[m] * po_[m] * rt;
+                        t1 += mi_[m] * p_[m] * rt;
                     }
                 }
                 t0 = half_sum(t0); t1 = half_sum(t1);
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 for (int m = 0; m < NJ; ++m) {
                     const int j = l32 + 32 * m;
                     const double p = p_[m] + 0.5 * e1 * g_[m];
-                    if (j < D) { Pm[j] = p; TH[j] = th_[m] + e1 * mi_[m] * p; }
+                    Pm[j] = p; TH[j] = th_[m] + e1 * mi_[m] * p;
                 }
             }
         }
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 }
                 if (upds) {
 #pragma unroll
-                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; if (j < D) { THS[j] = ths_[m]; GS[j] = gs_[m]; } }
+                    for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; THS[j] = ths_[m]; GS[j] = gs_[m]; }
                 }
                 if (welf || wend) {
                     double *WM = row(V_WMEAN), *W2 = row(V_WM2);
@@ -700,21 +703,19 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) {
                         const int j = l32 + 32 * m;
-                        if (j < D) {
-                            double mean = wm_[m], m2 = w2_[m];
-                            if (welf) {            // Welford (stan::math::welford_var_estimator)
-                                const double delta = ths_[m] - mean;
-                                mean += delta / wn;
-                                m2 += (ths_[m] - mean) * delta;
-                            }
-                            if (wend) {            // var_adaptation::learn_variance
-                                const double var = wn > 1.0 ? m2 / (wn - 1.0) : 0.0;
-                                mi_[m] = (wn / (wn + 5.0)) * var + 1e-3 * (5.0 / (wn + 5.0));
-                                MI[j] = mi_[m];
-                                mean = 0.0; m2 = 0.0;
-                            }
-                            WM[j] = mean; W2[j] = m2;
+                        double mean = wm_[m], m2 = w2_[m];
+                        if (welf) {            // Welford (stan::math::welford_var_estimator)
+                            const double delta = ths_[m] - mean;
+                            mean += delta / wn;
+                            m2 += (ths_[m] - mean) * delta;
                         }
+                        if (wend) {            // var_adaptation::learn_variance
+                            const double var = wn > 1.0 ? m2 / (wn - 1.0) : 0.0;
+                            mi_[m] = (wn / (wn + 5.0)) * var + 1e-3 * (5.0 / (wn + 5.0));
+                            MI[j] = mi_[m];
+                            mean = 0.0; m2 = 0.0;
+                        }
+                        WM[j] = mean; W2[j] = m2;
                     }
                 }
                 if (draw >= 0 && valid) {
@@ -771,18 +772,16 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) {
                         const int j = l32 + 32 * m;
-                        if (j < D) {
-                            const double p = pn_[m];
-                            if (next == 1) {
-                                rTHM[j] = ths_[m]; rTHP[j] = ths_[m];
-                                rPM[j] = p; rPP[j] = p;
-                                rGM[j] = gs_[m]; rGP[j] = gs_[m];
-                                rRHO[j] = p;
-                            }
-                            const double pk = p + 0.5 * e1 * gs_[m];
-                            Pm[j] = pk;
-                            TH[j] = ths_[m] + e1 * mi_[m] * pk;
+                        const double p = pn_[m];
+                        if (next == 1) {
+                            rTHM[j] = ths_[m]; rTHP[j] = ths_[m];
+                            rPM[j] = p; rPP[j] = p;
+                            rGM[j] = gs_[m]; rGP[j] = gs_[m];
+                            rRHO[j] = p;
                         }
+                        const double pk = p + 0.5 * e1 * gs_[m];
+                        Pm[j] = pk;
+                        TH[j] = ths_[m] + e1 * mi_[m] * pk;
                     }
                 } else if (next == 2) {
                     // continue from the trajectory end in the new direction
@@ -801,11 +800,9 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) {
                         const int j = l32 + 32 * m;
-                        if (j < D) {
-                            const double pk = ep_[m] + 0.5 * e1 * eg_[m];
-                            Pm[j] = pk;
-                            TH[j] = et_[m] + e1 * mi_[m] * pk;
-                        }
+                        const double pk = ep_[m] + 0.5 * e1 * eg_[m];
+                        Pm[j] = pk;
+                        TH[j] = et_[m] + e1 * mi_[m] * pk;
                     }
                 } else if (next == 4) {
 #pragma unroll

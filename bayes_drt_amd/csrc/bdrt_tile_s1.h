@@ -721,11 +721,19 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     double x_[UKV];
     {
         double tx_[UKV], tu_[UKV];
+        // (loads first, unconditionally, from a clamped index; THEN the selects: a load under `k < K` becomes a branch around an
+        // LDS read with its own s_waitcnt -- six serial LDS round trips per phase, tools/isa_blocks.py)
 #pragma unroll
         for (int u = 0; u < UKV; ++u) {
-            const int k = l32 + LPC * u;
-            tx_[u] = k < K ? TH(B.o_x + k) : 0.0;
-            tu_[u] = k < K ? TH(B.o_ups + k) : 0.0;
+            const int k = l32 + LPC * u, kk = k < K ? k : 0;
+            tx_[u] = TH(B.o_x + kk);
+            tu_[u] = TH(B.o_ups + kk);
+        }
+#pragma unroll
+        for (int u = 0; u < UKV; ++u) {
+            const bool in = l32 + LPC * u < K;
+            tx_[u] = in ? tx_[u] : 0.0;
+            tu_[u] = in ? tu_[u] : 0.0;
         }
         // all exponentials of the lane in one straight-line block (tx = 0 beyond K): the polynomial's constants are then
         // materialised once for the six evaluations instead of once per predicated block
@@ -944,13 +952,25 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         const int rk = TA == 2 ? toep_gen_odd(K) : (TA ? (K & 15) : 0);
         double lk0 = 0.0, lk1 = 0.0;
         if (TA == 2) toep_zero_split_gen<false>(nf, K, Xs, tid); else if (TA) toep_zero_split<false>(nf, K, Xs, tid);
+        // (the phase's LDS reads in one batch, from a clamped row: under `n < nf` each of them is a round trip of its own)
+        double azr_[UNV], azi_[UNV], tk0r_[UNV], tk0i_[UNV], tk1r_[UNV], tk1i_[UNV];
+#pragma unroll
+        for (int v = 0; v < UNV; ++v) {
+            const int n = l32 + LPC * v, nn = n < nf ? n : 0;
+            azr_[v] = Zh[swz(nn, c)]; azi_[v] = Zh[swz(nfi + nn, c)];
+            tk0r_[v] = 0.0; tk0i_[v] = 0.0; tk1r_[v] = 0.0; tk1i_[v] = 0.0;
+            if (TA && rk > 0) {
+                tk0r_[v] = Tt[TPAD + nn + rk - 1]; tk0i_[v] = Tt[tlen + TPAD + nn + rk - 1];
+                if (rk > 1) { tk1r_[v] = Tt[TPAD + nn + rk - 2]; tk1i_[v] = Tt[tlen + TPAD + nn + rk - 2]; }
+            }
+        }
 #pragma unroll
         for (int v = 0; v < UNV; ++v) {
             const int n = l32 + LPC * v;
             if (n >= nf) continue;
             const double wn = wn_[v];
-            const double zr = Zh[swz(n, c)] + Rinf;
-            const double zi = Zh[swz(nfi + n, c)] + induc * wn;
+            const double zr = azr_[v] + Rinf;
+            const double zi = azi_[v] + induc * wn;
             // outlier error model (Series_*_outliers_modelcode.txt): 2 Nf extra parameters, read where they are needed
             double so_re = 0.0, so_im = 0.0, r0 = 0.0, r1 = 0.0, t0 = 0.0, t1 = 0.0;
             if (omode) {
@@ -974,8 +994,8 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             Zh[swz(n, c)] = gzr;
             Zh[swz(nfi + n, c)] = gzi;
             if (TA && rk > 0) {            // A_part[n][K - rk + j] = tg[part][n + rk - 1 - j]
-                lk0 = fma(Tt[TPAD + n + rk - 1], gzr, fma(Tt[tlen + TPAD + n + rk - 1], gzi, lk0));
-                if (rk > 1) lk1 = fma(Tt[TPAD + n + rk - 2], gzr, fma(Tt[tlen + TPAD + n + rk - 2], gzi, lk1));
+                lk0 = fma(tk0r_[v], gzr, fma(tk0i_[v], gzi, lk0));
+                if (rk > 1) lk1 = fma(tk1r_[v], gzr, fma(tk1i_[v], gzi, lk1));
             }
             sR += gzr;
             sL += gzi * wn;
@@ -1047,16 +1067,22 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
 
     // ---- epilogue (M1): chain rule through x = exp(theta_x); coalesced gradient rows ----------------------------------------
     double gx_[UKV], gu_[UKV];
+    {
+        // (all LDS reads of the phase in one batch: the rows of A^T g beyond K lie inside the tile, the private rows are 32 KU long)
+        double ag_[UKV], gl2_[UKV];
 #pragma unroll
-    for (int u = 0; u < UKV; ++u) {
-        const int k = l32 + LPC * u;
-        gx_[u] = 0.0; gu_[u] = 0.0;
-        if (k < K) {
-            const double graw = Xs[swz(k, c)] + wrow[MAXBW + k];
-            gx_[u] = B.is_pos ? x_[u] * graw + jac : graw;
-            gu_[u] = xrow[MAXBW + k];
-            GW(B.o_x + k, gx_[u]);
-            GW(B.o_ups + k, gu_[u]);
+        for (int u = 0; u < UKV; ++u) {
+            const int k = l32 + LPC * u, kk = k < K ? k : 0;
+            ag_[u] = Xs[swz(kk, c)]; gl2_[u] = wrow[MAXBW + k]; gu_[u] = xrow[MAXBW + k];
+        }
+#pragma unroll
+        for (int u = 0; u < UKV; ++u) {
+            const int k = l32 + LPC * u;
+            const double graw = ag_[u] + gl2_[u];
+            const double gx = B.is_pos ? x_[u] * graw + jac : graw;
+            gx_[u] = k < K ? gx : 0.0;
+            gu_[u] = k < K ? gu_[u] : 0.0;
+            if (!LDSIO && k < K) { GW(B.o_x + k, gx_[u]); GW(B.o_ups + k, gu_[u]); }
         }
     }
     if (LDSIO) {
