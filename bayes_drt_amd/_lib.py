@@ -79,7 +79,8 @@ SYMBOLS = [
 
 
 def library_path():
-    return os.path.join(_HERE, 'libbdrt.so')
+    # BDRT_LIBRARY: another build of the same library (A/B measurements of kernel variants, tools/build_variant.sh)
+    return os.environ.get('BDRT_LIBRARY') or os.path.join(_HERE, 'libbdrt.so')
 
 
 def _preload_hip_runtime():

@@ -122,22 +122,36 @@ __device__ __forceinline__ double lean_rcp(double b)
 // exp(x) for finite x: n = rint(x / ln 2), r = x - n ln 2 in two steps (Cody-Waite), e^r by the degree-13 Taylor polynomial
 // (|r| <= 0.3466: truncation 6e-18 relative), 2^n by v_ldexp_f64, which overflows to inf and underflows towards 0 by itself.
 // 19 instructions against 28.  x = +-inf: NaN.
+// a * b + C with the constant C in a scalar register pair.  Left to itself the compiler writes a Horner step as `v_fmac_f64` (the
+// addend is the destination) and materialises every coefficient in a VGPR pair first -- two `v_mov_b32` per step, ~25 VALU
+// instructions per exponential on top of its 19 (tools/isa_blocks.py: 1.7 k static `v_mov` in the headline kernel); as the third
+// operand of `v_fma_f64` the coefficient comes from two `s_mov_b32`, which issue beside the other wave's VALU instructions.
+__device__ __forceinline__ double fma_sc(double a, double b, double C)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(C));
+    return d;
+#else
+    return __builtin_fma(a, b, C);
+#endif
+}
+
 __device__ __forceinline__ double lean_exp(double x)
 {
     const double n = __builtin_rint(x * 1.4426950408889634074);
     double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);
     r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821614599e-10;                 // 1/13!
-    p = __builtin_fma(p, r, 2.0876756987868098979e-09);   // 1/12!
-    p = __builtin_fma(p, r, 2.5052108385441718775e-08);   // 1/11!
-    p = __builtin_fma(p, r, 2.7557319223985890653e-07);   // 1/10!
-    p = __builtin_fma(p, r, 2.7557319223985892511e-06);   // 1/9!
-    p = __builtin_fma(p, r, 2.4801587301587301566e-05);   // 1/8!
-    p = __builtin_fma(p, r, 1.9841269841269841253e-04);   // 1/7!
-    p = __builtin_fma(p, r, 1.3888888888888889419e-03);   // 1/6!
-    p = __builtin_fma(p, r, 8.3333333333333332177e-03);   // 1/5!
-    p = __builtin_fma(p, r, 4.1666666666666664354e-02);   // 1/4!
-    p = __builtin_fma(p, r, 1.6666666666666665741e-01);   // 1/3!
+    double p = __builtin_fma(r, 1.6059043836821614599e-10, 2.0876756987868098979e-09);     // 1/13!, 1/12!
+    p = fma_sc(p, r, 2.5052108385441718775e-08);   // 1/11!
+    p = fma_sc(p, r, 2.7557319223985890653e-07);   // 1/10!
+    p = fma_sc(p, r, 2.7557319223985892511e-06);   // 1/9!
+    p = fma_sc(p, r, 2.4801587301587301566e-05);   // 1/8!
+    p = fma_sc(p, r, 1.9841269841269841253e-04);   // 1/7!
+    p = fma_sc(p, r, 1.3888888888888889419e-03);   // 1/6!
+    p = fma_sc(p, r, 8.3333333333333332177e-03);   // 1/5!
+    p = fma_sc(p, r, 4.1666666666666664354e-02);   // 1/4!
+    p = fma_sc(p, r, 1.6666666666666665741e-01);   // 1/3!
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
@@ -161,9 +175,9 @@ __device__ __forceinline__ double lean_log(double x)
     const double f = m - 1.0;
     const double s = f * lean_rcp(2.0 + f);
     const double z = s * s, w = z * z;
-    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
-                                                         2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double t1 = w * fma_sc(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma_sc(w, fma_sc(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                           2.857142874366239149e-01), 6.666666666666735130e-01);
     const double R = t1 + t2, hfsq = 0.5 * f * f, de = (double)e;
     const double r = __builtin_fma(de, 6.93147180369123816490e-01, f - (hfsq - __builtin_fma(s, hfsq + R, de * 1.90821492927058770002e-10)));
     return in_domain ? r : __builtin_nan("");

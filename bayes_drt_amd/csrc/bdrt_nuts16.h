@@ -55,6 +55,18 @@ __device__ __forceinline__ void lds_wave_sync()
 // unrolled into a batch of independent loads followed by the arithmetic (one memory round trip per stage instead of one
 // per element -- the state vectors of 2048+ chains live in HBM/MALL, not in L2).
 // TA (MODE 2 only): DevProblem::toepA (1: the default shapes, 2: any shape), the S1 tile's GEMMs take the A operands from the generator table in LDS
+#ifndef BDRT_DEEP_VARIANT
+#define BDRT_DEEP_VARIANT 1
+#endif
+#ifndef BDRT_PRE1
+#define BDRT_PRE1 0
+#endif
+#ifndef BDRT_GLDS
+#define BDRT_GLDS 0
+#endif
+#ifndef BDRT_NUTS_ABLATE
+#define BDRT_NUTS_ABLATE 0
+#endif
 #ifndef BDRT_NUTS_EARLY_STATE
 #define BDRT_NUTS_EARLY_STATE 1
 #endif
@@ -126,11 +138,25 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     io.Z_hat = nullptr; io.sigma_tot = nullptr; io.params = nullptr;
     io.prof = a.prof ? a.prof + (size_t)wg * 32 : nullptr;
     long long tnp = 0;
-#define BDRT_NUTS_PROF(slot) do { if (io.prof && tid == 0) { const long long t_ = clock64(); io.prof[slot] += t_ - tnp; tnp = t_; } } while (0)
+#define BDRT_NUTS_PROF(slot) do { if (!BDRT_PROF_FINE && io.prof && tid == 0) { const long long t_ = clock64(); io.prof[slot] += t_ - tnp; tnp = t_; } } while (0)
     // per-wave stage times (slots 17..24, summed over the 8 waves): where each wave spends the round, incl. the barrier wait
     long long twv = 0;
 #define BDRT_WAVE_PROF(slot) do { if (io.prof && lane == 0) { const long long t_ = clock64(); atomicAdd((unsigned long long *)&io.prof[slot], (unsigned long long)(t_ - twv)); twv = t_; } } while (0)
 
+    // -DBDRT_PROF_FINE=1 (tools/build_variant.sh): the thread-0 slots 0..16 of the phase profile become wave-summed timers of the
+    // register path's sub-stages (bench.py --phase-profile prints them with BDRT_BENCH_FINE=1)
+#ifndef BDRT_PROF_FINE
+#define BDRT_PROF_FINE 0
+#endif
+    long long tfn = 0;
+    // (accumulated in LDS -- the wide-vector path's `hvk` cells, free on the register path -- and added to the global slots at the
+    // end of the launch: a global atomic per stamp puts a memory operation in front of every stage's s_waitcnt)
+    typedef __attribute__((address_space(3))) unsigned long long *lds_u64;
+    const lds_u64 fine = (lds_u64)(unsigned long long *)hvk;
+    if (BDRT_PROF_FINE && tid < 2 * NC) fine[tid] = 0ull;
+#define BDRT_FINE(slot) do { if (BDRT_PROF_FINE && io.prof && lane == 0) { const long long t_ = clock64(); __hip_atomic_fetch_add(&fine[slot], (unsigned long long)(t_ - tfn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); tfn = t_; } } while (0)
+#define BDRT_FINE_COUNT(slot, cond) do { if (BDRT_PROF_FINE && io.prof) { const bool w_ = __builtin_amdgcn_ballot_w64(cond) != 0; if (lane == 0 && w_) __hip_atomic_fetch_add(&fine[slot], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } } while (0)
+    const int ndbg = BDRT_NUTS_ABLATE ? P.dbg : 0;          // timing ablations (-DBDRT_NUTS_ABLATE=1 builds only; results wrong on purpose)
     unsigned long long my_leaps = 0;
     double *TH = row(V_TH) + (SPEC && s.thsel ? TH2OFF : 0), *Pm = row(V_P), *G = row(V_G), *MI = row(V_MINV);
 
@@ -170,14 +196,28 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         any_act = __syncthreads_or(running);
     }
 
+    // Register path: what the top of a round needs of the chain state -- phase, leaf index, signed step size -- is carried in
+    // registers and refreshed from LDS at the end of a round only when the chain did anything but a plain continuing leaf.
+    int ph_c = 0, leaf_c = 0;
+    double e_c = 0.0;
+    auto refresh_carried = [&]() {
+        ph_c = s.phase; leaf_c = s.leaf;
+        e_c = ph_c == PH_EPS ? s.eps : (ph_c == PH_TREE ? s.dir * s.eps : 0.0);
+    };
+    if constexpr (!SPEC) refresh_carried();
+
     for (int round = 0; round < a.rounds; ++round) {
         // keep per-lane address arithmetic inside the loop (see the note in bdrt_tile_s1.h): hoisted, it is spilled
         __asm__ volatile("" : "+v"(c), "+v"(l32));
         if (SPEC && tid < NC) hvy[tid] = 0;
-        const int ph0 = s.phase;
+        int ph0;
+        double e;
+        if constexpr (SPEC) {
+            ph0 = s.phase;
+            e = ph0 == PH_EPS ? s.eps : (ph0 == PH_TREE ? s.dir * s.eps : 0.0);
+        } else { ph0 = ph_c; e = e_c; }
         const bool act = ph0 == PH_INIT || ph0 == PH_EPS || ph0 == PH_TREE;
         if (!any_act) break;
-        const double e = ph0 == PH_EPS ? s.eps : (ph0 == PH_TREE ? s.dir * s.eps : 0.0);
         if (io.prof && tid == 0) tnp = clock64();
         if (io.prof && lane == 0) twv = clock64();
 
@@ -435,59 +475,88 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 
         // ---- C: second half kick, kinetic energy, finiteness of the gradient -----------------------------
         // (p, g, Minv of this chain stay in registers from here to the end of stage D)
+        if (BDRT_PROF_FINE && io.prof && lane == 0) tfn = clock64();
         double kin = 0.0, nonfin = 0.0;
         bool bad_g = false;
-        const int dir_now = s.dir;
-        const int leaf_now = s.leaf;
-        // An odd leaf merges with the single leaf waiting at level 0 (known from the index alone): its momentum is requested
-        // here, so that the HBM round trip runs under the scalar logic of stage S1 instead of after it.  (Even leaves alias the
-        // chain's own momentum row: the load stays unconditional.)
+        const int leaf_now = leaf_c;
+        // The part of the chain state that a plain tree leaf reads, requested in ONE batch here and used in stage S1 (read where
+        // it is used, every member is an LDS round trip of its own behind the branches of the scalar logic: eight in a row).
+        struct LeafHot { int nleaves, depth, iter, n_leap_iter; double H0, lsw_sub, sum_metro, lpq; } h;
+        h.nleaves = s.nleaves; h.depth = s.depth; h.iter = s.iter; h.n_leap_iter = s.n_leap_iter;
+        h.H0 = s.H0; h.lsw_sub = s.lsw_sub; h.sum_metro = s.sum_metro; h.lpq = 0.0;
+        const double lp_now = lpn[c];
+        // The leaf's index says which waiting sub-subtrees it closes (nm_pre trailing one bits: levels 0 .. nm_pre - 1), before
+        // anything is evaluated.  Level 0 (the previous leaf's momentum) is requested here by every chain (even leaves alias the
+        // chain's own momentum row: the load stays unconditional); a wave with a chain that closes two levels or more requests
+        // level 1 as well, right behind the kick (below) -- both round trips run under the scalar logic of stage S1 instead of
+        // one after the other behind it; the levels from 2 on come two per round trip in stage D.  (Round 3 requested level 1
+        // with level 0 in every wave: spilled; levels 1 AND 2 here: 49 registers spilled.)
         constexpr bool PRE0 = NJ <= 11;                  // (16 elements per lane leave no registers for it)
-        double pl0_[PRE0 ? NA : 1];
+        const bool treeph = act && ph0 == PH_TREE;
+        const int nm_pre = treeph ? __builtin_ctz(~(unsigned)leaf_now) : 0;
+        const bool deep = PRE0 && __builtin_amdgcn_ballot_w64(nm_pre >= 2) != 0;       // (wave-uniform)
+        double pl0_[PRE0 ? NA : 1], alr_[PRE0 ? NA : 1], alp_[PRE0 ? NA : 1], blr_[PRE0 ? NA : 1], blp_[PRE0 ? NA : 1];
         if constexpr (PRE0) {
-            const double *PL0 = (act && ph0 == PH_TREE && (leaf_now & 1)) ? row(V_CKP) : Pm;
+            const double *PL0 = nm_pre >= 1 ? row(V_CKP) : Pm;
 #pragma unroll
             for (int m = 0; m < NJ; ++m) pl0_[m] = PL0[l32 + 32 * m];
         }
-        // (Measured and dropped: the two rows of level 1 requested here as well for leaves that end in two one bits -- 44 more live
-        // registers, 31 spilled: 0.766 -> 0.692.)
-        // (Measured and dropped: the two rows of level 1 requested here as well for leaves that end in two one bits -- 44 more live
-        // registers: 31 spilled, 0.766 -> 0.692; with the gradient re-read from its LDS row after stage C instead of held in registers
-        // (alone: 0.761) still 15 spilled, 0.698.  Any scratch access in this loop costs more than a memory round trip saved.)
+        // the rows of level l into a buffer (a level the chain does not close aliases its momentum row: no load under a condition)
+        auto request_level = [&](int l, int nmx, double (&lr_)[PRE0 ? NA : 1], double (&lp_)[PRE0 ? NA : 1]) {
+            if constexpr (PRE0) {
+                const double *RA = l < nmx ? row(V_CKC + l) : Pm, *PA = l < nmx ? row(V_CKP + l) : Pm;
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; lr_[m] = RA[j]; lp_[m] = PA[j]; }
+            }
+        };
         // No element of the passes below is guarded by `j < D`: every state row is DS = 32 NJ long and its elements from D on are
         // zero from bdrt_sampler_create on (the inverse metric's: finite), every statement maps zeros to zeros, so the lanes
         // beyond D add exact zeros to the sums and store zeros -- eleven `s_and_saveexec / s_cbranch_execz` pairs per pass
         // otherwise.  Exceptions: the gradient row in LDS (MODE 2: the evaluator's transit values lie behind element D), the
         // draws (rows of D) and the random re-initialisation.
-        if (act) {
+        BDRT_FINE(0);
+        // MODE 2: the gradient is NOT held in registers from here on -- it stays readable in the chain's LDS row until the next
+        // evaluation, and the stages that want it again (proposal copy, end of a subtree, the next kick) read it there: 22
+        // registers less across stages S1 and D, which is what leaves room for the rows of level 1.
+        constexpr bool GLDS = MODE == 2 && BDRT_GLDS;
+        auto load_grad = [&](double (&g)[NA]) {
 #pragma unroll
-            for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; g_[m] = G[j]; }
+            for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; g[m] = G[j]; }
             if constexpr (MODE == 2) {
                 const int lim = D - l32;
 #pragma unroll
-                for (int m = MSAFE; m < NJ; ++m) g_[m] = 32 * m < lim ? g_[m] : 0.0;
+                for (int m = MSAFE; m < NJ; ++m) g[m] = 32 * m < lim ? g[m] : 0.0;
             }
+        };
+        if (act) {
+            double gc_[NA];
+            load_grad(gc_);
 #pragma unroll
             for (int m = 0; m < NJ; ++m) {
-                const double p = p_[m] + 0.5 * e * g_[m];
+                const double p = p_[m] + 0.5 * e * gc_[m];
                 p_[m] = p;                            // written to memory by stage A' / E at the end of the body
                 kin += mi_[m] * p * p;
-                bad_g = bad_g || !isfinite(g_[m]);
+                bad_g = bad_g || !isfinite(gc_[m]);
+                if constexpr (!GLDS) g_[m] = gc_[m];
             }
         }
+        BDRT_FINE(1);
+        // (behind the first use of p / Minv: in front of it the kick would wait for these rows too -- s_waitcnt counts in order)
+        if constexpr (PRE0 && BDRT_PRE1) request_level(1, nm_pre, alr_, alp_);     // (under `if (deep)`: 150 bytes of spills)
         kin = 0.5 * half_sum(kin);
         // a non-finite gradient entry anywhere in the chain's half-wave: one ballot instead of a second butterfly
         nonfin = ((__builtin_amdgcn_ballot_w64(bad_g) >> (lane & 32)) & 0xffffffffull) ? 1.0 : 0.0;
+        BDRT_FINE(2);
         BDRT_NUTS_PROF(11);
         BDRT_WAVE_PROF(18);
 
         // ---- S1: per-chain scalar logic after the evaluation (redundant in the 32 lanes of the chain) --------
         bool copyq = false, cur2s = false, tree = false, last = false;
         bool upds = false, welf = false, wend = false;
-        int nm = 0, endt = 0, next = 0, draw = -1;
+        int nm = 0, endt = 0, next = 0, draw = -1, dir_now = 0;
         double wn = 0.0;
         if (act) {
-            const double lp = lpn[c];
+            const double lp = lp_now;
             const bool finite_pt = isfinite(lp) && nonfin == 0.0;
             if (ph0 == PH_INIT) {
                 if (finite_pt) {
@@ -507,20 +576,25 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 next = nuts_stepsize_trial(s, np, lp, kin);
             } else {   // PH_TREE: one new leaf
                 if (l32 == 0) my_leaps += 1;
-                nuts_tree_leaf(s, np, rng, lp, kin, leaf_now, copyq, tree, nm, last, endt);      // (bdrt_nuts_device.h)
+                nuts_tree_leaf(h, np, rng, lp, kin, leaf_now, copyq, tree, nm, last, endt);      // (bdrt_nuts_device.h)
+                s.n_leap_iter = h.n_leap_iter; s.sum_metro = h.sum_metro;
+                if (tree) s.lsw_sub = h.lsw_sub;
+                if (copyq) s.lpq = h.lpq;
                 if (last) *slow = round + 1;                        // closing a subtree (and maybe the transition): a long round
             }
         }
+        BDRT_FINE(3);
         BDRT_NUTS_PROF(12);
         BDRT_WAVE_PROF(19);
 
         // ---- D: proposal copy, checkpoints, running rho, U-turn tests, subtree close ----------------------------
-        if (copyq || cur2s) {
+        if ((copyq || cur2s) && !(ndbg & 64)) {
             double *THQ = row(V_THQ), *GQ = row(V_GQ), *THS = row(V_THS), *GS = row(V_GS);
             {
                 double th_[NJ];
 #pragma unroll
                 for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; th_[m] = TH[j]; }
+                if constexpr (GLDS) load_grad(g_);
 #pragma unroll
                 for (int m = 0; m < NJ; ++m) {
                     const int j = l32 + 32 * m;
@@ -529,6 +603,9 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 }
             }
         }
+        BDRT_FINE(4);
+        BDRT_FINE_COUNT(14, copyq || cur2s);
+        bool cont = false;                                  // a plain leaf: the trajectory goes on from the point just evaluated
         if (tree) {
             // Binary-counter bookkeeping of the new subtree (leaves arrive in time order): level l of the checkpoint rows
             // holds the completed left sub-subtree of 2^l leaves that still waits for its sibling -- rho (sum of momenta,
@@ -541,22 +618,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             {
 #pragma unroll
                 for (int m = 0; m < NJ; ++m) { rc_[m] = p_[m]; cpl_[m] = p_[m]; }
-                for (int l = 0; l < nm; ++l) {
-                    double lr_[NJ], lp_[NJ];
-                    if (l == 0) {
-                        if constexpr (PRE0) {
-#pragma unroll
-                            for (int m = 0; m < NJ; ++m) { lp_[m] = pl0_[m]; lr_[m] = lp_[m]; }
-                        } else {
-                            const double *PL = row(V_CKP);
-#pragma unroll
-                            for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; lp_[m] = PL[j]; lr_[m] = lp_[m]; }
-                        }
-                    } else {
-                        const double *RL = row(V_CKC + l), *PL = row(V_CKP + l);
-#pragma unroll
-                        for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; lr_[m] = RL[j]; lp_[m] = PL[j]; }
-                    }
+                auto merge = [&](const double (&lr_)[PRE0 ? NA : 1], const double (&lp_)[PRE0 ? NA : 1]) {
                     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) {
@@ -568,8 +630,40 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     }
                     a0 = half_sum(a0); a1 = half_sum(a1);
                     ok = ok && (a0 > 0.0) && (a1 > 0.0);
+                };
+                if constexpr (PRE0) {
+                    if (nm > 0) merge(pl0_, pl0_);
+                    BDRT_FINE(5);
+                    BDRT_FINE_COUNT(15, nm > 1);
+                    if (deep && !(ndbg & 16)) {
+                        // level 1 is here (requested in stage C); the levels beyond it one per round trip
+                        if (BDRT_PRE1 && nm > 1) merge(alr_, alp_);
+                        for (int l = BDRT_PRE1 ? 2 : 1; __builtin_amdgcn_ballot_w64(l < nm) != 0; l += 1) {
+                            request_level(l, nm, alr_, alp_);
+                            if (l < nm) merge(alr_, alp_);
+                        }
+                    }
+                } else {
+                    for (int l = 0; l < nm; ++l) {
+                        double lr_[NJ], lp_[NJ];
+                        const double *RL = row(l == 0 ? V_CKP : V_CKC + l), *PL = row(V_CKP + l);
+#pragma unroll
+                        for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; lr_[m] = RL[j]; lp_[m] = PL[j]; }
+                        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                        for (int m = 0; m < NJ; ++m) {
+                            const double rho = lr_[m] + rc_[m];
+                            a0 += mi_[m] * lp_[m] * rho;
+                            a1 += mi_[m] * p_[m] * rho;
+                            rc_[m] = rho;
+                            cpl_[m] = lp_[m];
+                        }
+                        a0 = half_sum(a0); a1 = half_sum(a1);
+                        ok = ok && (a0 > 0.0) && (a1 > 0.0);
+                    }
                 }
-                if (ok && !last) {
+                BDRT_FINE(6);
+                if (ok && !last && !(ndbg & 32)) {
                     // the sub-subtree of 2^nm leaves that ends here becomes the waiting left sibling of level nm
                     double *PLn = row(V_CKP + nm), *RLn = row(V_CKC + nm);
 #pragma unroll
@@ -580,10 +674,13 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     }
                 }
             }
+            BDRT_FINE(7);
+            BDRT_FINE_COUNT(16, ok && last);
             if (!ok) {
                 endt = 1;                                   // U-turn inside the new subtree: discard it, stop
             } else if (last) {
                 // subtree complete and valid (Stan base_nuts::transition after build_tree): extend the trajectory
+                dir_now = s.dir;
                 double *RHO = row(V_RHO);
                 double *THE = row(dir_now > 0 ? V_THP : V_THM), *PE = row(dir_now > 0 ? V_PP : V_PM);
                 double *GE = row(dir_now > 0 ? V_GP : V_GM);
@@ -596,6 +693,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                         const int j = l32 + 32 * m, jj = j;
                         rt_[m] = RHO[jj]; po_[m] = PO[jj]; th_[m] = TH[jj];
                     }
+                    if constexpr (GLDS) load_grad(g_);
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) {
                         const int j = l32 + 32 * m;
@@ -625,32 +723,36 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 }
             } else {
                 s.leaf = leaf_now + 1;
+                cont = true;
             }
         }
+        BDRT_FINE(8);
         if (endt) {
             next = nuts_transition_end(s, np, endt, draw, welf, wend, wn);     // (bdrt_nuts_device.h)
             if (draw >= 0 && a.lp_draws && valid && l32 == 0) a.lp_draws[(size_t)unit * np.n_draws + draw] = s.lps;
         }
+        BDRT_FINE(9);
         BDRT_NUTS_PROF(14);
         BDRT_WAVE_PROF(20);
 
         // ---- A' (common case): the trajectory continues from the point just evaluated: half kick + drift of the NEXT
-        //      leapfrog with p, g, Minv still in registers (theta is the only vector read; p is written once per leapfrog)
-        if (act && next == 0 && s.phase == PH_TREE) {
-            const double e1 = s.dir * s.eps;
-            {
-                double th_[NJ];
+        //      leapfrog with p, g, Minv still in registers (theta is the only vector read; p is written once per leapfrog).
+        //      Same direction, same step size: the signed step of this round.
+        if (cont) {
+            double th_[NJ];
 #pragma unroll
-                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; th_[m] = TH[j]; }
+            for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; th_[m] = TH[j]; }
+            if constexpr (GLDS) load_grad(g_);
 #pragma unroll
-                for (int m = 0; m < NJ; ++m) {
-                    const int j = l32 + 32 * m;
-                    const double p = p_[m] + 0.5 * e1 * g_[m];
-                    Pm[j] = p; TH[j] = th_[m] + e1 * mi_[m] * p;
-                }
+            for (int m = 0; m < NJ; ++m) {
+                const int j = l32 + 32 * m;
+                const double p = p_[m] + 0.5 * e * g_[m];
+                if (!(ndbg & 128)) Pm[j] = p;
+                TH[j] = th_[m] + e * mi_[m] * p;
             }
         }
 
+        BDRT_FINE(10);
         // ---- Z: momentum normals of the NEXT transition, ahead of time.  When some chain of the workgroup closes a subtree
         //      or a transition this round, every other wave would only wait for it at the round barrier; a wave whose own
         //      two chains are on the plain path uses that time to draw the 2*ceil(D/2) normals its chains need at their
@@ -674,6 +776,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 s.z_iter = (int)it1;
             }
         }
+        BDRT_FINE(11);
         BDRT_WAVE_PROF(21);
         // ---- E: sample update, metric adaptation, draw output, and the start of the next leapfrog when the trajectory does
         //      not simply continue (new transition, next doubling, step-size search, re-initialisation).  One batch of
@@ -790,6 +893,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     double et_[NJ], ep_[NJ], eg_[NJ];
                     if (dir == dir_now) {
                         // same direction again: that end of the trajectory is the point just evaluated (theta, p, grad are here)
+                        if constexpr (GLDS) load_grad(g_);
 #pragma unroll
                         for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; et_[m] = TH[j]; ep_[m] = p_[m]; eg_[m] = g_[m]; }
                     } else {
@@ -816,13 +920,15 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 }
             }
         }
+        BDRT_FINE(12);
         BDRT_NUTS_PROF(15);
         BDRT_NUTS_PROF(16);
 
         BDRT_WAVE_PROF(22);
         if (io.prof && lane == 0 && next) atomicAdd((unsigned long long *)&io.prof[24], 1ull);
         {
-            const int ph = s.phase;
+            if (cont) leaf_c = leaf_now + 1; else refresh_carried();
+            const int ph = ph_c;
             const bool running = ph == PH_INIT || ph == PH_EPS || ph == PH_TREE;
             if constexpr (FREE_RUN) {
                 if (l32 == 0) actf[c] = running ? 1 : 0;
@@ -838,6 +944,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 
     // ---- write the chain states back -----------------------------------------------------------------------------
     __syncthreads();
+    if (BDRT_PROF_FINE && io.prof && tid < 17) atomicAdd((unsigned long long *)&io.prof[tid], (unsigned long long)fine[tid]);
     if (MODE == 2) {
         double *THg = row(V_TH);
         for (int j = l32; j < D; j += 32) THg[j] = TH[j];

@@ -706,6 +706,13 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
 #define BDRT_S1_TRACE(slot) do { if (trc && (lane == 0)) trc[slot] = clock64(); } while (0)
     BDRT_S1_TRACE(0);
 #define BDRT_S1_PROF(slot) do { if (io.prof && tid == 0) { const long long t_ = clock64(); io.prof[slot] += t_ - tprev; tprev = t_; } } while (0)
+    // wait at the four barriers, summed over the workgroup's waves (slots 25..28 of the phase profile): the cost of the waves' skew;
+    // slots 29..31: the waves' own time from the entry to B1, from B1 to B2 and from B2 to B3 (B3 .. the end: the rest of the tile)
+    long long twe = io.prof ? clock64() : 0;
+#define BDRT_S1_BARRIER(slot, wslot) do { if (io.prof) { const long long tb_ = clock64(); __syncthreads(); const long long te_ = clock64(); \
+        if (lane == 0) { atomicAdd((unsigned long long *)&io.prof[slot], (unsigned long long)(te_ - tb_)); \
+                         if (wslot) atomicAdd((unsigned long long *)&io.prof[wslot], (unsigned long long)(tb_ - twe)); } \
+        twe = te_; } else __syncthreads(); } while (0)
 
     // ---- P1 (M1): parameters of this chain: scalars by lanes 0..8, x and ups rows coalesced -----------------------------
     double sraw = 0.0, st = 0.0;
@@ -797,7 +804,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     for (int step = 0; step < 2; ++step) {
     if (EARLY_P2 ? step == 1 : step == 0) {
         BDRT_S1_TRACE(1);
-        __syncthreads();                                               // B1: X of all 16 chains in the operand tile
+        BDRT_S1_BARRIER(25, 29);                                           // B1: X of all 16 chains in the operand tile
         after_x_ready();
         BDRT_S1_TRACE(2);
         BDRT_S1_PROF(1);
@@ -935,7 +942,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         }
     }
     BDRT_S1_TRACE(5);
-    __syncthreads();                                                   // B2: A x of all chains in Zh
+    BDRT_S1_BARRIER(26, 30);                                               // B2: A x of all chains in Zh
     BDRT_S1_TRACE(6);
     BDRT_S1_PROF(7);
 
@@ -1051,7 +1058,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         }
     }
     BDRT_S1_TRACE(7);
-    __syncthreads();                                                   // B3: g_Zhat of all chains in Zh
+    BDRT_S1_BARRIER(27, 31);                                               // B3: g_Zhat of all chains in Zh
     BDRT_S1_TRACE(8);
     BDRT_S1_PROF(4);
     before_backward();
@@ -1061,7 +1068,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         else gemm_sw<NWV, GPFV>(B.BkA, B.tilesK, B.rpairsA, Zh, Xs, wave, lane);                    // Xs = A^T g_Zhat
     }
     BDRT_S1_TRACE(9);
-    __syncthreads();                                                   // B4
+    BDRT_S1_BARRIER(28, 0);                                               // B4
     BDRT_S1_TRACE(10);
     BDRT_S1_PROF(8);
 

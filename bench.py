@@ -415,9 +415,21 @@ def main():
         rounds_total = args.steps * args.rounds
         for k, nm in enumerate(names):
             print('PHASE %-20s %6.2f %%  %9.0f cycles/round' % (nm, 100 * cyc[k] / tot, cyc[k] / n_wg / rounds_total), file=sys.stderr)
+        if os.environ.get('BDRT_BENCH_FINE') == '1':      # a library built with -DBDRT_PROF_FINE=1 (tools/build_variant.sh)
+            fn = ['C.a state + level-0 request', 'C.b gradient + kick', 'C.c sums', 'S1 scalar logic', 'D.a proposal copy', 'D.b merge level 0',
+                  'D.c merges of levels >= 1', 'D.d checkpoint store', 'D.e subtree end / leaf index', 'D.f transition end', "A' kick + drift",
+                  'Z normals ahead', 'E next start point']
+            for k, nm in enumerate(fn):
+                print('FINE %-32s %7.0f cycles/round (wave average)' % (nm, cyc[k] / n_wg / rounds_total / 8), file=sys.stderr)
+            for k, nm in zip((14, 15, 16), ('proposal copy', 'two levels or more', 'subtree end')):
+                print('FINE waves per round with %-20s %6.3f of 8' % (nm, cyc[k] / n_wg / rounds_total), file=sys.stderr)
         wnames = ['tile', 'C', 'S1', 'D', "A'", "E+S3+A''", 'end-of-round barrier wait']
         for k, nm in enumerate(wnames):
             print('WAVE-AVG %-26s %9.0f cycles/round' % (nm, cyc[17 + k] / n_wg / rounds_total / 8), file=sys.stderr)
+        for k, nm in enumerate(['B1 (X ready)', 'B2 (A x ready)', 'B3 (g ready)', 'B4 (A^T g ready)']):
+            print('WAVE-AVG wait at barrier %-17s %6.0f cycles/round' % (nm, cyc[25 + k] / n_wg / rounds_total / 8), file=sys.stderr)
+        for k, nm in enumerate(['entry -> B1 (P1, prior chain)', 'B1 -> B2 (forward GEMM)', 'B2 -> B3 (likelihood)']):
+            print('WAVE-AVG tile %-30s %6.0f cycles/round' % (nm, cyc[29 + k] / n_wg / rounds_total / 8), file=sys.stderr)
         print('half-waves per round in stage E (new start point): %.2f of 16' % (cyc[24] / n_wg / rounds_total * 2), file=sys.stderr)
     smp.close()
 
