@@ -67,6 +67,9 @@ __device__ __forceinline__ void lds_wave_sync()
 #ifndef BDRT_NUTS_ABLATE
 #define BDRT_NUTS_ABLATE 0
 #endif
+#ifndef BDRT_RESIDENT
+#define BDRT_RESIDENT 1
+#endif
 #ifndef BDRT_NUTS_EARLY_STATE
 #define BDRT_NUTS_EARLY_STATE 1
 #endif
@@ -205,6 +208,17 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         e_c = ph_c == PH_EPS ? s.eps : (ph_c == PH_TREE ? s.dir * s.eps : 0.0);
     };
     if constexpr (!SPEC) refresh_carried();
+    // RESIDENT (MODE 2, <= 11 elements per lane): the chain's momentum and inverse metric stay in the registers of its half-wave
+    // for the whole launch -- loaded here, written back behind the loop; the stages that set a new momentum (next start point,
+    // next doubling) set the registers as well as the row.  Two row reads and one row write less per leapfrog (33 of ~100
+    // vector-memory instructions per wave and round, 8 of 19 KB), no wait for them in front of the kick.
+    constexpr bool RESIDENT = BDRT_RESIDENT && MODE == 2 && !SPEC && NJ <= 11;
+    constexpr int NR = RESIDENT ? NJ : 1;
+    double pr_[NR], mir_[NR];
+    if constexpr (RESIDENT) {
+#pragma unroll
+        for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; pr_[m] = valid ? Pm[j] : 0.0; mir_[m] = valid ? MI[j] : 1.0; }
+    }
 
     for (int round = 0; round < a.rounds; ++round) {
         // keep per-lane address arithmetic inside the loop (see the note in bdrt_tile_s1.h): hoisted, it is spilled
@@ -233,8 +247,12 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         double p_[NA], g_[NA], mi_[NA];
 #pragma unroll
         for (int m = 0; m < NA; ++m) { p_[m] = 0.0; g_[m] = 0.0; mi_[m] = 1.0; }
+        if constexpr (RESIDENT) {
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) { p_[m] = pr_[m]; mi_[m] = mir_[m]; }
+        }
         auto load_state = [&]() {
-            if constexpr (!SPEC) {
+            if constexpr (!SPEC && !RESIDENT) {
                 if (act) {
 #pragma unroll
                     for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; p_[m] = Pm[j]; mi_[m] = MI[j]; }
@@ -497,7 +515,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         const bool deep = PRE0 && __builtin_amdgcn_ballot_w64(nm_pre >= 2) != 0;       // (wave-uniform)
         double pl0_[PRE0 ? NA : 1], alr_[PRE0 ? NA : 1], alp_[PRE0 ? NA : 1], blr_[PRE0 ? NA : 1], blp_[PRE0 ? NA : 1];
         if constexpr (PRE0) {
-            const double *PL0 = nm_pre >= 1 ? row(V_CKP) : Pm;
+            const double *PL0 = (RESIDENT || nm_pre >= 1) ? row(V_CKP) : Pm;      // (RESIDENT: the same row whatever the leaf)
 #pragma unroll
             for (int m = 0; m < NJ; ++m) pl0_[m] = PL0[l32 + 32 * m];
         }
@@ -545,7 +563,12 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         if constexpr (PRE0 && BDRT_PRE1) request_level(1, nm_pre, alr_, alp_);     // (under `if (deep)`: 150 bytes of spills)
         kin = 0.5 * half_sum(kin);
         // a non-finite gradient entry anywhere in the chain's half-wave: one ballot instead of a second butterfly
-        nonfin = ((__builtin_amdgcn_ballot_w64(bad_g) >> (lane & 32)) & 0xffffffffull) ? 1.0 : 0.0;
+        {
+            // (the half is picked through `c`, which is opaque per round: a mask made from `lane` is hoisted out of the round loop and spilled)
+            const unsigned long long bl = __builtin_amdgcn_ballot_w64(bad_g);
+            const unsigned half = (c & 1) ? (unsigned)(bl >> 32) : (unsigned)bl;
+            nonfin = half ? 1.0 : 0.0;
+        }
         BDRT_FINE(2);
         BDRT_NUTS_PROF(11);
         BDRT_WAVE_PROF(18);
@@ -747,7 +770,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             for (int m = 0; m < NJ; ++m) {
                 const int j = l32 + 32 * m;
                 const double p = p_[m] + 0.5 * e * g_[m];
-                if (!(ndbg & 128)) Pm[j] = p;
+                if constexpr (RESIDENT) p_[m] = p; else if (!(ndbg & 128)) Pm[j] = p;
                 TH[j] = th_[m] + e * mi_[m] * p;
             }
         }
@@ -883,7 +906,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                             rRHO[j] = p;
                         }
                         const double pk = p + 0.5 * e1 * gs_[m];
-                        Pm[j] = pk;
+                        if constexpr (RESIDENT) p_[m] = pk; else Pm[j] = pk;
                         TH[j] = ths_[m] + e1 * mi_[m] * pk;
                     }
                 } else if (next == 2) {
@@ -905,7 +928,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     for (int m = 0; m < NJ; ++m) {
                         const int j = l32 + 32 * m;
                         const double pk = ep_[m] + 0.5 * e1 * eg_[m];
-                        Pm[j] = pk;
+                        if constexpr (RESIDENT) p_[m] = pk; else Pm[j] = pk;
                         TH[j] = et_[m] + e1 * mi_[m] * pk;
                     }
                 } else if (next == 4) {
@@ -914,7 +937,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                         const int j = l32 + 32 * m;
                         if (j < D) {
                             TH[j] = np.init_radius * (2.0 * rng_uniform(rng, (uint32_t)j, RNG_INIT, 0, att, 0) - 1.0);
-                            Pm[j] = 0.0;
+                            if constexpr (RESIDENT) p_[m] = 0.0; else Pm[j] = 0.0;
                         }
                     }
                 }
@@ -926,6 +949,10 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 
         BDRT_WAVE_PROF(22);
         if (io.prof && lane == 0 && next) atomicAdd((unsigned long long *)&io.prof[24], 1ull);
+        if constexpr (RESIDENT) {
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) { pr_[m] = p_[m]; mir_[m] = mi_[m]; }
+        }
         {
             if (cont) leaf_c = leaf_now + 1; else refresh_carried();
             const int ph = ph_c;
@@ -948,6 +975,12 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     if (MODE == 2) {
         double *THg = row(V_TH);
         for (int j = l32; j < D; j += 32) THg[j] = TH[j];
+    }
+    if constexpr (RESIDENT) {
+        if (valid) {
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; Pm[j] = pr_[m]; }
+        }
     }
     if (l32 == 0 && valid) a.states[unit] = s;
     {
