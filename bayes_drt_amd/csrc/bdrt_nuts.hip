@@ -746,13 +746,16 @@ static int wide1_hot_rows(const Wide1Geom &G, int ds)
     return n;
 }
 
-static_assert((size_t)3 * NC * sizeof(double) + NC * sizeof(ChainState) + 3 * NC * sizeof(int) + 16 <= SAMPLER_LDS_RESERVE,
+// what the 16-chain kernel keeps beside the tile region: lp / hand-over cells, chain states, spectrum ids / offsets / flags, and
+// the uniforms of sixteen leaves per chain
+constexpr size_t NUTS16_SCALAR_LDS = (size_t)3 * NC * sizeof(double) + NC * sizeof(ChainState) + 3 * NC * sizeof(int) + 16 + (size_t)NC * 16 * sizeof(double);
+static_assert(NUTS16_SCALAR_LDS <= SAMPLER_LDS_RESERVE,
               "bdrt_problem_create reserves SAMPLER_LDS_RESERVE bytes for what the sampler keeps beside the tile region");
 static size_t nuts_lds_bytes(const DevProblem &P, bool s1)
 {
     const int nj = s1_nj(P.D);
     const size_t tile = s1 ? s1_lds_doubles(P) + (size_t)NC * 32 * nj : lds_doubles(P);   // s1: + theta rows
-    return (tile + (size_t)3 * NC) * sizeof(double) + NC * sizeof(ChainState) + 3 * NC * sizeof(int) + 16;
+    return tile * sizeof(double) + NUTS16_SCALAR_LDS;
 }
 
 int launch_logp_grad_few(Problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp, double *d_grad,
@@ -987,8 +990,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     S.s1_hbm = !S.use_s1 && P.dev.fast_s1 && P.dev.D <= 32 * 16;
     S.hw = P.dev.fast_hw && P.dev.D <= 32 * 27;
     if (S.s1_hbm || S.hw)
-        S.lds_bytes = ((S.hw ? hw_lds_doubles(P.dev) : s1_lds_doubles(P.dev)) + (size_t)3 * NC) * sizeof(double) + NC * sizeof(ChainState) +
-                      3 * NC * sizeof(int) + 16;
+        S.lds_bytes = (S.hw ? hw_lds_doubles(P.dev) : s1_lds_doubles(P.dev)) * sizeof(double) + NUTS16_SCALAR_LDS;
     else
         S.lds_bytes = nuts_lds_bytes(P.dev, S.use_s1);
     if (S.wide1 && !S.big) {

@@ -70,6 +70,11 @@ __device__ __forceinline__ void lds_wave_sync()
 #ifndef BDRT_RESIDENT
 #define BDRT_RESIDENT 1
 #endif
+// cache hints of the checkpoint traffic (bits): 1 the single-use reads of waiting siblings non-temporal, 2 the proposal copies
+// non-temporal stores, 4 the checkpoints of levels >= 3 non-temporal stores
+#ifndef BDRT_NT
+#define BDRT_NT 1
+#endif
 #ifndef BDRT_NUTS_EARLY_STATE
 #define BDRT_NUTS_EARLY_STATE 1
 #endif
@@ -102,6 +107,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     volatile int *slow = spec + NC;     // round stamp (round + 1) of the last round in which some chain did something long (see stage Z)
     int *thoff = spec + NC + 4;         // wide-vector path: offset of each chain's live theta row (0 or V_TH2 - V_TH rows)
     int *hvy = thoff + NC;              // wide-vector path: chains that the cooperative phase finishes (bdrt_nuts_wide.h)
+    double *ublk = reinterpret_cast<double *>(hvy + NC);     // register path: [NC][16] uniforms of sixteen consecutive leaves (stage S1)
     constexpr bool SPEC = NJ > 16 || (NJ > 11 && MODE < 2);      // wide-vector path (the S1 evaluator leaves room for 16 elements per lane)
     const int TH2OFF = (V_TH2 - V_TH) * NC * DS;
 
@@ -517,14 +523,18 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         if constexpr (PRE0) {
             const double *PL0 = (RESIDENT || nm_pre >= 1) ? row(V_CKP) : Pm;      // (RESIDENT: the same row whatever the leaf)
 #pragma unroll
-            for (int m = 0; m < NJ; ++m) pl0_[m] = PL0[l32 + 32 * m];
+            for (int m = 0; m < NJ; ++m) pl0_[m] = (BDRT_NT & 1) ? __builtin_nontemporal_load(PL0 + l32 + 32 * m) : PL0[l32 + 32 * m];
         }
         // the rows of level l into a buffer (a level the chain does not close aliases its momentum row: no load under a condition)
         auto request_level = [&](int l, int nmx, double (&lr_)[PRE0 ? NA : 1], double (&lp_)[PRE0 ? NA : 1]) {
             if constexpr (PRE0) {
                 const double *RA = l < nmx ? row(V_CKC + l) : Pm, *PA = l < nmx ? row(V_CKP + l) : Pm;
 #pragma unroll
-                for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; lr_[m] = RA[j]; lp_[m] = PA[j]; }
+                for (int m = 0; m < NJ; ++m) {
+                    const int j = l32 + 32 * m;
+                    if (BDRT_NT & 1) { lr_[m] = __builtin_nontemporal_load(RA + j); lp_[m] = __builtin_nontemporal_load(PA + j); }
+                    else { lr_[m] = RA[j]; lp_[m] = PA[j]; }
+                }
             }
         };
         // No element of the passes below is guarded by `j < D`: every state row is DS = 32 NJ long and its elements from D on are
@@ -599,7 +609,16 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                 next = nuts_stepsize_trial(s, np, lp, kin);
             } else {   // PH_TREE: one new leaf
                 if (l32 == 0) my_leaps += 1;
-                nuts_tree_leaf(h, np, rng, lp, kin, leaf_now, copyq, tree, nm, last, endt);      // (bdrt_nuts_device.h)
+                // The leaf's uniform (a Philox block: ~110 VALU instructions, the same in all 32 lanes) for SIXTEEN consecutive
+                // leaves at once: lane i of the chain draws leaf 16 b + i into the chain's LDS cells when a block of sixteen
+                // begins (a new subtree begins at leaf 0) and in the first round of a launch; same counters, same values.
+                if ((leaf_now & 15) == 0 || round == 0) {
+                    if (l32 < 16)
+                        ublk[c * 16 + l32] = rng_uniform(rng, (uint32_t)((leaf_now & ~15) + l32), RNG_LEAF, (uint32_t)h.depth, 0, (uint32_t)h.iter);
+                    lds_wave_sync();
+                }
+                const double u_leaf = ublk[c * 16 + (leaf_now & 15)];
+                nuts_tree_leaf(h, np, rng, lp, kin, leaf_now, copyq, tree, nm, last, endt, &u_leaf);      // (bdrt_nuts_device.h)
                 s.n_leap_iter = h.n_leap_iter; s.sum_metro = h.sum_metro;
                 if (tree) s.lsw_sub = h.lsw_sub;
                 if (copyq) s.lpq = h.lpq;
@@ -621,7 +640,10 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 #pragma unroll
                 for (int m = 0; m < NJ; ++m) {
                     const int j = l32 + 32 * m;
-                    if (copyq) { THQ[j] = th_[m]; GQ[j] = g_[m]; }
+                    if (copyq) {
+                        if (BDRT_NT & 2) { __builtin_nontemporal_store(th_[m], THQ + j); __builtin_nontemporal_store(g_[m], GQ + j); }
+                        else { THQ[j] = th_[m]; GQ[j] = g_[m]; }
+                    }
                     if (cur2s) { THS[j] = th_[m]; GS[j] = g_[m]; }
                 }
             }
@@ -690,10 +712,10 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                     // the sub-subtree of 2^nm leaves that ends here becomes the waiting left sibling of level nm
                     double *PLn = row(V_CKP + nm), *RLn = row(V_CKC + nm);
 #pragma unroll
-                    for (int m = 0; m < NJ; ++m) {
-                        const int j = l32 + 32 * m;
-                        PLn[j] = cpl_[m];
-                        if (nm > 0) RLn[j] = rc_[m];
+                    for (int m = 0; m < NJ; ++m) PLn[l32 + 32 * m] = cpl_[m];
+                    if (nm > 0) {
+#pragma unroll
+                        for (int m = 0; m < NJ; ++m) RLn[l32 + 32 * m] = rc_[m];
                     }
                 }
             }

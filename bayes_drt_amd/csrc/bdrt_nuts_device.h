@@ -226,9 +226,10 @@ __host__ __device__ inline int nuts_stepsize_trial(S &s, const NutsParams &np, d
 // divergence test, acceptance statistic, and the uniform sampling inside the subtree (keep leaf i with probability
 // w_i / W_i).  Outputs: endt = 2 on divergence; otherwise tree = true, copyq (this leaf becomes the subtree's proposal),
 // nm (trailing one bits of the leaf index = sub-subtrees that end here), last (the subtree is complete).
+// (u_pre: the leaf's uniform when the caller has drawn it ahead -- rng_uniform(rng, leaf_now, RNG_LEAF, depth, 0, iter) --, else nullptr)
 template <class S>
 __host__ __device__ inline void nuts_tree_leaf(S &s, const NutsParams &np, const Philox &rng, double lp, double kin, int leaf_now,
-                                               bool &copyq, bool &tree, int &nm, bool &last, int &endt)
+                                               bool &copyq, bool &tree, int &nm, bool &last, int &endt, const double *u_pre = nullptr)
 {
     s.n_leap_iter = s.n_leap_iter + 1;
     double h = -lp + kin;
@@ -242,7 +243,7 @@ __host__ __device__ inline void nuts_tree_leaf(S &s, const NutsParams &np, const
         return;
     }
     const double lsw_new = log_sum_exp2(s.lsw_sub, w);
-    const double u = rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
+    const double u = u_pre ? *u_pre : rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
     if (leaf_now == 0 || u < BDRT_NUTS_EXP(w - lsw_new)) { copyq = true; s.lpq = lp; }
     s.lsw_sub = lsw_new;
     tree = true;

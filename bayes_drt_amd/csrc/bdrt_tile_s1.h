@@ -796,16 +796,30 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
     // that is early spends the wait on its P2 -- VALU work that fills the issue slots the late waves' memory-bound bookkeeping
     // leaves -- instead of idling at B1 and then sharing the fp64 pipe with the forward GEMM (an fp64 MFMA occupies the SIMD's VALU
     // for its 64 cycles: MFMA and VALU work add up, whatever the order; tools/ubench/f64_overlap.hip).
+#ifndef BDRT_SPEC_EARLY
+#define BDRT_SPEC_EARLY 0
+#endif
 #ifndef BDRT_EARLY_P2
 #define BDRT_EARLY_P2 1
 #endif
     constexpr bool EARLY_P2 = BDRT_EARLY_P2 != 0;
+    double zre_[UNV], zim_[UNV], wn_[UNV];
+    auto load_spectrum = [&]() {
+        const int sp = io.spec ? io.spec[cc] : 0;
+        const double *Zm = P.Z + (size_t)sp * N2;
+#pragma unroll
+        for (int v = 0; v < UNV; ++v) {
+            const int n = l32 + LPC * v, nn = n < nf ? n : 0;
+            zre_[v] = Zm[nn]; zim_[v] = Zm[nf + nn]; wn_[v] = P.w[nn];
+        }
+    };
 #pragma unroll 1
     for (int step = 0; step < 2; ++step) {
     if (EARLY_P2 ? step == 1 : step == 0) {
         BDRT_S1_TRACE(1);
         BDRT_S1_BARRIER(25, 29);                                           // B1: X of all 16 chains in the operand tile
         after_x_ready();
+        if constexpr (BDRT_SPEC_EARLY) load_spectrum();
         BDRT_S1_TRACE(2);
         BDRT_S1_PROF(1);
         BDRT_S1_TRACE(3);
@@ -930,17 +944,9 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         }
     }
     }
-    // measured spectrum of this chain: issued before the barrier so that its latency hides behind the wait
-    double zre_[UNV], zim_[UNV], wn_[UNV];
-    {
-        const int sp = io.spec ? io.spec[cc] : 0;
-        const double *Zm = P.Z + (size_t)sp * N2;
-#pragma unroll
-        for (int v = 0; v < UNV; ++v) {
-            const int n = l32 + LPC * v, nn = n < nf ? n : 0;
-            zre_[v] = Zm[nn]; zim_[v] = Zm[nf + nn]; wn_[v] = P.w[nn];
-        }
-    }
+    // measured spectrum of this chain: requested in front of the forward GEMM (BDRT_SPEC_EARLY: right behind the first barrier, so
+    // that the round trip runs under the MFMAs; else in front of the second barrier, where only the wait hides it)
+    if constexpr (!(BDRT_SPEC_EARLY)) load_spectrum();
     BDRT_S1_TRACE(5);
     BDRT_S1_BARRIER(26, 30);                                               // B2: A x of all chains in Zh
     BDRT_S1_TRACE(6);
@@ -959,6 +965,7 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         const int rk = TA == 2 ? toep_gen_odd(K) : (TA ? (K & 15) : 0);
         double lk0 = 0.0, lk1 = 0.0;
         if (TA == 2) toep_zero_split_gen<false>(nf, K, Xs, tid); else if (TA) toep_zero_split<false>(nf, K, Xs, tid);
+        double pp_lo = 1.0, pp_hi = 1.0;
         // (the phase's LDS reads in one batch, from a clamped row: under `n < nf` each of them is a round trip of its own)
         double azr_[UNV], azi_[UNV], tk0r_[UNV], tk0i_[UNV], tk1r_[UNV], tk1i_[UNV];
 #pragma unroll
@@ -993,7 +1000,10 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
             const double e_re = zre_[v] - zr, e_im = zim_[v] - zi;
             const double prod = s2_re * s2_im, ip = lean_rcp(prod);       // one reciprocal and one logarithm per (re, im) pair
             const double w_re = s2_im * ip, w_im = s2_re * ip;
-            lp += -0.5 * lean_log(prod) - 0.5 * e_re * e_re * w_re - 0.5 * e_im * e_im * w_im;
+            // (the logarithm of the PRODUCT of two (re, im) pairs: one lean_log -- 33 instructions -- per two frequencies of the
+            // lane instead of one each; sigma_tot^8 stays far inside the double range for every point a trajectory visits)
+            if (v < UNV / 2) pp_lo *= prod; else pp_hi *= prod;
+            lp += -0.5 * e_re * e_re * w_re - 0.5 * e_im * e_im * w_im;
             const double h_re = -0.5 * w_re + 0.5 * e_re * e_re * w_re * w_re;
             const double h_im = -0.5 * w_im + 0.5 * e_im * e_im * w_im * w_im;
             const double gzr = e_re * w_re + 2.0 * zr * (h_re * (ap2 + ar2) + h_im * ar2);
@@ -1027,6 +1037,8 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
                 io.sigma_tot[(size_t)c * N2 + nf + n] = sqrt(s2_im);
             }
         }
+        lp += -0.5 * lean_log(pp_lo);
+        if (nf > LPC * (UNV / 2)) lp += -0.5 * lean_log(pp_hi);
         // the six sums, the odd row of A^T g and the chain's log-posterior (complete by now) in one butterfly: lane j gets sum j
         double dl = 0.0;
         if constexpr (LPC == 32) {
