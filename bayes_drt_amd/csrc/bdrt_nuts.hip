@@ -44,7 +44,7 @@ int launch_wave_eval(const DevProblem *dp, const WaveGeom &g, const double *d_th
 namespace bdrt {
 // (defined in bdrt_nuts_k0.hip .. bdrt_nuts_k4.hip)
 BDRT_NUTS16_G0(BDRT_NUTS16_DECLARE) BDRT_NUTS16_G1(BDRT_NUTS16_DECLARE) BDRT_NUTS16_G2(BDRT_NUTS16_DECLARE)
-BDRT_NUTS16_G3(BDRT_NUTS16_DECLARE) BDRT_NUTS16_G4(BDRT_NUTS16_DECLARE)
+BDRT_NUTS16_G3(BDRT_NUTS16_DECLARE) BDRT_NUTS16_G4(BDRT_NUTS16_DECLARE) BDRT_NUTS16_G5(BDRT_NUTS16_DECLARE_PROF)
 
 
 
@@ -1095,7 +1095,9 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     static LdsAttrCache attr_cache;
     const hipError_t ae = attr_cache.ensure(S.lds_bytes, [&]() {
-        const void *fns[34] = {(const void *)nuts_kernel<4, 2, 2>, (const void *)nuts_kernel<6, 2, 2>, (const void *)nuts_kernel<7, 2, 2>,
+        const void *fns[38] = {(const void *)nuts_kernel<11, 2, 1, true>, (const void *)nuts_kernel<11, 2, 2, true>,
+                               (const void *)nuts_kernel<7, 2, 2, true>, (const void *)nuts_kernel<27, 4, 0, true>,
+                               (const void *)nuts_kernel<4, 2, 2>, (const void *)nuts_kernel<6, 2, 2>, (const void *)nuts_kernel<7, 2, 2>,
                                (const void *)nuts_kernel<4, 2, 0>, (const void *)nuts_kernel<6, 2, 0>, (const void *)nuts_kernel<7, 2, 0>,
                                (const void *)nuts_kernel<6, 2, 1>,
                                (const void *)nuts_kernel<11, 2, 2>, (const void *)nuts_kernel<16, 2, 2>,
@@ -1115,7 +1117,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
             e = hipFuncSetAttribute((const void *)nuts_solo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)nuts_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
-        for (int i = 0; i < 34 && e == hipSuccess; ++i)
+        for (int i = 0; i < 38 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         return e;
     });
@@ -1192,12 +1194,19 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
         else if (S.use_s1) {
             const int nj = S.args.ds / 32, ta = S.prob->dev.toepA;
 #define BDRT_S1_NUTS(NJ_, TA_) hipLaunchKernelGGL((nuts_kernel<NJ_, 2, TA_>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args)
+#define BDRT_S1_NUTS_PROF(NJ_, TA_) hipLaunchKernelGGL((nuts_kernel<NJ_, 2, TA_, true>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args)
+            // (the phase profile is filled by the profiling instantiations: the headline family's and BASELINE config 5's)
+            if (S.args.prof && nj == 11 && ta == 1) BDRT_S1_NUTS_PROF(11, 1);
+            else if (S.args.prof && nj == 11 && ta == 2) BDRT_S1_NUTS_PROF(11, 2);
+            else if (S.args.prof && nj == 7 && ta == 2) BDRT_S1_NUTS_PROF(7, 2);
+            else
             if (nj == 4) { if (ta == 2) BDRT_S1_NUTS(4, 2); else BDRT_S1_NUTS(4, 0); }
             else if (nj == 6) { if (ta == 2) BDRT_S1_NUTS(6, 2); else if (ta == 1) BDRT_S1_NUTS(6, 1); else BDRT_S1_NUTS(6, 0); }
             else if (nj == 7) { if (ta == 2) BDRT_S1_NUTS(7, 2); else BDRT_S1_NUTS(7, 0); }
             else if (nj == 11) { if (ta == 2) BDRT_S1_NUTS(11, 2); else if (ta == 1) BDRT_S1_NUTS(11, 1); else BDRT_S1_NUTS(11, 0); }
             else { if (ta == 2) BDRT_S1_NUTS(16, 2); else if (ta == 1) BDRT_S1_NUTS(16, 1); else BDRT_S1_NUTS(16, 0); }
 #undef BDRT_S1_NUTS
+#undef BDRT_S1_NUTS_PROF
         }
         else if (S.s1_hbm || S.hw) {
             // the evaluator's instantiation by the longest basis (3, 4 or 6 basis functions per lane)
@@ -1210,6 +1219,7 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             if (S.s1_hbm) { if (nj == 11) BDRT_X_KU(11, 3); else BDRT_X_KU(16, 3); }
             else if (nj == 11) BDRT_X_KU(11, 4);
             else if (nj == 16) BDRT_X_KU(16, 4);
+            else if (S.args.prof && ku == 0) hipLaunchKernelGGL((nuts_kernel<27, 4, 0, true>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);
             else BDRT_X_KU(27, 4);
 #undef BDRT_X_KU
 #undef BDRT_X_NUTS

@@ -78,7 +78,10 @@ __device__ __forceinline__ void lds_wave_sync()
 #ifndef BDRT_NUTS_EARLY_STATE
 #define BDRT_NUTS_EARLY_STATE 1
 #endif
-template <int NJ, int MODE, int TA = 0>   // MODE 0: dense L, 1: structured L (generic tile), 2: S1 tile + theta rows in LDS, 3: S1 tile, state in HBM, 4: general half-wave tile
+// PROF: the instantiation that fills the phase profile (NutsArgs::prof).  The measurement kernel is a kernel of its own: with a
+// run-time `if (prof)` in front of every stamp the production kernel carries ~25 scalar branches per round, two copies of
+// every barrier of the evaluator, and basic-block boundaries the scheduler cannot move loads across.
+template <int NJ, int MODE, int TA = 0, bool PROF = false>   // MODE 0: dense L, 1: structured L (generic tile), 2: S1 tile + theta rows in LDS, 3: S1 tile, state in HBM, 4: general half-wave tile
 __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     io.nvalid = NC;            // padded columns carry a DONE state and finite vectors
     io.jacobian = 1;
     io.Z_hat = nullptr; io.sigma_tot = nullptr; io.params = nullptr;
-    io.prof = a.prof ? a.prof + (size_t)wg * 32 : nullptr;
+    io.prof = (PROF && a.prof) ? a.prof + (size_t)wg * 32 : nullptr;
     long long tnp = 0;
 #define BDRT_NUTS_PROF(slot) do { if (!BDRT_PROF_FINE && io.prof && tid == 0) { const long long t_ = clock64(); io.prof[slot] += t_ - tnp; tnp = t_; } } while (0)
     // per-wave stage times (slots 17..24, summed over the 8 waves): where each wave spends the round, incl. the barrier wait
@@ -1026,7 +1029,11 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
 #define BDRT_NUTS16_G2(X) X(11, 1, 0) X(11, 0, 0) X(16, 1, 0) X(16, 0, 0) X(27, 1, 0) X(27, 0, 0)
 #define BDRT_NUTS16_G3(X) X(11, 3, 0) X(16, 3, 0) X(11, 3, 3) X(16, 3, 3) X(11, 3, 4) X(16, 3, 4)
 #define BDRT_NUTS16_G4(X) X(11, 4, 0) X(16, 4, 0) X(27, 4, 0) X(11, 4, 3) X(16, 4, 3) X(27, 4, 3) X(11, 4, 4) X(16, 4, 4) X(27, 4, 4)
-#define BDRT_NUTS16_DEFINE(NJ_, MODE_, TA_) template __global__ void nuts_kernel<NJ_, MODE_, TA_>(const DevProblem *__restrict__, NutsParams, NutsArgs);
-#define BDRT_NUTS16_DECLARE(NJ_, MODE_, TA_) extern template __global__ void nuts_kernel<NJ_, MODE_, TA_>(const DevProblem *__restrict__, NutsParams, NutsArgs);
+// (group 5: the profiling instantiations -- the headline family and BASELINE config 5's; other kernels leave the profile empty)
+#define BDRT_NUTS16_G5(X) X(11, 2, 1) X(11, 2, 2) X(7, 2, 2) X(27, 4, 0)
+#define BDRT_NUTS16_DEFINE(NJ_, MODE_, TA_) template __global__ void nuts_kernel<NJ_, MODE_, TA_, false>(const DevProblem *__restrict__, NutsParams, NutsArgs);
+#define BDRT_NUTS16_DECLARE(NJ_, MODE_, TA_) extern template __global__ void nuts_kernel<NJ_, MODE_, TA_, false>(const DevProblem *__restrict__, NutsParams, NutsArgs);
+#define BDRT_NUTS16_DEFINE_PROF(NJ_, MODE_, TA_) template __global__ void nuts_kernel<NJ_, MODE_, TA_, true>(const DevProblem *__restrict__, NutsParams, NutsArgs);
+#define BDRT_NUTS16_DECLARE_PROF(NJ_, MODE_, TA_) extern template __global__ void nuts_kernel<NJ_, MODE_, TA_, true>(const DevProblem *__restrict__, NutsParams, NutsArgs);
 
 }  // namespace bdrt
