@@ -53,7 +53,7 @@ BDRT_NUTS16_G3(BDRT_NUTS16_DECLARE) BDRT_NUTS16_G4(BDRT_NUTS16_DECLARE) BDRT_NUT
 // all vectors in LDS.  Global state layout: vecs [n_units][SG_COUNT][ds]; states [n_units].
 // ---------------------------------------------------------------------------------------------------------------------------
 
-template <int WPE>   // waves per SIMD the register budget allows: 2 = one workgroup per CU, 4 = two (when their LDS fits)
+template <int WPE, bool PROF = false>   // waves per SIMD the register budget allows: 2 = one workgroup per CU, 4 = two (when their LDS fits); PROF: fills the phase profile
 __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, SoloGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
         const double e = ph0 == PH_EPS ? s.eps : (ph0 == PH_TREE ? s.dir * s.eps : 0.0);
 
         // ---- B: log-posterior + gradient at the new point ------------------------------------------------------------------
-        long long *prof = a.prof ? a.prof + (size_t)unit * 32 : nullptr;
+        long long *prof = (PROF && a.prof) ? a.prof + (size_t)unit * 32 : nullptr;
         // the uniform that decides whether this leaf replaces the subtree's proposal depends on (leaf, depth, iteration)
         // only: wave 7, which has no per-element work in the first phases of the evaluation, draws it now (Philox, ~200
         // integer instructions) and publishes it through LDS, off the other waves' critical path
@@ -436,6 +436,7 @@ __host__ __device__ inline size_t wide1_lds_bytes(const Wide1Geom &G, int ds, in
 
 static_assert((W1_SCRATCH + 2) * sizeof(double) + sizeof(ChainState) + 128 <= 16384, "wide1_capable (bdrt_solo_wide.h) leaves 16 KiB beside the evaluator");
 
+template <bool PROF = false>
 __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, Wide1Geom G, int nhot)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
     for (int round = 0; round < a.rounds; ++round) {
         const int ph = sts[0].phase;
         if (!(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)) break;
-        long long *prof = a.prof ? a.prof + (size_t)wg * 32 : nullptr;       // slots 0 / 1: evaluation / everything after it (thread 0)
+        long long *prof = (PROF && a.prof) ? a.prof + (size_t)wg * 32 : nullptr;       // slots 0 / 1: evaluation / everything after it (thread 0)
         const long long t0 = (prof && tid == 0) ? clock64() : 0;
         wide1_eval(P, G, smem, row(V_TH), row(V_G), lpn, er, 1, tid, prof);
         const long long t1 = (prof && tid == 0) ? clock64() : 0;
@@ -1116,7 +1117,13 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)nuts_solo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)nuts_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
+            e = hipFuncSetAttribute((const void *)nuts_solo_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)nuts_solo_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)nuts_wide1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)nuts_wide1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         for (int i = 0; i < 38 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)S.lds_bytes);
         return e;
@@ -1167,8 +1174,11 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
         } while (0)
         if (S.big)
             hipLaunchKernelGGL(nuts_big_kernel, dim3(S.n_wg), dim3(SOLO_NT), nuts_big_lds_bytes(), S.stream, dp, S.np, S.args);
+        else if (S.wide1 && S.args.prof)
+            hipLaunchKernelGGL(nuts_wide1_kernel<true>, dim3(S.n_wg), dim3(SOLO_NT), wide1_lds_bytes(S.geom1, S.args.ds, S.nhot1), S.stream, dp,
+                               S.np, S.args, S.geom1, S.nhot1);
         else if (S.wide1)
-            hipLaunchKernelGGL(nuts_wide1_kernel, dim3(S.n_wg), dim3(SOLO_NT), wide1_lds_bytes(S.geom1, S.args.ds, S.nhot1), S.stream, dp,
+            hipLaunchKernelGGL(nuts_wide1_kernel<false>, dim3(S.n_wg), dim3(SOLO_NT), wide1_lds_bytes(S.geom1, S.args.ds, S.nhot1), S.stream, dp,
                                S.np, S.args, S.geom1, S.nhot1);
         else if (S.solo && S.wave && (S.wave_force == 1 || !S.solo_ok || wave_pays(S.live, S.n_cu)))
         {
@@ -1186,8 +1196,12 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             const size_t lds2 = ((size_t)S.geom.o_vec + (size_t)SOLO_NHOT * S.geom.DSS) * sizeof(double) + 64;
             const char *e = getenv("BDRT_SOLO_DUO");
             const bool duo = 2 * lds2 <= 160 * 1024 && (e ? atoi(e) != 0 : S.n_solo > S.n_cu);
-            if (duo)
+            if (duo && S.args.prof)
+                hipLaunchKernelGGL((nuts_solo_kernel<4, true>), dim3(S.n_solo), dim3(SOLO_NT), lds2, S.stream, dp, S.np, S.args, S.geom);
+            else if (duo)
                 hipLaunchKernelGGL(nuts_solo_kernel<4>, dim3(S.n_solo), dim3(SOLO_NT), lds2, S.stream, dp, S.np, S.args, S.geom);
+            else if (S.args.prof)
+                hipLaunchKernelGGL((nuts_solo_kernel<2, true>), dim3(S.n_solo), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
             else
                 hipLaunchKernelGGL(nuts_solo_kernel<2>, dim3(S.n_solo), dim3(SOLO_NT), S.lds_bytes, S.stream, dp, S.np, S.args, S.geom);
         }

@@ -26,6 +26,7 @@ static hipError_t wave_set_lds_limit(size_t bytes)
         hipError_t e = hipSuccess;
 #define BDRT_WV_ATTR(KS_, NS_)                                                                                                        \
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nuts_wave_kernel<KS_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nuts_wave_kernel<KS_, NS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)wave_eval_kernel<KS_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         BDRT_WV_ATTR(1, 1) BDRT_WV_ATTR(1, 2) BDRT_WV_ATTR(2, 1) BDRT_WV_ATTR(2, 2) BDRT_WV_ATTR(3, 1) BDRT_WV_ATTR(3, 2)
 #undef BDRT_WV_ATTR
@@ -60,8 +61,11 @@ int launch_wave_nuts(const DevProblem *dp, const NutsParams &np, const NutsArgs 
 {
     BDRT_HIP(wave_set_lds_limit(lds));
 #define BDRT_WV_CALL(KS_, NS_) hipLaunchKernelGGL((nuts_wave_kernel<KS_, NS_>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, np, args, g, nhot)
-    BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL);
+#define BDRT_WV_CALL_PROF(KS_, NS_) hipLaunchKernelGGL((nuts_wave_kernel<KS_, NS_, true>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, np, args, g, nhot)
+    if (args.prof) BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL_PROF);
+    else BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL);
 #undef BDRT_WV_CALL
+#undef BDRT_WV_CALL_PROF
     BDRT_HIP(hipGetLastError());
     return 0;
 }

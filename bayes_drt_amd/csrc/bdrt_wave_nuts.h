@@ -10,7 +10,8 @@ namespace bdrt {
 typedef __attribute__((address_space(3))) double wv_lds_d;
 typedef __attribute__((address_space(1))) double wv_glb_d;
 
-template <int KS, int NS>
+// PROF: the instantiation that fills the phase profile (a kernel of its own: see nuts_kernel, bdrt_nuts16.h)
+template <int KS, int NS, bool PROF = false>
 __global__ __launch_bounds__(WV_NT, 2) void nuts_wave_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, WaveGeom g, int nhot)
 {
     constexpr int NJ = 2 * KS + 1;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(WV_NT, 2) void nuts_wave_kernel(const DevProblem *_
     // uniforms of 64 consecutive leaves of a subtree at once (lane l: leaf 64 b + l), refreshed when the key changes
     double uvec = 0.0;
     int u_iter = -1, u_depth = -1, u_blk = -1;
-    long long *prof = a.prof ? a.prof + (size_t)blockIdx.x * 32 : nullptr;
+    long long *prof = (PROF && a.prof) ? a.prof + (size_t)blockIdx.x * 32 : nullptr;
 
     for (int round = 0; round < a.rounds; ++round) {
         const int ph0 = s.phase;

@@ -758,6 +758,25 @@ class Inverter:
             'LBFGS' -- Stan's L-BFGS(5) with Stan's line search and termination tests alone, i.e. the kind of iterate the
             reference's `optimizing` call returns."""
         self._fit_argument_checks(part, mode, fitY, SA, SASY, n_starts, algorithm)
+        job = self._fit_prepare(frequencies, Z, part, scale_Z, nonneg, outliers, init_from_ridge, ridge_kw, sigma_min,
+                                inductance_scale, outlier_lambda, mode, add_stan_data, model_str, fitY, SA, SASY, n_starts)
+        model, dat = job['model'], job['dat']
+        if mode == 'optimize':
+            self._opt_result = model.optimizing(dat, iter=max_iter, seed=random_seed, init=job['init'],
+                                                extra_inits=job['extra_inits'], algorithm=algorithm or 'LBFGS+Newton')
+            self._opt_report = model.last_report
+        else:
+            self._sample_result = model.sampling(dat, warmup=warmup, iter=warmup + samples, chains=chains,
+                                                 seed=random_seed, init=job['init'], control=dict(self._NUTS_CONTROL))
+        self._fit_finish(job, mode, sigma_min, check_outliers)
+
+    _NUTS_CONTROL = {'adapt_delta': 0.9, 'adapt_t0': 10}        # reference :1221
+
+    def _fit_prepare(self, frequencies, Z, part, scale_Z, nonneg, outliers, init_from_ridge, ridge_kw, sigma_min,
+                     inductance_scale, outlier_lambda, mode, add_stan_data, model_str, fitY, SA, SASY, n_starts):
+        """Everything `fit` does on the host before the engine runs (reference :1153-1214): initial values, matrices, model
+        selection, the Stan data dict.  Sets the training attributes of this instance; returns the job description that
+        `fit` hands to one engine call and `fit_many` to one batched call for all spectra."""
         _validate_spectrum(frequencies, Z)
         init = 'random'
         if init_from_ridge:
@@ -787,20 +806,181 @@ class Inverter:
         if outliers and model_type == 'Series':
             dat['N'] = len(frequencies)        # package Series outlier models declare N = Nf (:1208-1211)
         self._stan_input = dat.copy()
-        if mode == 'optimize':
-            self._opt_result = model.optimizing(dat, iter=max_iter, seed=random_seed, init=init, extra_inits=extra_inits,
-                                                algorithm=algorithm or 'LBFGS+Newton')
-            self._opt_report = model.last_report
-        else:
-            self._sample_result = model.sampling(dat, warmup=warmup, iter=warmup + samples, chains=chains,
-                                                 seed=random_seed, init=init,
-                                                 control={'adapt_delta': 0.9, 'adapt_t0': 10})
-        self._store_bayes_fit(model_type, mode, sigma_min, outliers)
-        if outliers == False and check_outliers:
+        return dict(model=model, model_str=model_str, model_type=model_type, dat=dat, init=init, extra_inits=extra_inits,
+                    outliers=outliers, frequencies=frequencies)
+
+    def _fit_finish(self, job, mode, sigma_min, check_outliers):
+        """Engine result (`_opt_result` / `_sample_result` of this instance) -> fit attributes, then the outlier check of
+        the reference (:1223-1289)."""
+        self._store_bayes_fit(job['model_type'], mode, sigma_min, job['outliers'])
+        frequencies = job['frequencies']
+        if job['outliers'] == False and check_outliers:
             idx = self.check_outliers(frequencies, self.Z_train, threshold=3.5, use_existing_fit=True)
             if len(idx) > 0:
                 warnings.warn('Possible outliers were identified at indices {}, f={} Hz. Check the residuals and consider '
                               're-running with outliers=True'.format(idx, frequencies[idx]))
+
+    def fit_many(self, frequencies, Z_list, part='both', scale_Z=True, nonneg=False, outliers=False, check_outliers=True,
+                 init_from_ridge=False, ridge_kw={}, sigma_min=0.002, inductance_scale=1, outlier_lambda=None,
+                 mode='optimize', random_seed=1234, max_iter=50000, warmup=200, samples=200, chains=2, add_stan_data={},
+                 model_str=None, n_starts=None, algorithm=None, group=None):
+        """The fits `[copy(self).fit(frequencies, Z, ...) for Z in Z_list]` -- the reference's own workload is such a loop
+        over spectra measured on one frequency grid (code_EchemActa/Run fits.ipynb cells 4-5, inversion.py:1072-1081,
+        :1218-1221) -- as ONE batch: one shared problem in HBM (the matrices are those of the common grid), every
+        (spectrum, chain) unit of mode='sample' in one device-resident sampler, every (spectrum, start) fit of
+        mode='optimize' in one lock-step batch.  Inside an initialised torch.distributed process group with more than one
+        rank (or with `group` given) the units are sharded over the ranks' GPUs (`parallel.sample_sharded`: one broadcast
+        of the problem, one scatter of the spectra, one gather of the results over RCCL); every rank returns the same list.
+
+        Arguments as `fit`.  Each spectrum is scaled and weighted exactly as `fit` does it, and the random streams depend on
+        (random_seed, chain) only: the result of spectrum i equals that of a separate `fit` call (same draws, same MAP).
+        Returns a list of Inverter objects (shallow copies of this one) carrying the fit attributes of `fit`, readable
+        through `predict_*`, `coef_percentile`, ...; this instance itself is left as it was."""
+        self._fit_argument_checks(part, mode, False, False, False, n_starts, algorithm)
+        views, jobs = self._batch_jobs(frequencies, Z_list, part, scale_Z, nonneg, outliers, init_from_ridge, ridge_kw, sigma_min,
+                                       inductance_scale, outlier_lambda, mode, add_stan_data, model_str, n_starts)
+        if not views:
+            return []
+        # spectra that resolve to the same model (outliers='auto' may choose differently per spectrum) share a batch
+        order = {}
+        for i, job in enumerate(jobs):
+            order.setdefault(job['model_str'], []).append(i)
+        for name, idx in order.items():
+            self._fit_batch([views[i] for i in idx], [jobs[i] for i in idx], mode, random_seed, max_iter, warmup, samples,
+                            chains, algorithm, group)
+        for inv, job in zip(views, jobs):
+            inv._fit_finish(job, mode, sigma_min, check_outliers)
+        return views
+
+    def _batch_jobs(self, frequencies, Z_list, part, scale_Z, nonneg, outliers, init_from_ridge, ridge_kw, sigma_min,
+                    inductance_scale, outlier_lambda, mode, add_stan_data, model_str, n_starts):
+        """`_fit_prepare` for every spectrum of a batch, each on a shallow copy of this instance (the copies share the matrix
+        cache of the common grid: nothing is built twice).  Returns (views, jobs)."""
+        import copy
+        views, jobs = [], []
+        base = self
+        for Z in Z_list:
+            inv = copy.copy(base)
+            job = inv._fit_prepare(frequencies, np.asarray(Z), part, scale_Z, nonneg, outliers, init_from_ridge, ridge_kw, sigma_min,
+                                   inductance_scale, outlier_lambda, mode, add_stan_data, model_str, False, False, False, n_starts)
+            views.append(inv); jobs.append(job)
+            base = inv
+        return views, jobs
+
+    @staticmethod
+    def _stack_stan_data(jobs):
+        """One Stan data dict for spectra that share everything but Z: 'Z' becomes [n_spectra, 2 Nf]."""
+        d0 = jobs[0]['dat']
+        for job in jobs[1:]:
+            if set(job['dat']) != set(d0):
+                raise ValueError('fit_many: the spectra do not share one model')
+            for k, v in job['dat'].items():
+                if k != 'Z' and not np.array_equal(np.asarray(v), np.asarray(d0[k])):
+                    raise ValueError('fit_many: the spectra do not share the Stan data entry %r (one frequency grid, one '
+                                     'basis and one set of options per call)' % k)
+        dat = dict(d0)
+        dat['Z'] = np.vstack([np.asarray(job['dat']['Z'], dtype=float).reshape(1, -1) for job in jobs])
+        return dat
+
+    def batch_stan_data(self, frequencies, Z_list, part='both', scale_Z=True, nonneg=False, outliers=False, sigma_min=0.002,
+                        inductance_scale=1, outlier_lambda=None, mode='sample', add_stan_data={}):
+        """(model file name, Stan data dict with 'Z' = [n_spectra, 2 Nf]) of the batch `fit_many` would run: every spectrum scaled
+        and weighted as `fit` does it (reference :1153-1214).  For callers that drive the engine themselves (bench.py)."""
+        _, jobs = self._batch_jobs(frequencies, Z_list, part, scale_Z, nonneg, outliers, False, {}, sigma_min, inductance_scale,
+                                   outlier_lambda, mode, add_stan_data, None, 1)
+        if len({job['model_str'] for job in jobs}) != 1:
+            raise ValueError('batch_stan_data: the spectra resolve to different models')
+        return jobs[0]['model_str'], self._stack_stan_data(jobs)
+
+    @staticmethod
+    def _fit_batch(views, jobs, mode, random_seed, max_iter, warmup, samples, chains, algorithm, group):
+        """One engine call for the spectra of one model: fills `_opt_result` / `_sample_result` of every view."""
+        import ctypes as C
+        from . import engine, parallel
+        from ._lib import NutsControl
+        ns = len(jobs)
+        dat = Inverter._stack_stan_data(jobs)
+        model = jobs[0]['model']
+        P = model._prepare(dat)
+        world = 1
+        dist = None
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                world = dist.get_world_size(group)
+        except ImportError:
+            pass
+        if mode == 'optimize':
+            # rows: for each spectrum its designated start, then its extra starts -- the rows `optimizing` builds for one fit
+            rows, owner = [], []
+            for i, job in enumerate(jobs):
+                r = [model._init_theta(job['init'], 1, random_seed)]
+                for e in job['extra_inits']:
+                    try:
+                        if isinstance(e, tuple) and e[0] == 'random':
+                            r.append(model._init_theta('random', 1, random_seed + int(e[1])))
+                        else:
+                            r.append(model._init_theta(e, 1, random_seed))
+                    except ValueError:
+                        pass
+                rows += r; owner += [i] * len(r)
+            theta0 = np.vstack(rows)
+            owner = np.asarray(owner, dtype=np.int32)
+            opts = {}
+            alg = algorithm or 'LBFGS+Newton'
+            if alg == 'LBFGS':
+                opts['newton_max_iter'] = 0
+            if world > 1:
+                rank = dist.get_rank(group)
+                lo, hi = parallel.shard_bounds(len(owner), world, rank)
+                out_l, rep_l = (engine.optimize_batch(P, theta0[lo:hi], spec=owner[lo:hi], max_iter=max_iter, **opts)
+                                if hi > lo else (np.zeros((0, P.D)), []))
+                keys = ('iterations', 'n_evals', 'return_code', 'lp', 'grad_norm', 'newton_iterations', 'grad_inf')
+                loc = np.array([[r[k] for k in keys] for r in rep_l], dtype=float).reshape(hi - lo, len(keys))
+                counts = [b - a for a, b in (parallel.shard_bounds(len(owner), world, r) for r in range(world))]
+                out = parallel.gather_rows(out_l, counts, group)
+                rep = parallel.gather_rows(loc, counts, group)
+                reports = [dict((k, (int(v) if k in ('iterations', 'n_evals', 'return_code', 'newton_iterations') else float(v)))
+                                for k, v in zip(keys, row)) for row in rep]
+            else:
+                out, reports = engine.optimize_batch(P, theta0, spec=owner, max_iter=max_iter, **opts)
+            for i, inv in enumerate(views):
+                sel = np.nonzero(owner == i)[0]
+                best = 0
+                for j in range(1, len(sel)):                       # the rule of StanModel.optimizing
+                    a, b = reports[sel[j]], reports[sel[best]]
+                    higher = np.isfinite(a['lp']) and (not np.isfinite(b['lp']) or a['lp'] > b['lp'] + 1e-6 * max(1.0, abs(b['lp'])))
+                    if higher and (a['return_code'] == 0 or b['return_code'] != 0):
+                        best = j
+                inv._opt_result = model.result_dict(out[sel[best]])
+                inv._opt_report = dict(reports[sel[best]], start=best, starts=[reports[k] for k in sel])
+            return
+        # ---- mode == 'sample'
+        n_draws = int(samples)
+        spec, chain = parallel.make_units(ns, chains)
+        init_theta = None
+        if any(not (isinstance(job['init'], str) and job['init'] == 'random') for job in jobs):
+            init_theta = np.vstack([model._init_theta(job['init'], chains, random_seed) for job in jobs])
+        control = dict(Inverter._NUTS_CONTROL)
+        if world > 1:
+            blocks, kw, _ = engine.blocks_from_dat(model.model_name, dat)
+            pk = dict(kw, blocks=blocks, Z=np.asarray(dat['Z'], dtype=float), freq=np.asarray(dat['freq'], dtype=float))
+            res = parallel.sample_sharded(pk if dist.get_rank(group) == 0 else None, ns, chains, warmup, n_draws, seed=random_seed,
+                                          control=control, group=group, gather='draws', init_theta=init_theta)
+            draws, lp = res['draws'], res['lp']
+            diag = [dict(n_leapfrog=int(r[0]), n_divergent=int(r[1]), n_max_treedepth=int(r[2]), stepsize=float(r[3]),
+                         mean_accept=float(r[4])) for r in res['stats']]
+        else:
+            ctrl = NutsControl()
+            P._lib.bdrt_nuts_defaults(C.byref(ctrl))
+            for k, v in control.items():
+                setattr(ctrl, k, v)
+            draws, lp, diag = engine.sample_units(P, ns * chains, warmup, n_draws, random_seed, ctrl, spec=spec, chain_ids=chain,
+                                                  init_theta=init_theta)
+        for i, inv in enumerate(views):
+            u0, u1 = i * chains, (i + 1) * chains
+            inv._sample_result = engine.StanFit(model, draws[u0:u1].reshape(chains * n_draws, P.D), lp[u0:u1].reshape(-1),
+                                                diag[u0:u1], chains, n_draws)
 
     @staticmethod
     def _fit_argument_checks(part, mode, fitY, SA, SASY, n_starts, algorithm):
@@ -1092,7 +1272,15 @@ class Inverter:
                 B = store['B'].copy()
             dist_mat[name] = {}
             fb = 1 / (2 * np.pi * tau)
-            if penalty == 'integral':
+            # (the penalty matrices depend on the basis grid only: kept with the A matrices while the grid stands -- a batch of
+            # spectra on one grid, `fit_many`, builds them once)
+            pen_cached = (not self._recalc_mat) and store.get('_penalty') == (penalty, self.basis, float(epsilon), len(tau),
+                                                                             float(tau[0]), float(tau[-1]))
+            if pen_cached:
+                for k_ in (('M0', 'M1', 'M2') if penalty == 'integral' else ('L0', 'L1', 'L2') if penalty == 'discrete' else
+                           ('M0', 'M1', 'M2', 'L0', 'L1', 'L2')):
+                    dist_mat[name][k_] = store[k_]
+            elif penalty == 'integral':
                 for o in (0, 1, 2):
                     dist_mat[name]['M%d' % o] = construct_M(fb, basis=self.basis, order=o, epsilon=epsilon)
             elif penalty == 'discrete':
@@ -1108,6 +1296,7 @@ class Inverter:
             else:
                 raise ValueError(f'Invalid penalty argument {penalty}. Options are integral, discrete, and cholesky')
             store.update(dist_mat[name])
+            store['_penalty'] = (penalty, self.basis, float(epsilon), len(tau), float(tau[0]), float(tau[-1]))
             dist_mat[name].update({'A_re': A_re, 'A_im': A_im, 'WA_re': W_re @ A_re, 'WA_im': W_im @ A_im, 'B': B})
         self._recalc_mat = False
         self._cached_distributions = self.distributions.copy()

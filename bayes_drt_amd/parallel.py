@@ -153,7 +153,7 @@ class GpuWorker:
         self.D = self.problem.D
         self.sampler = None
 
-    def run(self, spec, chain_ids, warmup, n_draws, seed, control):
+    def run(self, spec, chain_ids, warmup, n_draws, seed, control, init_theta=None):
         import ctypes as C
         from . import _lib
         from .engine import Sampler
@@ -161,7 +161,8 @@ class GpuWorker:
         self.problem._lib.bdrt_nuts_defaults(C.byref(ctrl))
         for k, v in (control or {}).items():
             setattr(ctrl, k, v)
-        self.sampler = Sampler(self.problem, len(spec), warmup, n_draws, seed, ctrl, spec=spec, chain_ids=chain_ids)
+        self.sampler = Sampler(self.problem, len(spec), warmup, n_draws, seed, ctrl, spec=spec, chain_ids=chain_ids,
+                               init_theta=init_theta)
         self.sampler.run()
         _, self._lp, diag = self.sampler.results(want_draws=False)
         self._stats = np.array([[d['n_leapfrog'], d['n_divergent'], d['n_max_treedepth'], d['stepsize'], d['mean_accept']]
@@ -236,7 +237,7 @@ def _unpack_problem(flat):
 
 
 def sample_sharded(problem_kwargs, n_spectra, chains, warmup, n_draws, seed=1234, control=None, group=None,
-                   worker_cls=None, gather='draws', q=(2.5, 50.0, 97.5)):
+                   worker_cls=None, gather='draws', q=(2.5, 50.0, 97.5), init_theta=None):
     """Sample `chains` chains for each of `n_spectra` spectra on all ranks of the process group.
 
     problem_kwargs (needed on rank 0 only; other ranks may pass None): dict(blocks=[...], Z=[n_spectra x 2nf], freq=...,
@@ -247,7 +248,9 @@ def sample_sharded(problem_kwargs, n_spectra, chains, warmup, n_draws, seed=1234
       draws [n_units, n_draws, D] (unconstrained)        only with gather='draws'
     gather='summary' moves n_spectra*(1+len(q))*D numbers instead of the draws; when the chains of a
     spectrum are spread over ranks (fewer spectra than ranks) the summary needs all of them, so the draws are gathered
-    in that case regardless."""
+    in that case regardless.
+    init_theta (rank 0; optional): [n_units, D] unconstrained start points in unit order (Stan `init=` values; default: the
+    sampler's own random starts); each rank receives the rows of its units with the scatter of the spectra."""
     if gather not in ('draws', 'summary'):
         raise ValueError("gather must be 'draws' or 'summary'")
     dist = _dist()
@@ -261,15 +264,31 @@ def sample_sharded(problem_kwargs, n_spectra, chains, warmup, n_draws, seed=1234
     # receives the rows of Z it samples -- unless the chains of a spectrum are spread over ranks (fewer spectra
     # than ranks: every rank then needs the few spectra, and they travel with the broadcast)
     Zfull = None
+    status = [None]
     if rank == 0:
-        flat0 = _pack_problem(problem_kwargs)
-        Zfull = np.atleast_2d(flat0['kw_Z'])
-        if Zfull.shape[0] != n_spectra:
-            raise ValueError('sample_sharded: Z has %d spectra, n_spectra = %d' % (Zfull.shape[0], n_spectra))
-        if whole:
-            flat0.pop('kw_Z')
-            flat0['Z_width'] = np.array(Zfull.shape[1])
+        # (arguments are checked HERE and the verdict travels first: an exception on rank 0 alone would leave the other ranks
+        # waiting in the broadcast below until the process-group timeout)
+        try:
+            flat0 = _pack_problem(problem_kwargs)
+            Zfull = np.atleast_2d(flat0['kw_Z'])
+            if Zfull.shape[0] != n_spectra:
+                raise ValueError('sample_sharded: Z has %d spectra, n_spectra = %d' % (Zfull.shape[0], n_spectra))
+            if init_theta is not None:
+                init_theta = np.ascontiguousarray(np.asarray(init_theta, dtype=np.float64))
+                if init_theta.ndim != 2 or init_theta.shape[0] != n_spectra * chains:
+                    raise ValueError('sample_sharded: init_theta must be [n_spectra * chains, D]')
+            if whole:
+                flat0.pop('kw_Z')
+                flat0['Z_width'] = np.array(Zfull.shape[1])
+            flat0['init_width'] = np.array(0 if init_theta is None else init_theta.shape[1])
+        except Exception as e:          # noqa: BLE001 -- re-raised on every rank
+            status[0] = '%s: %s' % (type(e).__name__, e)
+    dist.broadcast_object_list(status, src=0, group=group)
+    if status[0] is not None:
+        raise ValueError('sample_sharded (rank 0): ' + status[0])
     flat = broadcast_arrays(flat0 if rank == 0 else None, src=0, group=group)
+    init_width = int(flat.pop('init_width'))
+    init_local = scatter_rows(init_theta, counts, init_width, src=0, group=group) if init_width else None
     if whole:
         width = int(flat.pop('Z_width'))
         rows = [c // chains for c in counts]                        # whole spectra per rank
@@ -286,7 +305,10 @@ def sample_sharded(problem_kwargs, n_spectra, chains, warmup, n_draws, seed=1234
         # only this rank's spectra go to HBM: what the scatter delivered, or this rank's rows of the broadcast copy
         local_kw['Z'] = np.atleast_2d(kw['Z']) if whole else np.atleast_2d(kw['Z'])[s0:s1]
         worker = cls(local_kw)
-        worker.run(spec[u0:u1] - s0, chain[u0:u1], warmup, n_draws, seed, control)
+        if init_local is not None:
+            worker.run(spec[u0:u1] - s0, chain[u0:u1], warmup, n_draws, seed, control, init_theta=init_local)
+        else:
+            worker.run(spec[u0:u1] - s0, chain[u0:u1], warmup, n_draws, seed, control)
         D = int(worker.D)
     # ranks without work learn D (and which parameters are <lower=0>) from the first rank that has some
     owners = [r for r in range(world) if counts[r] > 0]

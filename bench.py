@@ -65,12 +65,15 @@ MFMA_PER_TILE = {2: 924, 4: 820}
 MFMA_FLOP_PER_EVAL = MFMA_PER_TILE[4] * 2048 / 16.0
 
 
-def synth_spectra(n, seed=20260101):
-    """n two-ZARC spectra, parameters per SURVEY 8(d) config 4; noise models cycled uniform/Orazem/Macdonald 0.25 %."""
+def synth_spectra(n, seed=20260101, raw=False):
+    """n two-ZARC spectra, parameters per SURVEY 8(d) config 4; noise models cycled uniform/Orazem/Macdonald 0.25 %.
+    raw=False: [n, 2 NF] stacked (Z', Z'') scaled as Inverter._scale_Z does (the oracle leg's input, which must not depend on the
+    product package); raw=True: the complex spectra as measured, for `Inverter.batch_stan_data` / `fit_many`."""
     rs = np.random.RandomState(seed)
     f = np.logspace(6, -2, NF)
     w = 2 * np.pi * f
     Z = np.empty((n, 2 * NF))
+    Zraw = []
     for s in range(n):
         R1, R2 = rs.uniform(0.5, 2, 2)
         t1, t2 = 10 ** rs.uniform(-3, -1), 10 ** rs.uniform(-4, -2)
@@ -85,10 +88,11 @@ def synth_spectra(n, seed=20260101):
             sig = 0.0025 * np.abs(z)
         noise = rs.normal(size=(NF, 2))
         z = z + sig * noise[:, 0] + 1j * sig * noise[:, 1]
+        Zraw.append(z)
         scale = np.std(np.abs(z)) / np.sqrt(NF / 81)       # Inverter._scale_Z (inversion.py:2437-2441)
         z = z / scale
         Z[s] = np.concatenate([z.real, z.imag])
-    return f, Z
+    return (f, Zraw) if raw else (f, Z)
 
 
 _CPU_WORKER = r'''
@@ -230,16 +234,17 @@ def self_launch(n, argv):
 
 
 def build_problem_kwargs(n_spectra, lib=None):
-    """Global problem of the benchmark: shared 81 x 161 grids, matrices built on the GPU, n_spectra synthetic spectra."""
-    from bayes_drt_amd import matrices as gm
-    f, Z = synth_spectra(n_spectra)
-    basis_freq = np.logspace(10, -6, K)
-    tau = 1 / (2 * np.pi * basis_freq)
-    eps = 1 / np.mean(np.diff(np.log(tau)))
-    A = np.vstack([gm.construct_A(f, 'real', tau=tau, epsilon=eps), gm.construct_A(f, 'imag', tau=tau, epsilon=eps)])
-    L = [gm.construct_L(basis_freq, tau=tau, epsilon=eps, order=o) for o in (0, 1, 2)]
-    blk = dict(A=A, L0=L[0], L1=L[1], L2=0.75 * L[2], nonneg=True)       # sample-mode scaling (inversion.py:1725-1730)
-    return dict(blocks=[blk], Z=Z, freq=f, sigma_min=0.002, ups_alpha=1.0, ups_beta=0.1, induc_scale=1.0)
+    """Global problem of the benchmark: shared 81 x 161 grids, n_spectra synthetic spectra -- the batch that
+    `Inverter(basis_freq=...).fit_many(f, spectra, nonneg=True, mode='sample')` runs, taken from the Inverter itself (matrices built
+    on the GPU, every spectrum scaled as `fit` scales it, sample-mode hyper-parameters of `_prep_stan_data`, inversion.py:1725-1754)."""
+    from bayes_drt_amd import engine
+    from bayes_drt_amd.inversion import Inverter
+    f, spectra = synth_spectra(n_spectra, raw=True)
+    model_name, dat = Inverter(basis_freq=np.logspace(10, -6, K)).batch_stan_data(f, spectra, nonneg=True, mode='sample')
+    assert model_name == 'Series_pos_StanModel.pkl'
+    blocks, kw, _ = engine.blocks_from_dat(model_name, dat)
+    kw = {k: v for k, v in kw.items() if k in ('sigma_min', 'ups_alpha', 'ups_beta', 'induc_scale')}
+    return dict(kw, blocks=blocks, Z=np.asarray(dat['Z'], dtype=float), freq=np.asarray(dat['freq'], dtype=float))
 
 
 SHAPES = ((81, 161), (81, 101), (81, 81), (41, 51), (53, 81), (106, 101))       # (frequencies, basis functions): the headline, the

@@ -33,8 +33,11 @@ class FakeWorker:
         self.kw = kw
         self.D = 2 * kw['blocks'][0]['A'].shape[1] + 9
 
-    def run(self, spec, chain_ids, warmup, n_draws, seed, control):
+    def run(self, spec, chain_ids, warmup, n_draws, seed, control, init_theta=None):
         self._draws, self._lp, self._stats = _fake_sampler(self.kw, spec, chain_ids, warmup, n_draws, seed, control)
+        if init_theta is not None:                     # the start point a unit was handed shows up in its first draw
+            assert init_theta.shape == (len(spec), self.D)
+            self._draws[:, 0, :] = init_theta
         self._stats[:, 1] = dist.get_rank()            # "n_divergent" column abused as the rank that sampled the unit
         self._stats[:, 2] = np.atleast_2d(self.kw['Z']).shape[0]     # "n_max_treedepth": spectra this rank was handed
 
@@ -189,3 +192,67 @@ def test_broadcast_rejects_what_float64_cannot_carry():
     with pytest.raises(TypeError):
         par._pack_problem(dict(blocks=[dict(A=np.ones((2, 2)) * 1j, L0=np.eye(2), L1=np.eye(2), L2=np.eye(2))], Z=np.ones(2),
                                freq=np.ones(1)))
+
+
+def _worker_init(rank, world, port, n_spectra, chains, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        pk = _problem(n_spectra) if rank == 0 else None
+        D = 2 * 4 + 9
+        it = np.arange(n_spectra * chains * D, dtype=float).reshape(n_spectra * chains, D) if rank == 0 else None
+        res = par.sample_sharded(pk, n_spectra, chains, 5, 4, seed=11, worker_cls=FakeWorker, gather='draws', init_theta=it)
+        if rank == world - 1:
+            q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_spectra,chains', [(1, 3, 2), (2, 3, 2), (2, 1, 4), (3, 2, 2)])
+def test_start_points_travel_with_their_units(world, n_spectra, chains):
+    """`init_theta` rows (Stan `init=` values of Inverter.fit_many(init_from_ridge=True)) reach the rank that samples the unit, whatever
+    the partition: whole spectra per rank, or the chains of one spectrum spread over the ranks."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_init, args=(r, world, port, n_spectra, chains, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    D = 2 * 4 + 9
+    assert np.array_equal(res['draws'][:, 0, :], np.arange(n_spectra * chains * D, dtype=float).reshape(n_spectra * chains, D))
+
+
+def _worker_bad(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        pk = _problem(3) if rank == 0 else None        # three spectra handed over, four announced
+        try:
+            par.sample_sharded(pk, 4, 2, 5, 4, seed=11, worker_cls=FakeWorker)
+            q.put((rank, 'no error'))
+        except ValueError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_bad_argument_on_rank_0_fails_on_every_rank_instead_of_hanging():
+    """rank 0 used to raise before the collectives while the other ranks waited in the broadcast until the
+    process-group timeout.  The verdict of the argument check now travels first and every rank raises."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bad, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert set(got) == {0, 1} and all('Z has 3 spectra' in m for m in got.values())
