@@ -103,7 +103,8 @@ def test_rc_family_saturation_is_a_property_of_the_start_point(stem, ref_sat, me
     (profiles/r04/rc_family_seeds.txt: per spectrum and seed, 8 seeds).  Asserted here over four seeds per spectrum: a run
     with a saturated chain occurs (except RC_Macdonald: 1 of 8 seeds), a saturated iteration is 1023 leapfrogs, and the
     posterior mean of the unsaturated runs is on the stored curve (<= 1 %; RC_Macdonald_0.25 sits 17.5-17.9 %
-    off in EVERY seed, stuck chain or not: recorded, not explained -- no second reference run of it exists)."""
+    off in EVERY seed, stuck chain or not: explained by the two tests below -- on that spectrum the reference's frozen chain
+    did not sit at the mode)."""
     S = load('hmc_suite')
     i = [str(s_) for s_ in S['stems']].index(stem)
     f, Z = S['Z'][i][:, 0], S['Z'][i][:, 1] + 1j * S['Z'][i][:, 2]
@@ -123,8 +124,75 @@ def test_rc_family_saturation_is_a_property_of_the_start_point(stem, ref_sat, me
         assert min(errs) <= mean_bound, errs
         # a chain saturates when its warm-up ends below ~0.006; the unsaturated runs agree with the stored curve
         assert all(e_ <= 0.02 for e_, s_ in zip(errs, sat) if s_ <= 40), (errs, sat)
-    else:
-        assert all(0.15 <= e_ <= 0.20 for e_ in errs), errs           # (see docstring)
+    # (RC_Macdonald_0.25 -- mean_bound None: its stored curve is not a posterior mean to compare with; see the two tests below)
+
+
+def _phi(inv):
+    from bayes_drt_amd.inversion import _gaussian
+    info = inv.distributions['DRT']
+    return _gaussian(np.log(TAU_PLOT[:, None] / info['tau'][None, :]), info['epsilon'])
+
+
+def test_rc_macdonald_long_run_equals_the_oracle_long_run():
+    """RC_Macdonald_0.25, 4 x (1000 + 1000): the posterior mean and the 2.5 % / 97.5 % percentiles of the coefficients from the HIP
+    sampler against the same run of the CPU oracle's recursive NUTS (tests/golden/rc_macdonald_oracle.npz, written by
+    tools/rc_macdonald_oracle.py: its four chains agree among themselves to 0.3 %).  Measured 0.14 % / 0.8 % / 0.3 %
+    (profiles/r05/rc_macdonald_study.txt): whatever separates this spectrum's stored curve from ours, it is not the HIP path."""
+    from bayes_drt_amd.inversion import Inverter
+    S, O = load('hmc_suite'), load('rc_macdonald_oracle')
+    i = [str(s_) for s_ in S['stems']].index('RC_Macdonald_0.25')
+    f, Z = S['Z'][i][:, 0], S['Z'][i][:, 1] + 1j * S['Z'][i][:, 2]
+    inv = Inverter(basis_freq=f)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        inv.fit(f, Z, nonneg=True, mode='sample', warmup=int(O['warmup']), samples=int(O['draws']), chains=4, random_seed=1234)
+    fit = inv._sample_result
+    x = inv._rescale_coef(fit[inv._get_stan_coef_name('DRT')], 'series')
+    e = [rel_l2(x.mean(axis=0), O['x_mean']), rel_l2(np.percentile(x, 2.5, axis=0), O['x_lo']), rel_l2(np.percentile(x, 97.5, axis=0), O['x_hi'])]
+    print('HIP vs oracle, 4 x (%d + %d): coefficient mean %.4f, 2.5 %% %.4f, 97.5 %% %.4f; saturated %d, divergent %d'
+          % (int(O['warmup']), int(O['draws']), e[0], e[1], e[2], fit.n_max_treedepth, fit.n_divergent))
+    assert e[0] <= 0.02 and e[1] <= 0.05 and e[2] <= 0.05, e
+    assert np.mean(inv._rescale_coef(fit['Rinf'], 'series')) == pytest.approx(float(O['Rinf_mean']), rel=2e-3)
+    assert fit.n_max_treedepth <= 40                                   # (the oracle's chains: none)
+
+
+def test_rc_macdonald_stored_curve_is_a_converged_chain_mixed_with_a_frozen_one():
+    """Why RC_Macdonald_0.25 alone sits 17.5-17.9 % from its stored posterior mean in every seed while its three siblings land
+    within 1 % (the four were one event: the reference saturated tree depth 10 in ONE of its two chains on each of them for the
+    whole run -- a chain that does not move).  On the siblings that chain happened to sit at the mode; on this spectrum it did not:
+      * the reference's OWN two results disagree here -- stored HMC mean vs stored MAP curve 18.7 % (siblings 3-5 %) -- while our
+        posterior mean is 3.5 % from the stored MAP curve, like the siblings' stored means;
+      * read as the 50 / 50 mixture of a converged chain and a chain frozen at g_s = 2 * stored - ours, the stored curve yields a
+        g_s that IS a distribution (non-negative, unit area like every single-RC curve of the study, a broader peak), and the
+        mixture reproduces the stored 2.5 % / 97.5 % curves 3-4 x better than a converged chain alone (1.34 -> 0.32, 0.28 -> 0.10).
+    Asserted so that a regression of OUR posterior would fail: the distance to the stored MAP curve, the properties of g_s, the
+    improvement of the percentile curves (tools/rc_macdonald_study.py prints the same for the siblings)."""
+    S = load('hmc_suite')
+    i = [str(s_) for s_ in S['stems']].index('RC_Macdonald_0.25')
+    f, Z = S['Z'][i][:, 0], S['Z'][i][:, 1] + 1j * S['Z'][i][:, 2]
+    ref, gmap = S['Gout_bayes'][i], S['Gout_map'][i][:, 1]
+    assert 0.17 <= rel_l2(ref[:, 1], gmap) <= 0.20                     # the reference against itself
+    from bayes_drt_amd.inversion import Inverter
+    inv = Inverter(basis_freq=f)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        inv.fit(f, Z, nonneg=True, mode='sample', warmup=200, samples=200, chains=2, random_seed=1234)
+    fit = inv._sample_result
+    ours = inv.predict_distribution('DRT', eval_tau=TAU_PLOT)
+    assert rel_l2(ours, gmap) <= 0.06, rel_l2(ours, gmap)
+    Phi = _phi(inv)
+    X = inv._rescale_coef(fit.chain_draws(inv._get_stan_coef_name('DRT'))[0], 'series')
+    x_s = 2.0 * np.linalg.lstsq(Phi, ref[:, 1], rcond=None)[0] - X.mean(axis=0)
+    g_s = Phi @ x_s
+    area = float(np.sum(0.5 * (g_s[1:] + g_s[:-1]) * np.diff(np.log(TAU_PLOT))))
+    area_ours = float(np.sum(0.5 * (ours[1:] + ours[:-1]) * np.diff(np.log(TAU_PLOT))))
+    assert g_s.min() >= -0.01 * g_s.max() and abs(area - area_ours) <= 0.02 and 1.3 <= g_s.max() <= 1.9, (g_s.min(), area, g_s.max())
+    mix = np.vstack([X, np.tile(x_s, (X.shape[0], 1))])
+    lo_m, hi_m = rel_l2(Phi @ np.percentile(mix, 2.5, axis=0), ref[:, 2]), rel_l2(Phi @ np.percentile(mix, 97.5, axis=0), ref[:, 3])
+    lo_1, hi_1 = rel_l2(Phi @ np.percentile(X, 2.5, axis=0), ref[:, 2]), rel_l2(Phi @ np.percentile(X, 97.5, axis=0), ref[:, 3])
+    print('RC_Macdonald_0.25: ours vs stored MAP %.4f; frozen-chain curve area %.3f peak %.3f; stored 2.5 %% / 97.5 %% curves vs mixture %.3f / %.3f, '
+          'vs one converged chain %.3f / %.3f' % (rel_l2(ours, gmap), area, g_s.max(), lo_m, hi_m, lo_1, hi_1))
+    assert lo_m <= 0.45 and hi_m <= 0.15 and lo_1 >= 2.5 * lo_m and hi_1 >= 2.0 * hi_m
 
 
 MAP_SUITE = ['2ZARC_Orazem_1.0', '2ZARC_uniform_2.5', 'ZARC_Macdonald_1.0', 'ZARC_uniform_0.25', 'ZARC-RL_Macdonald_2.5',
@@ -223,3 +291,50 @@ def test_other_families_match_the_published_hmc_curves(stem, model, bounds):
             assert fit.n_max_treedepth >= 190
         # (in between -- one of the two chains saturated for part of the run -- the count is a coin flip per chain and pins nothing)
     assert fit.n_divergent <= 20
+
+
+def test_the_whole_published_study_in_three_fit_many_calls():
+    """All 60 spectra of Run fits.ipynb cell 5 on the CURRENT binary (the per-spectrum tests above cover 14 of them): the spectra
+    that share their options are one `Inverter.fit_many` batch (45 + 5 + 9 + 1; the notebook: 60 `fit` calls of 32-180 s each).
+    Per spectrum: posterior mean within 4 % of the stored curve (RC_Macdonald_0.25: see the mixture test), the saturation CLASS of
+    the reference, few divergent iterations; in total: saturated iterations in the reference's range (3035 of 24 000 there; ours
+    2400-3000 depending on which chains freeze), wall time of the whole study."""
+    import time
+    from bayes_drt_amd.inversion import Inverter
+    S = load('hmc_suite')
+    stems = [str(s_) for s_ in S['stems']]
+    f = S['Z'][0][:, 0]
+    groups = {}
+    for i, stem in enumerate(stems):
+        assert np.array_equal(S['Z'][i][:, 0], f)
+        groups.setdefault((not stem.startswith('ZARC-RL'), 0.005 if 'noiseless' in stem else 0.002), []).append(i)
+    assert sorted(len(v) for v in groups.values()) == [1, 5, 9, 45]
+    views = {}
+    t0 = time.time()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for (nonneg, smin), idx in groups.items():
+            out = Inverter(basis_freq=f).fit_many(f, [S['Z'][i][:, 1] + 1j * S['Z'][i][:, 2] for i in idx], nonneg=nonneg, mode='sample',
+                                                  warmup=200, samples=200, chains=2, sigma_min=smin)
+            views.update(zip(idx, out))
+    wall = time.time() - t0
+    sat = div = 0
+    bad = []
+    for i, stem in enumerate(stems):
+        v, ref, d = views[i], S['Gout_bayes'][i], S['diag'][i]
+        fit = v._sample_result
+        e = rel_l2(v.predict_distribution('DRT', eval_tau=TAU_PLOT), ref[:, 1])
+        sat += fit.n_max_treedepth; div += fit.n_divergent
+        assert fit.n_leapfrog >= 1023 * fit.n_max_treedepth
+        ok = (e <= 0.04 or stem == 'RC_Macdonald_0.25') and fit.n_divergent <= 20
+        if d[0] <= 5:
+            ok = ok and fit.n_max_treedepth <= 200          # (at most one chain frozen where the reference had none)
+        if d[0] >= 380:
+            ok = ok and fit.n_max_treedepth >= 190
+        if not ok:
+            bad.append((stem, round(e, 4), fit.n_max_treedepth, int(d[0]), fit.n_divergent))
+    print('published HMC study, 60 spectra in %d fit_many calls: %.1f s; saturated %d (reference %d of 24000), divergent %d (reference %d); outside the bands: %s'
+          % (len(groups), wall, sat, int(S['diag'][:, 0].sum()), div, int(S['diag'][:, 1].sum()), bad))
+    assert len(bad) <= 2, bad                               # (2 x 200 draws: a frozen chain on a spectrum where the reference had none moves a mean by a few %)
+    assert 1800 <= sat <= 3800 and div <= 80
+    assert wall <= 30.0

@@ -52,7 +52,7 @@ if __name__ == '__main__':
     theta = np.concatenate([r[1] for r in res])                        # [4 * draws, D] unconstrained
     # Series_pos layout (include/bdrt.h): Rinf_raw, induc_raw, x[K] (log), sigma_res.., ups[K] (log), d[3] (log)
     x = np.exp(theta[:, 2:2 + K]) * zscale
-    rinf = 100.0 * theta[:, 0] * zscale
+    rinf = 100.0 * np.exp(theta[:, 0]) * zscale                       # Rinf_raw is declared <lower=0>
     out = dict(stem=STEM, warmup=warm, draws=draws, seed=1234, K=K, x_mean=x.mean(axis=0), x_lo=np.percentile(x, 2.5, axis=0),
                x_hi=np.percentile(x, 97.5, axis=0), Rinf_mean=rinf.mean(), lp_mean=np.mean([r[2].mean() for r in res]),
                x_chain_mean=np.stack([np.exp(r[1][:, 2:2 + K]).mean(axis=0) * zscale for r in res]),
