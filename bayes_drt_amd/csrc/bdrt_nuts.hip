@@ -516,8 +516,13 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
 // streamed evaluator (workspace in HBM), everything after it by the cooperative stage of bdrt_nuts_wide.h.  Slow but working:
 // the reference accepts any grid (inversion.py:2127-2209).  State layout: that of nuts_wide1_kernel.
 // ---------------------------------------------------------------------------------------------------------------------------
-__host__ __device__ inline size_t nuts_big_lds_bytes() { return (size_t)(W1_SCRATCH + 2 + 9 * 8) * sizeof(double) + sizeof(ChainState) + 128; }
+// NJX: elements of a parameter vector per thread of the cooperative stage, D <= 512 NJX (2: D <= 1024; 4: D <= 2048 -- three
+// distributions of 301 basis functions are 1821 parameters).  The stage's LDS scratch holds the D momentum normals behind its
+// 512 doubles of reduction scratch.
+__host__ __device__ inline int big_scratch_doubles(int njx) { return njx <= 2 ? W1_SCRATCH : 512 + 512 * njx + 64; }
+__host__ __device__ inline size_t nuts_big_lds_bytes(int njx = 2) { return (size_t)(big_scratch_doubles(njx) + 2 + 9 * 8) * sizeof(double) + sizeof(ChainState) + 128; }
 
+template <int NJX>
 __global__ __launch_bounds__(SOLO_NT) void nuts_big_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_big_kernel(const DevProblem *__r
     const int wg = blockIdx.x, unit = a.unit_map ? a.unit_map[wg] : wg;
     const int D = P.D, DS = a.ds;
     double *scr = smem;
-    double *lpn = scr + W1_SCRATCH;
+    double *lpn = scr + big_scratch_doubles(NJX);
     double *red = lpn + 2;
     ChainState *sts = reinterpret_cast<ChainState *>(red + 9 * 8);
     signed char *hslot = reinterpret_cast<signed char *>(sts + 1);      // [V_COUNT] (64 bytes): no row is LDS-resident
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_big_kernel(const DevProblem *__r
         big_eval(P, ws, row(V_TH), row(V_G), lpn, spec, 1, red, tid);
         __threadfence_block();
         __syncthreads();
-        wide_coop_tail<2, true>(wx, 0, false, my_leaps, tid);
+        wide_coop_tail<NJX, true>(wx, 0, false, my_leaps, tid);
         __syncthreads();
     }
     if (tid == 0) {
@@ -999,16 +1004,16 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         S.nhot1 = wide1_hot_rows(S.geom1, ds1);
         S.lds_bytes = std::max(S.lds_bytes, wide1_lds_bytes(S.geom1, ds1, S.nhot1));     // (one attribute value for every kernel)
     }
-    if (S.big) S.lds_bytes = nuts_big_lds_bytes();
+    if (S.big) S.lds_bytes = nuts_big_lds_bytes(S.D <= 1024 ? 2 : 4);
     auto fail = [&](const char *msg) -> bdrt_sampler * { set_error("%s", msg); bdrt_sampler_destroy(s); return nullptr; };
     if (S.lds_bytes > 160 * 1024) return fail("bdrt_sampler_create: problem too large for the 160 KiB LDS budget");
     for (int u = 0; u < n_units; ++u)
         if (spec && (spec[u] < 0 || spec[u] >= P.dev.n_spectra)) return fail("bdrt_sampler_create: spectrum index out of range");
 
     // row stride of the state vectors = 32*NJ of the kernel instantiation; the solo kernel keeps [unit][row][ds] with one column
-    const int DS = S.solo ? S.geom.DSS : (S.use_s1 ? 32 * s1_nj(S.D) : (S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : (S.D <= 32 * 27 ? 32 * 27 : 32 * 32))));
-    if (S.D > (S.big ? 1024 : 32 * 27)) {
-        set_error("bdrt_sampler_create: D = %d > %d not supported", S.D, S.big ? 1024 : 864); bdrt_sampler_destroy(s); return nullptr;
+    const int DS = S.solo ? S.geom.DSS : (S.use_s1 ? 32 * s1_nj(S.D) : (S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : (S.D <= 32 * 27 ? 32 * 27 : (S.D <= 1024 ? 1024 : 2048)))));
+    if (S.D > (S.big ? 2048 : 32 * 27)) {
+        set_error("bdrt_sampler_create: D = %d > %d not supported", S.D, S.big ? 2048 : 864); bdrt_sampler_destroy(s); return nullptr;
     }
     S.args.ds = DS;
     const int ncol = (S.solo || S.wide1) ? 1 : NC, nrow = S.solo ? (int)SG_COUNT : (int)V_COUNT;
@@ -1172,8 +1177,10 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
             if (tp) hipLaunchKernelGGL((nuts_kernel<NJV, 1>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args); \
             else hipLaunchKernelGGL((nuts_kernel<NJV, 0>), dim3(S.n_wg), dim3(NT), S.lds_bytes, S.stream, dp, S.np, S.args);   \
         } while (0)
-        if (S.big)
-            hipLaunchKernelGGL(nuts_big_kernel, dim3(S.n_wg), dim3(SOLO_NT), nuts_big_lds_bytes(), S.stream, dp, S.np, S.args);
+        if (S.big && S.D <= 1024)
+            hipLaunchKernelGGL(nuts_big_kernel<2>, dim3(S.n_wg), dim3(SOLO_NT), nuts_big_lds_bytes(2), S.stream, dp, S.np, S.args);
+        else if (S.big)
+            hipLaunchKernelGGL(nuts_big_kernel<4>, dim3(S.n_wg), dim3(SOLO_NT), nuts_big_lds_bytes(4), S.stream, dp, S.np, S.args);
         else if (S.wide1 && S.args.prof)
             hipLaunchKernelGGL(nuts_wide1_kernel<true>, dim3(S.n_wg), dim3(SOLO_NT), wide1_lds_bytes(S.geom1, S.args.ds, S.nhot1), S.stream, dp,
                                S.np, S.args, S.geom1, S.nhot1);

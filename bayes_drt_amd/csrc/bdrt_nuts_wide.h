@@ -329,11 +329,15 @@ __device__ inline void wide_coop_tail(const WideCtx &x, int hc, bool c_done, uns
         if (next == 1 || next == 3) {
             // fresh momentum p ~ N(0, M), M = diag(1/Minv): normals 2i and 2i+1 share one Philox block and one Box-Muller
             // transform; thread i produces the pair, the LDS row hands element j to thread j
-            static_assert(NJX <= 2, "one normal pair per thread covers D <= 1024");
-            if (2 * tid < D) {
-                double z0, z1;
-                rng_normal_pair(rng, (uint32_t)tid, next == 1 ? RNG_MOMENTUM : RNG_EPS_MOMENTUM, next == 1 ? 0u : trial, iter, z0, z1);
-                zrow[2 * tid] = z0; zrow[2 * tid + 1] = z1;
+            // (a thread produces the pairs tid, tid + 512, ...: one pair per thread covers D <= 1024, the streamed path goes beyond)
+#pragma unroll
+            for (int mp = 0; mp < (NJX + 1) / 2; ++mp) {
+                const int i = tid + WIDE_NT * mp;
+                if (2 * i < D) {
+                    double z0, z1;
+                    rng_normal_pair(rng, (uint32_t)i, next == 1 ? RNG_MOMENTUM : RNG_EPS_MOMENTUM, next == 1 ? 0u : trial, iter, z0, z1);
+                    zrow[2 * i] = z0; zrow[2 * i + 1] = z1;
+                }
             }
             __syncthreads();
             double pn_[NJX];

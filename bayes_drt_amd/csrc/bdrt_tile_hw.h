@@ -88,10 +88,16 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
         {
             double tx_[UKV], tu_[UKV], ex_[UKV];
 #pragma unroll
+            for (int u = 0; u < UKV; ++u) {                                // (loads from a clamped index, THEN the selects: a load
+                const int k = l32 + LPC * u, kk = k < K ? k : 0;           //  under `k < K` is a branch around a memory round trip of
+                tx_[u] = TH(B.o_x + kk);                                   //  its own -- six in a row per block, bdrt_tile_s1.h)
+                tu_[u] = TH(B.o_ups + kk);
+            }
+#pragma unroll
             for (int u = 0; u < UKV; ++u) {
-                const int k = l32 + LPC * u;
-                tx_[u] = k < K ? TH(B.o_x + k) : 0.0;
-                tu_[u] = k < K ? TH(B.o_ups + k) : 0.0;
+                const bool in = l32 + LPC * u < K;
+                tx_[u] = in ? tx_[u] : 0.0;
+                tu_[u] = in ? tu_[u] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < UKV; ++u) ex_[u] = lean_exp(tx_[u]);
@@ -230,11 +236,17 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
         __syncthreads();                                                   // B2: A_b x_b of all chains in Zh
         // ---- accumulate Z_hat; a parallel block contributes conj(Y)/|Y|^2 and parks Y ----------------------------------------
         double *Y = Yp + (size_t)B.yp_slot * TA * NC;
+        double yr_[UNV], yi_[UNV];
+#pragma unroll
+        for (int v = 0; v < UNV; ++v) {
+            const int n = l32 + LPC * v, nn = n < nf ? n : 0;
+            yr_[v] = Zh[swz(nn, c)]; yi_[v] = Zh[swz(nf + nn, c)];
+        }
 #pragma unroll
         for (int v = 0; v < UNV; ++v) {
             const int n = l32 + LPC * v;
             if (n >= nf) continue;
-            const double yr = Zh[swz(n, c)], yi = Zh[swz(nf + n, c)];
+            const double yr = yr_[v], yi = yi_[v];
             if (!B.is_parallel) { zre_a[v] += yr; zim_a[v] += yi; }
             else {
                 Y[swz(n, c)] = yr; Y[swz(nf + n, c)] = yi;
@@ -266,17 +278,27 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
         const double c0 = P.sigma_min * P.sigma_min + s_res * s_res;
         const double ap2 = a_p * a_p, ar2 = a_r * a_r, ai2 = a_i * a_i;
         double sR = 0, sL = 0, sH = 0, sHz2 = 0, sHzr2 = 0, sHzi2 = 0;
+        // (the phase's memory reads -- weights, measured spectrum, outlier parameters -- in one batch from a clamped row)
+        double wn_[UNV], zmr_[UNV], zmi_[UNV], to0_[UNV], to1_[UNV];
+        const int omode = P.outlier_mode;
+#pragma unroll
+        for (int v = 0; v < UNV; ++v) {
+            const int n = l32 + LPC * v, nn = n < nf ? n : 0;
+            wn_[v] = P.w[nn]; zmr_[v] = Zm[nn]; zmi_[v] = Zm[nf + nn];
+            to0_[v] = 0.0; to1_[v] = 0.0;
+            if (omode) { to0_[v] = TH(P.o_so + nn); to1_[v] = TH(P.o_so + nf + nn); }
+        }
 #pragma unroll
         for (int v = 0; v < UNV; ++v) {
             const int n = l32 + LPC * v;
             gzr_[v] = 0.0; gzi_[v] = 0.0;
             if (n >= nf) continue;
-            const double wn = P.w[n];
+            const double wn = wn_[v];
             const double zr = zre_a[v] + Rinf;
             const double zi = zim_a[v] + induc * wn;
             double so_re = 0.0, so_im = 0.0, r0 = 0.0, r1 = 0.0, t0 = 0.0, t1 = 0.0;
             if (P.outlier_mode) {
-                t0 = TH(P.o_so + n); t1 = TH(P.o_so + nf + n);
+                t0 = to0_[v]; t1 = to1_[v];
                 r0 = lean_exp(t0); r1 = lean_exp(t1);
                 PW(P.o_so + n, r0); PW(P.o_so + nf + n, r1);
                 if (P.outlier_mode == 1) so_re = so_im = 0.05 * r0 * r1;
@@ -285,7 +307,7 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
             const double common = ar2 * zr * zr + ai2 * zi * zi;
             const double s2_re = c0 + ap2 * zr * zr + common + so_re * so_re;
             const double s2_im = c0 + ap2 * zi * zi + common + so_im * so_im;
-            const double e_re = Zm[n] - zr, e_im = Zm[nf + n] - zi;
+            const double e_re = zmr_[v] - zr, e_im = zmi_[v] - zi;
             const double prod = s2_re * s2_im, ip = lean_rcp(prod);
             const double w_re = s2_im * ip, w_im = s2_re * ip;
             lp += -0.5 * lean_log(prod) - 0.5 * e_re * e_re * w_re - 0.5 * e_im * e_im * w_im;
@@ -335,13 +357,23 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
         const int K = B.K;
         const double *Y = Yp + (size_t)B.yp_slot * TA * NC;
         // operand of A_b^T: g_Zhat, or J^T g_Zhat through Z_hat_p = conj(Y)/|Y|^2 (times xp_scale) for a parallel block
+        double yr_[UNV], yi_[UNV];
+#pragma unroll
+        for (int v = 0; v < UNV; ++v) { yr_[v] = 1.0; yi_[v] = 0.0; }
+        if (B.is_parallel) {
+#pragma unroll
+            for (int v = 0; v < UNV; ++v) {
+                const int n = l32 + LPC * v, nn = n < nf ? n : 0;
+                yr_[v] = Y[swz(nn, c)]; yi_[v] = Y[swz(nf + nn, c)];
+            }
+        }
 #pragma unroll
         for (int v = 0; v < UNV; ++v) {
             const int n = l32 + LPC * v;
             if (n >= nf) continue;
             double rr = gzr_[v], ri = gzi_[v];
             if (B.is_parallel) {
-                const double yr = Y[swz(n, c)], yi = Y[swz(nf + n, c)];
+                const double yr = yr_[v], yi = yi_[v];
                 const double dn = yr * yr + yi * yi, id2 = lean_rcp(dn * dn);
                 const double dd = (yi * yi - yr * yr) * id2, doff = 2.0 * yr * yi * id2;
                 rr = (gzr_[v] * dd + gzi_[v] * doff) * B.x_scale;
@@ -354,20 +386,23 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
         gemm_sw<NWV, GPFV>(B.BkA, B.tilesK, B.rpairsA, Zh, Xs, wave, lane);   // Xs = A_b^T (.)
         __syncthreads();                                                   // B4
         {
-            double tx_[UKV], gl_[UKV], ex_[UKV];
+            double tx_[UKV], gl_[UKV], ex_[UKV], ag_[UKV];
 #pragma unroll
             for (int u = 0; u < UKV; ++u) {
-                const int k = l32 + LPC * u;
-                tx_[u] = (k < K && B.is_pos) ? TH(B.o_x + k) : 0.0;
-                gl_[u] = k < K ? GR(B.o_x + k) : 0.0;                      // L^T w of this block, parked by the prior phase
+                const int k = l32 + LPC * u, kk = k < K ? k : 0;
+                tx_[u] = TH(B.o_x + kk);
+                gl_[u] = GR(B.o_x + kk);                                   // L^T w of this block, parked by the prior phase
+                ag_[u] = Xs[swz(kk, c)];
             }
+#pragma unroll
+            for (int u = 0; u < UKV; ++u) tx_[u] = (l32 + LPC * u < K && B.is_pos) ? tx_[u] : 0.0;
 #pragma unroll
             for (int u = 0; u < UKV; ++u) ex_[u] = lean_exp(tx_[u]);
 #pragma unroll
             for (int u = 0; u < UKV; ++u) {
                 const int k = l32 + LPC * u;
                 if (k < K) {
-                    const double graw = Xs[swz(k, c)] + gl_[u] + xs_term;
+                    const double graw = ag_[u] + gl_[u] + xs_term;
                     GW(B.o_x + k, B.is_pos ? ex_[u] * graw + jac : graw);
                 }
             }

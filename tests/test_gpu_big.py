@@ -142,3 +142,46 @@ def test_inverter_fit_on_a_grid_beyond_the_tiles():
         rms2 = np.sqrt(np.mean(np.abs(inv.predict_Z(f) - Z) ** 2)) / np.std(np.abs(Z))
         assert rms2 < 0.05, rms2
         assert inv._sample_result.n_divergent <= 10
+
+
+def test_sampler_beyond_1024_parameters_on_the_streamed_path():
+    """The streamed path's sampler took D <= 1024 until round 4 (one element pair per thread of its cooperative stage); the
+    reference has no limit (three distributions of 301 basis functions are 1821 parameters).  Here: a series and a parallel
+    distribution of 301 basis functions on 200 frequencies with the stacked outlier model, D = 1616 -- a short NUTS run equal to the
+    oracle's, draw by draw (nuts_big_kernel<4>: four elements per thread, D <= 2048)."""
+    from bayes_drt_amd import matrices as gm
+    from bayes_drt_amd._lib import NutsControl
+    from bayes_drt_amd.engine import Sampler
+    from bayes_drt_amd.model import Problem
+    from oracle import oracle as orc
+    nf, K = 200, 301
+    f = np.logspace(6, -3, nf)
+    bf = np.logspace(8, -5, K)
+    tau = 1 / (2 * np.pi * bf); eps = 1 / np.mean(np.diff(np.log(tau)))
+    blocks = []
+    for par in (False, True):
+        kw = dict(tau=tau, epsilon=eps) if not par else dict(tau=tau, epsilon=eps, kernel='DDT', dist_type='parallel', symmetry='planar', bc='transmissive')
+        A = np.vstack([gm.construct_A(f, 'real', **kw), gm.construct_A(f, 'imag', **kw)])
+        L = [gm.construct_L(bf, tau=tau, epsilon=eps, order=o) for o in (0, 1, 2)]
+        blocks.append(dict(A=A, L0=L[0], L1=L[1], L2=0.75 * L[2], nonneg=True, parallel=par, x_scale=0.8 if par else 1.0))
+    w = 2 * np.pi * f
+    z = 1.0 + 1.2 / (1 + (1j * w * 3e-3) ** 0.8) + 1.0 / (0.5 * np.sqrt(1j * w * 2.0) * np.tanh(np.sqrt(1j * w * 2.0)) + 1e-12)
+    rs = np.random.RandomState(2)
+    z = z + 0.003 * (rs.normal(size=nf) + 1j * rs.normal(size=nf))
+    z = z / (np.std(np.abs(z)) / np.sqrt(nf / 81))
+    Z = np.concatenate([z.real, z.imag])
+    kw = dict(sigma_min=0.002, ups_alpha=1.0, ups_beta=0.1, outlier_mode=2, so_lambda=5.0, use_x_sum=True, x_sum_invscale=0.1)
+    prob = Problem(blocks, Z, f, **kw)
+    om = orc.OracleModel(blocks, Z, f, **kw)
+    assert prob.evaluator() == 5 and prob.D == 2 + 2 * K + 4 + 2 * nf + 2 * K + 6 == 1616
+    ctrl = NutsControl(); prob._lib.bdrt_nuts_defaults(C.byref(ctrl)); ctrl.max_treedepth = 4
+    with Sampler(prob, 2, 6, 3, 1234, ctrl) as smp:
+        assert smp.kind() == 4
+        smp.run()
+        draws, lp, diag = smp.results()
+    octrl = orc.nuts_control(max_treedepth=4)
+    for c in range(2):
+        ref, lpr, dr = orc.nuts_sample(om, c, 1234, 6, 3, control=octrl)
+        assert dr['n_leapfrog'] == diag[c]['n_leapfrog'], (c, dr, diag[c])
+        assert np.max(np.abs(draws[c] - ref)) < 1e-6 * np.max(np.abs(ref)), c
+    prob.close()
