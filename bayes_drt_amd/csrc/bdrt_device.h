@@ -74,7 +74,7 @@ struct DevProblem {
     int fast_hw;              // any other family on log-uniform grids that fits: bdrt_tile_hw.h evaluates it
     int toepA;                // fast_s1 and A_re, A_im exactly Toeplitz with nf % 16 <= 2, K % 16 <= 2: the S1 tile's two GEMMs take their
                               // A operands from a [2][tlen] table in LDS instead of streaming packed fragments from L2 (bdrt_tile_s1.h)
-                              // 2: the same for any shape with nf, K >= 16 (toep_gemm_gen: partial tiles, any reduction length)
+                              // 2: the same for any shape with nf, K >= 32 (toep_gemm_gen: partial tiles, any reduction length)
     int tlen;                 // length of one part of that table: 8 (toepA == 2: 16) leading zeros, the nf + K - 1 generators, trailing zeros
     const unsigned *tsteps;   // toepA == 2: the waves' step lists through the two GEMMs, [2][8][TOEP_STEPS][2] (bdrt_tile_s1.h::toep_gen_steps)
     int zrows;                // toepA == 2: rows of the S1 tile's A x region (the imaginary rows start at nf rounded up to four; else 16 tilesA)

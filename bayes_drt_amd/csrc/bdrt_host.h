@@ -77,8 +77,12 @@ struct Problem {
     // headline family's, 2 the general one), decided once -- the call is launch-latency-bound, host microseconds count
     int few_kind = -1, few_ncu = 0;
     // problems beyond the LDS budget (bdrt_big.h): per-point workspace of the evaluator, grown on demand
+    // (ONE buffer per problem, indexed by workgroup: launches on different streams take turns -- each waits for the event the
+    // one before it recorded --, and the bookkeeping is under a mutex)
     double *d_bigws = nullptr;
     size_t bigws_doubles = 0;
+    hipEvent_t bigws_done = nullptr;
+    std::mutex bigws_mu;
     int ensure_bigws(size_t doubles);
 };
 

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(BIG_NT) void big_eval_kernel(const DevProblem *__re
 int Problem::ensure_bigws(size_t doubles)
 {
     if (doubles <= bigws_doubles) return 0;
+    // (growing: hipFree waits for the device, so no launch that was handed the old buffer is still running)
     if (d_bigws) { hipFree(d_bigws); d_bigws = nullptr; bigws_doubles = 0; }
     BDRT_HIP(hipMalloc((void **)&d_bigws, doubles * sizeof(double)));
     bigws_doubles = doubles;
@@ -313,6 +314,11 @@ static int build_problem(Problem &P, const bdrt_dat *dat)
                 nf, dat->nblocks, D.D, D.toep_all, toep_ok[0], dat->nblocks > 1 ? toep_ok[1] : -1, dat->nblocks > 2 ? toep_ok[2] : -1,
                 D.fast_s1, D.fast_hw, D.XR, D.ZR, 1 + D.npar, D.LR, D.XCR, lds_doubles(D) * sizeof(double));
     if (const char *e = getenv("BDRT_DEBUG_SKIP")) D.dbg = atoi(e);
+    // a half-wave evaluator whose tile does not fit while the generic tile does: the generic tile, not the streamed evaluator
+    if (D.fast_s1 && s1_lds_doubles(D) * sizeof(double) + SAMPLER_LDS_RESERVE > 160 * 1024 &&
+        lds_doubles(D) * sizeof(double) + SAMPLER_LDS_RESERVE <= 160 * 1024) { D.fast_s1 = 0; D.toepA = 0; D.tlen = 0; D.zrows = 0; }
+    if (D.fast_hw && hw_lds_doubles(D) * sizeof(double) + SAMPLER_LDS_RESERVE > 160 * 1024 &&
+        lds_doubles(D) * sizeof(double) + SAMPLER_LDS_RESERVE <= 160 * 1024) D.fast_hw = 0;
     P.lds_bytes = std::max(std::max(lds_doubles(D), D.fast_hw ? hw_lds_doubles(D) : (size_t)0), D.fast_s1 ? s1_lds_doubles(D) : (size_t)0) * sizeof(double);
     D.big = 0;
     if (P.lds_bytes + SAMPLER_LDS_RESERVE > 160 * 1024 || getenv("BDRT_BIG")) {
@@ -431,10 +437,15 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
     BDRT_HIP(hipSetDevice(p->device));
     if (p->dev.big) {
         const int grid = std::min(B, 1024);
+        std::lock_guard<std::mutex> lock(p->bigws_mu);
+        // the workspace is the problem's, not the stream's: this launch starts when the previous one (whatever its stream) is done
+        if (!p->bigws_done) BDRT_HIP(hipEventCreateWithFlags(&p->bigws_done, hipEventDisableTiming));
+        else BDRT_HIP(hipStreamWaitEvent(stream, p->bigws_done, 0));
         if (int rc = p->ensure_bigws((size_t)grid * big_ws_doubles(p->dev))) return rc;
         hipLaunchKernelGGL(big_eval_kernel, dim3(grid), dim3(BIG_NT), 0, stream, (const DevProblem *)p->d_dev, p->d_bigws, d_theta, d_spec, B,
                            jacobian, d_lp, d_grad, d_params, d_Zhat, d_sig);
         BDRT_HIP(hipGetLastError());
+        BDRT_HIP(hipEventRecord(p->bigws_done, stream));
         return 0;
     }
     static LdsAttrCache attr_cache;
@@ -557,6 +568,7 @@ void bdrt_problem_destroy(bdrt_problem *p)
     if (P.d_dev) hipFree(P.d_dev);
     if (P.d_theta) { hipFree(P.d_theta); hipFree(P.d_grad); hipFree(P.d_lp); hipFree(P.d_spec); }
     if (P.d_bigws) hipFree(P.d_bigws);
+    if (P.bigws_done) hipEventDestroy(P.bigws_done);
     if (P.stream) hipStreamDestroy(P.stream);
     delete p;
 }

@@ -1268,8 +1268,16 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
 int bdrt_sampler_sync(bdrt_sampler *s)
 {
     if (!s) return -1;
-    BDRT_HIP(hipStreamSynchronize(s->impl.stream));
-    return harvest_events(s->impl, true);
+    Sampler &S = s->impl;
+    BDRT_HIP(hipStreamSynchronize(S.stream));
+    // the live-chain count that picks the next launch's kernel (one chain per wave / per workgroup, the wave kernel's LDS share):
+    // `advance(..., NULL)` does not read the launch's done counter back, a sync does (the last launch wrote it)
+    if (S.solo && S.n_launch > 0) {
+        int done = 0;
+        BDRT_HIP(hipMemcpy(&done, S.d_done, sizeof(int), hipMemcpyDeviceToHost));
+        S.live = std::max(0, S.n_solo - done);
+    }
+    return harvest_events(S, true);
 }
 
 // frees its device pointers unless they were handed over (error paths of the two re-layout passes below)

@@ -655,7 +655,7 @@ int bdrt_qp_box_batch(const double *P, const double *q, const double *lo, int n,
     const size_t msize = (size_t)n * (n + 1) / 2;
     const bool in_lds = vec_bytes + msize * sizeof(double) <= 160 * 1024 - 2560;      // (2.5 KB of static LDS in chol_packed)
     const size_t lds = in_lds ? vec_bytes + msize * sizeof(double) : vec_bytes;
-    if (lds > 160 * 1024) { set_error("bdrt_qp_box_batch: n = %d too large", n); return -2; }
+    if (lds + 2560 > 160 * 1024) { set_error("bdrt_qp_box_batch: n = %d too large", n); return -2; }      // (+ chol_packed's static LDS)
     double *dP = nullptr, *dq = nullptr, *dlo = nullptr, *dx = nullptr, *dobj = nullptr, *dwork = nullptr;
     int *dit = nullptr;
     auto cleanup = [&]() { hipFree(dP); hipFree(dq); hipFree(dlo); hipFree(dx); hipFree(dobj); hipFree(dwork); hipFree(dit); };
@@ -721,7 +721,7 @@ int bdrt_ridge(const bdrt_ridge_options *opt, int nb, int ng, const double *G, c
     const size_t vec = (size_t)(QP_NVEC + 1) * np + 32, extra = (size_t)6 * np + 32 + 2;
     const bool in_lds = (vec + msize + extra) * sizeof(double) <= 160 * 1024 - 2560;
     const size_t lds = (vec + (in_lds ? msize : 0) + extra) * sizeof(double);
-    if (lds > 160 * 1024) { set_error("bdrt_ridge: n = %d too large", n); return -2; }
+    if (lds + 2560 > 160 * 1024) { set_error("bdrt_ridge: n = %d too large", n); return -2; }      // (+ chol_packed's static LDS)
     std::vector<void *> owned;
     auto cleanup = [&]() { for (void *p : owned) hipFree(p); };
 #define RG_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return -10; } } while (0)

@@ -602,6 +602,9 @@ def main():
                        'evals_in_timed_region': evals, 'timed_region_s': elapsed, 'setup_ms': setup_ms},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F64_MFMA_TFLOPS, 'traffic': traffic,
+                         # `traffic` is NOT measured by this process: it is bytes-per-round of the committed PMC passes x the rounds
+                         # of a launch (PMC counters need rocprofv3 around the process: tools/profile_bench.sh)
+                         'traffic_measured': False,
                          'kernel': 'nuts_kernel', 'avg_launch_ms': avg_ms, 'launches': launches,
                          'flop_per_eval_algorithmic': FLOP_PER_EVAL,
                          # the same launch priced on what the structured path executes (band convolutions instead of dense
@@ -622,7 +625,9 @@ def main():
         if strong is not None:
             line['config']['strong_scaling'] = strong
         elif world == 1:
-            line['config']['strong_scaling'] = {'workload': 'BASELINE config 4 as written: %d spectra x %d chains in total' % (N_SPECTRA, args.chains),
+            is_config4 = args.spectra == N_SPECTRA and args.chains == CHAINS_PER_SPECTRUM
+            line['config']['strong_scaling'] = {'workload': ('BASELINE config 4 as written: %d spectra x %d chains in total' % (N_SPECTRA, args.chains)) if is_config4
+                                                else ('this run\'s own job (%d spectra x %d chains: NOT config 4)' % (args.spectra, args.chains)),
                                                 'value': value, 'unit': 'evals/s', 'note': 'the headline job itself at N = 1'}
         if mid is not None:
             line['config']['mid_occupancy'] = mid          # sampler_kind 0: 16 chains per workgroup, 1: one chain per 512-thread workgroup, 3: one chain per wave
