@@ -117,6 +117,40 @@ print(n, time.perf_counter() - t0)
 ''' % ROOT
 
 
+_CPU_TUNED_WORKER = r'''
+import sys, time, numpy as np
+sys.path.insert(0, %r)
+from oracle import oracle as orc
+from bench import synth_spectra, NF, K
+f, Z = synth_spectra(1)
+tau = 1 / (2 * np.pi * np.logspace(10, -6, K)); eps = 1 / np.mean(np.diff(np.log(tau)))
+A = np.vstack([orc.construct_A(f, 'real', tau=tau, epsilon=eps), orc.construct_A(f, 'imag', tau=tau, epsilon=eps)])
+blk = dict(A=A, L0=orc.construct_L(tau, eps, 0), L1=orc.construct_L(tau, eps, 1), L2=0.75 * orc.construct_L(tau, eps, 2), nonneg=True)
+banded, budget = int(sys.argv[1]) != 0, float(sys.argv[2])
+m = orc.TunedS1(blk, Z[0], f, ups_alpha=1.0, ups_beta=0.1, banded=banded)
+assert m.banded == banded
+th = np.random.default_rng(int(sys.argv[3])).uniform(-1, 1, m.D)
+n = 0; chunk = 200; m.bench(th, 50)
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < budget:
+    m.bench(th, chunk); n += chunk
+print(n, time.perf_counter() - t0)
+''' % ROOT
+
+
+def _cpu_tuned_leg(nproc, seconds, banded):
+    procs = [subprocess.Popen([sys.executable, '-c', _CPU_TUNED_WORKER, str(int(banded)), str(seconds), str(i)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, cwd=ROOT) for i in range(nproc)]
+    total = 0.0
+    for p in procs:
+        out, err = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('cpu_baseline.tuned worker failed: ' + err.decode()[-400:])
+        n, t = out.decode().split()
+        total += float(n) / float(t)
+    return total
+
+
 def _cpu_leg(nproc, seconds):
     env = dict(os.environ, BDRT_ORACLE_NATIVE='1')
     procs = [subprocess.Popen([sys.executable, '-c', _CPU_WORKER, str(i), str(seconds)], stdout=subprocess.PIPE,
@@ -174,6 +208,21 @@ def cpu_baseline(seconds=8.0):
     # a box that grants fewer cores than it shows (no readable quota) gives itself away by the aggregate: report the
     # parallelism actually obtained beside the process count
     effective = allc / single if single > 0 else float(ncores)
+    # the tuned leg (oracle/bdrt_tuned.c: the same formulas from a preallocated workspace, vectorised products): raw
+    # log-posterior + gradient evaluations, dense (SURVEY 8(d)'s accounting: A, A^T and the three K x K penalty operators as full
+    # products) and banded (the penalty operators through their 13 diagonals: what the GPU's structured path executes)
+    tuned = None
+    try:
+        orc.tuned_lib(force=True)
+        ts = min(seconds, 4.0)
+        tuned = dict(unit='evals/s', cores=ncores,
+                     dense=dict(single_core=_cpu_tuned_leg(1, ts, False), value=_cpu_tuned_leg(ncores, ts, False)),
+                     banded=dict(single_core=_cpu_tuned_leg(1, ts, True), value=_cpu_tuned_leg(ncores, ts, True)),
+                     sample='raw log-posterior + gradient evaluations of oracle/bdrt_tuned.c (Series_pos 81x161, jacobian on; checked against the '
+                            'oracle by tests/test_oracle_tuned.py), gcc -O3 -march=native -ffp-contract=fast: 1 process, then %d processes, %.0f s each; '
+                            'NOT inside a NUTS driver (a leapfrog is one evaluation plus O(D) vector work)' % (ncores, ts))
+    except Exception as e:          # noqa: BLE001 -- the tuned figure is context, the line must not depend on it
+        tuned = dict(error=str(e)[-200:])
     model = ''
     try:
         with open('/proc/cpuinfo') as fh:
@@ -181,7 +230,7 @@ def cpu_baseline(seconds=8.0):
     except OSError:
         pass
     return dict(value=allc, unit='evals/s', cores=ncores, kind='port', tuning=CPU_PORT_NOTE, single_core=single,
-                cpu_model=model, logical_cpus=os.cpu_count(), effective_parallelism=effective, pystan_derived=PYSTAN_DERIVED,
+                cpu_model=model, logical_cpus=os.cpu_count(), effective_parallelism=effective, pystan_derived=PYSTAN_DERIVED, tuned=tuned,
                 sample='leapfrogs of real NUTS warm-up transitions (oracle/nuts_oracle.c driving oracle/bdrt_oracle.c, '
                        'Series_pos 81x161, jacobian on), gcc -O3 -march=native: 1 process x %.0f s (single_core), then %d '
                        'processes x %.0f s, one chain per core (value)' % (seconds, ncores, seconds))

@@ -313,3 +313,55 @@ def eval_loop(model, theta0, n, jacobian=True):
     fn = lib().orc_eval_loop
     fn.restype = C.c_double
     return fn(C.byref(model.m), _p(_f64(theta0)), int(n), int(jacobian))
+
+
+# ---- the tuned CPU evaluator of the headline family (oracle/bdrt_tuned.c): bench.py's cpu_baseline.tuned, checked against the oracle
+_TUNED = None
+
+
+def tuned_lib(force=False):
+    global _TUNED
+    so = os.path.join(_HERE, 'libtuned_native.so')
+    src = os.path.join(_HERE, 'bdrt_tuned.c')
+    if force and os.path.exists(so):
+        os.remove(so); _TUNED = None
+    if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+        subprocess.check_call(['make', '-s', '-C', _HERE, 'libtuned_native.so'])
+    if _TUNED is None:
+        _TUNED = C.CDLL(so)
+        _TUNED.tuned_s1_create.restype = C.c_void_p
+        _TUNED.tuned_s1_logp_grad.restype = C.c_double
+        _TUNED.tuned_s1_bench.restype = C.c_double
+        _TUNED.tuned_s1_is_banded.restype = C.c_int
+    return _TUNED
+
+
+class TunedS1:
+    """Series / Series_pos without outlier parameters on one DRT block: the oracle's log-posterior and gradient from a preallocated
+    workspace, dense (banded=False) or through the diagonals of the penalty operators when they are banded Toeplitz."""
+
+    def __init__(self, blk, Z, freq, sigma_min=0.002, ups_alpha=1.0, ups_beta=0.1, induc_scale=1.0, banded=True):
+        L = tuned_lib()
+        self._a = [_f64(blk[k]) for k in ('A', 'L0', 'L1', 'L2')] + [_f64(Z), _f64(freq)]
+        A = self._a[0]
+        self.nf, self.K = A.shape[0] // 2, A.shape[1]
+        self.D = 2 * self.K + 9
+        self.h = C.c_void_p(L.tuned_s1_create(C.c_int(self.nf), C.c_int(self.K), C.c_int(int(bool(blk.get('nonneg', False)))),
+                                              *[_p(a) for a in self._a[:5]], _p(self._a[5]), C.c_double(sigma_min), C.c_double(ups_alpha),
+                                              C.c_double(ups_beta), C.c_double(induc_scale), C.c_int(int(banded))))
+        self.banded = bool(L.tuned_s1_is_banded(self.h))
+
+    def logp_grad(self, theta, jacobian=True):
+        th = _f64(theta); g = np.empty(self.D)
+        lp = tuned_lib().tuned_s1_logp_grad(self.h, _p(th), C.c_int(int(jacobian)), _p(g))
+        return float(lp), g
+
+    def bench(self, theta0, n):
+        th = _f64(theta0); g = np.empty(self.D)
+        return float(tuned_lib().tuned_s1_bench(self.h, _p(th), C.c_int(int(n)), _p(g)))
+
+    def __del__(self):
+        try:
+            tuned_lib().tuned_s1_destroy(self.h)
+        except Exception:
+            pass
