@@ -7,7 +7,7 @@ TAG=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT/bayes_drt_amd/csrc"
 mkdir -p ../variants
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -w -mllvm -disable-machine-licm "$@" -c bdrt_nuts_k0.hip -o ../variants/k0_$TAG.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -w -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp "$@" -c bdrt_nuts_k0.hip -o ../variants/k0_$TAG.o
 OBJS=$(ls *.o | grep -v bdrt_nuts_k0.o)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../variants/libbdrt_$TAG.so ../variants/k0_$TAG.o $OBJS
 echo built bayes_drt_amd/variants/libbdrt_$TAG.so

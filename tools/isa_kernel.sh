@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$OUT"
 F="$OUT/probe_${NJ}_${MODE}_${TA}.hip"
 printf '#include "bdrt_nuts16.h"\nnamespace bdrt { BDRT_NUTS16_DEFINE(%s, %s, %s) }\n' "$NJ" "$MODE" "$TA" > "$F"
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -mllvm -disable-machine-licm -w \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp -w \
     -I"$ROOT/bayes_drt_amd/csrc" $ISA_FLAGS --offload-device-only -S "$F" -o "$OUT/probe_${NJ}_${MODE}_${TA}.s"
 S="$OUT/nuts_kernel_${NJ}_${MODE}_${TA}.s"
 awk '/^_ZN4bdrt11nuts_kernel.*:/{p=1} p{print} /^\.Lfunc_end/{if(p)exit}' "$OUT/probe_${NJ}_${MODE}_${TA}.s" > "$S"
