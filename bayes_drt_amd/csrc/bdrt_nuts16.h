@@ -75,6 +75,9 @@ __device__ __forceinline__ void lds_wave_sync()
 #ifndef BDRT_NT
 #define BDRT_NT 1
 #endif
+#ifndef BDRT_KARG_RELOAD
+#define BDRT_KARG_RELOAD 1
+#endif
 #ifndef BDRT_NUTS_EARLY_STATE
 #define BDRT_NUTS_EARLY_STATE 1
 #endif
@@ -229,7 +232,20 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
         for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; pr_[m] = valid ? Pm[j] : 0.0; mir_[m] = valid ? MI[j] : 1.0; }
     }
 
-    for (int round = 0; round < a.rounds; ++round) {
+    // The kernel's by-value arguments (48 dwords of NutsParams / NutsArgs) are read where they are used, from the kernarg segment,
+    // through a pointer the optimiser cannot see through: kept in scalar registers across the round loop they -- with the masks and
+    // addresses of the evaluator -- oversubscribe the 102 SGPRs, and an SGPR spilled to a VGPR lane costs a v_writelane / v_readlane
+    // (VALU instructions: 700 of them in the round loop's listing, profiles/r05/isa_mix_nuts_kernel.txt) per use.
+    struct KArgs { const DevProblem *Pp; NutsParams np; NutsArgs a; };
+    typedef const __attribute__((address_space(4))) KArgs *kargs_ptr;
+    kargs_ptr ka = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const int n_rounds = a.rounds;
+    for (int round = 0; round < n_rounds; ++round) {
+#if BDRT_KARG_RELOAD
+        __asm__ volatile("" : "+s"(ka));
+        const NutsParams &np = *(const NutsParams *)&ka->np;
+        const NutsArgs &a = *(const NutsArgs *)&ka->a;
+#endif
         // keep per-lane address arithmetic inside the loop (see the note in bdrt_tile_s1.h): hoisted, it is spilled
         __asm__ volatile("" : "+v"(c), "+v"(l32));
         if (SPEC && tid < NC) hvy[tid] = 0;
