@@ -308,7 +308,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             if constexpr (!EARLY) load_state();
         }
         else if (MODE == 3) { logp_grad_tile_s1<false, 32, NoHook, NoHook, 0, KUX>(P, io, smem); load_state(); }
-        else if (MODE == 4) { logp_grad_tile_hw<KUX>(P, io, smem); load_state(); }
+        else if (MODE == 4) { logp_grad_tile_hw<KUX, PROF>(P, io, smem); load_state(); }
         else { logp_grad_tile<MODE == 1>(P, io, smem); load_state(); }
         if (io.prof && tid == 0) tnp = clock64();
         BDRT_WAVE_PROF(17);

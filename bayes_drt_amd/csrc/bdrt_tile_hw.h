@@ -31,7 +31,8 @@ __host__ __device__ inline int hw_kmax(const DevProblem &P)
 
 // All threads of the workgroup must call.  Ends with a __syncthreads().  KU: basis functions per lane (every block's K <= 32 KU),
 // as in logp_grad_tile_s1.
-template <int KU = 6>
+// PROFT: the profiling instantiation (slots 4..8, 25..31 of the sampler's phase profile: wave-summed cycles of the sub-phases).
+template <int KU = 6, bool PROFT = false>
 __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, double *smem)
 {
     int tid = threadIdx.x;
@@ -45,6 +46,9 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
     const bool valid = c < io.nvalid;
     const int cc = valid ? c : 0;
     const double jac = io.jacobian ? 1.0 : 0.0;
+    long long thw = (PROFT && io.prof) ? clock64() : 0;
+#define BDRT_HW_PROF(slot) do { if (PROFT && io.prof) { const long long t_ = clock64(); \
+        if (lane == 0) atomicAdd((unsigned long long *)&io.prof[slot], (unsigned long long)(t_ - thw)); thw = t_; } } while (0)
 
     double *Xs = smem;
     double *Zh = Xs + (size_t)P.XR * NC;
@@ -121,8 +125,11 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
             }
         }
         const double d0 = __shfl(sraw, hb | (6 + 3 * b)), d1 = __shfl(sraw, hb | (7 + 3 * b)), d2 = __shfl(sraw, hb | (8 + 3 * b));
+        BDRT_HW_PROF(4);
         __syncthreads();                                                   // B1: X_b of all 16 chains in the operand tile
+        BDRT_HW_PROF(5);
         gemm_sw<NWV, GPFV>(B.Af, B.tilesA, B.kpairs, Xs, Zh, wave, lane); // Zh = A_b x_b (pad rows: exact zeros)
+        BDRT_HW_PROF(6);
 
         // ---- P2 (M2): v_i = L_i x, q / ups / dups priors, w_i, sum_i L_i^T w_i on the private row ------------------------------
         {
@@ -233,7 +240,9 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
                 GW(B.o_d + i, -0.5 * sraw * sv - 6.0 + 5.0 * lean_rcp(sraw) + jac);
             }
         }
+        BDRT_HW_PROF(7);
         __syncthreads();                                                   // B2: A_b x_b of all chains in Zh
+        BDRT_HW_PROF(8);
         // ---- accumulate Z_hat; a parallel block contributes conj(Y)/|Y|^2 and parks Y ----------------------------------------
         double *Y = Yp + (size_t)B.yp_slot * TA * NC;
         double yr_[UNV], yi_[UNV];
@@ -256,6 +265,7 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
             }
         }
         // (the next block's B1 separates these reads from its GEMM's writes to Zh)
+        BDRT_HW_PROF(25);
     }
 
     // ================================================= x_sum prior, likelihood ==============================================
@@ -350,6 +360,7 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
         }
     }
 
+    BDRT_HW_PROF(26);
     // ================================================= backward, block by block ===========================================
 #pragma unroll 1
     for (int b = 0; b < nblocks; ++b) {
@@ -382,9 +393,13 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
             Zh[swz(n, c)] = rr;
             Zh[swz(nf + n, c)] = ri;
         }
+        BDRT_HW_PROF(27);
         __syncthreads();                                                   // B3: operand of all chains in Zh
+        BDRT_HW_PROF(28);
         gemm_sw<NWV, GPFV>(B.BkA, B.tilesK, B.rpairsA, Zh, Xs, wave, lane);   // Xs = A_b^T (.)
+        BDRT_HW_PROF(29);
         __syncthreads();                                                   // B4
+        BDRT_HW_PROF(30);
         {
             double tx_[UKV], gl_[UKV], ex_[UKV], ag_[UKV];
 #pragma unroll
@@ -408,11 +423,13 @@ __device__ inline void logp_grad_tile_hw(const DevProblem &P, const TileIO &io, 
             }
         }
         // (the next block's B3 comes after every wave has left this epilogue: Xs and Zh are free again by then)
+        BDRT_HW_PROF(31);
     }
     lp = hsum<LPC>(lp);
     const bool rej = __shfl((int)reject, hb) != 0;
     if (l32 == 0 && io.lp && valid) io.lp[c] = rej ? -INFINITY : lp;
     __syncthreads();
+#undef BDRT_HW_PROF
 }
 
 }  // namespace bdrt

@@ -802,6 +802,9 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
 #ifndef BDRT_EARLY_P2
 #define BDRT_EARLY_P2 1
 #endif
+#ifndef BDRT_P2_OPAQUE_K
+#define BDRT_P2_OPAQUE_K 1
+#endif
     constexpr bool EARLY_P2 = BDRT_EARLY_P2 != 0;
     double zre_[UNV], zim_[UNV], wn_[UNV];
     auto load_spectrum = [&]() {
@@ -870,7 +873,12 @@ __device__ inline void logp_grad_tile_s1(const DevProblem &P, const TileIO &io, 
         double w0_[UKV], w1_[UKV], w2_[UKV], gup[UKV];
 #pragma unroll
         for (int u = 0; u < UKV; ++u) {
-            const int k = kb + u;
+            // (k through an opaque copy per element: with k = kb + u visible the compiler forms the lane masks of all six elements'
+            // range tests at once, up front -- ten SGPR pairs that do not fit and travel through v_writelane / v_readlane)
+            int k = kb + u;
+#if BDRT_P2_OPAQUE_K
+            __asm__ volatile("" : "+v"(k));
+#endif
             w0_[u] = 0.0; w1_[u] = 0.0; w2_[u] = 0.0; gup[u] = 0.0;
             if (k < K) {
                 const double um2 = ue[u], um1 = ue[u + 1], uu = ue[u + 2], up1 = ue[u + 3], up2 = ue[u + 4];

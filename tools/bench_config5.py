@@ -56,6 +56,10 @@ if prof:
     # wide-vector kernels (D > 512): per-wave averages of the round's stages (bdrt_nuts.hip, bdrt_nuts_wide.h)
     for nm, k in (('evaluation (MFMA tile)', 17), ("chain's own pass (phase P)", 18), ('cooperative phase (phase H)', 20), ('round barrier wait', 23)):
         print('WAVE-AVG %-28s %8.0f cycles/round' % (nm, cyc[k] / wr))
+    if cyc[4]:                                                   # sub-phases of the half-wave evaluator (bdrt_tile_hw.h, PROFT), both blocks summed
+        print('EVALUATOR per wave-round: ' + ', '.join('%s %.0f' % (nm, cyc[k] / wr) for nm, k in (
+            ('P1', 4), ('B1 wait', 5), ('A x', 6), ('prior chain', 7), ('B2 wait', 8), ('accumulate', 25), ('likelihood', 26),
+            ('operand', 27), ('B3 wait', 28), ('A^T g', 29), ('B4 wait', 30), ('epilogue', 31))))
     for k, nm in enumerate(['finished by its own pass', 'with a chain finished cooperatively']):
         if cyc[2 * k + 1]: print('WAVE-CLASS %-36s %5.1f %% of wave-rounds, %8.0f cycles after the evaluation' % (
             nm, 100.0 * cyc[2 * k + 1] / wr, cyc[2 * k] / cyc[2 * k + 1]))

@@ -80,6 +80,27 @@ fi
 if has config5; then
   python tools/bench_config5.py 4096 --phase-profile 2>&1 | grep -v amdgpu.ids > $OUT/config5.txt
   python tools/config5_run.py 2>&1 | grep -v amdgpu.ids > $OUT/config5_run.txt
+  # the same load with fewer workgroups on the chip (16 chains each): what the row passes cost without the other CUs' traffic
+  for n in 2048 1024 256; do
+    BDRT_CHAINS_PER_WG=16 BDRT_COMPACTION=0 BDRT_TAIL_MIGRATION=0 BDRT_WAVE=0 python tools/bench_config5.py $n --phase-profile 2>&1 | grep -v amdgpu.ids | head -6
+  done > $OUT/config5_fewer_workgroups.txt
+  # rocprofv3 records of nuts_kernel<27,4,0>: kernel trace, HBM counters (separate passes), SQ counters
+  timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r05_c5 -o run -- python3 tools/bench_config5.py 4096 > $OUT/config5_trace.log 2>&1
+  DB=$(find gpurun_out/prof_r05_c5 -name '*.db' | head -1); [ -n "$DB" ] && python3 tools/rocpd_summary.py "$DB" > $OUT/config5_kernel_stats.txt
+  : > $OUT/config5_pmc.txt
+  for CTR in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $CTR -d gpurun_out/pmc_r05_c5_$CTR -o run -- python3 tools/bench_config5.py 4096 > $OUT/config5_pmc_$CTR.log 2>&1
+    DB=$(find gpurun_out/pmc_r05_c5_$CTR -name '*.db' | head -1)
+    [ -n "$DB" ] && python3 - "$DB" >> $OUT/config5_pmc.txt <<'PY'
+import sqlite3, sys
+cur = sqlite3.connect(sys.argv[1]).cursor()
+for r in cur.execute("select counter_name, count(*), avg(value), max(value) from counters_collection where kernel_name like '%nuts_kernel%' group by counter_name"):
+    print('%-12s dispatches %4d (50 rounds of 4096 chains each)  avg/dispatch %.6g  max %.6g   [raw counter units: KB on this image]' % r)
+PY
+    rm -f $OUT/config5_pmc_$CTR.log
+  done
+  bash tools/profile_pmc.sh r05_c5 nuts_kernel tools/bench_config5.py 4096 > $OUT/config5_sq.log 2>&1
+  grep -v "simple_timer\|amdgpu.ids" gpurun_out/pmc_r05_c5/summary.txt > $OUT/config5_sq.txt
 fi
 if has hmc; then
   python tools/hmc_suite_many.py 2>&1 | grep -v amdgpu.ids > $OUT/hmc_suite_many.txt
@@ -88,5 +109,5 @@ if has fuzz; then
   python -m tests.fuzz_parity --first 4000 --count 300 > $OUT/fuzz_parity.txt 2>&1
   python -m tests.fuzz_inverter --first 4000 --count 100 > $OUT/fuzz_inverter.txt 2>&1
 fi
-find $OUT gpurun_out/prof_r05 gpurun_out/sq_r05 gpurun_out/prof_r05_wave gpurun_out/pmc_r05_1024 gpurun_out/pmc_r05_2048 -name '*.db' -size +20M -delete 2>/dev/null
+find $OUT gpurun_out/prof_r05_c5 gpurun_out/pmc_r05_c5 gpurun_out/pmc_r05_c5_FETCH_SIZE gpurun_out/pmc_r05_c5_WRITE_SIZE gpurun_out/prof_r05 gpurun_out/sq_r05 gpurun_out/prof_r05_wave gpurun_out/pmc_r05_1024 gpurun_out/pmc_r05_2048 -name '*.db' -size +20M -delete 2>/dev/null
 ls -la $OUT
