@@ -151,6 +151,8 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
             kin = mi * p * p;
             nonfin = isfinite(gj) ? 0.0 : 1.0;
         }
+        // (measured and dropped: the U-turn products of the first three merge levels -- known from the leaf index -- in this same
+        // block reduction: stages C + D 3.2 k -> 2.9 k cycles, the evaluation + 0.5 k from the registers it takes; 6.12 -> 6.32 us)
         solo_block_sum2(kin, nonfin, red, slot, wave, lane);
         kin *= 0.5;
         BDRT_SOLO_NPROF(5);
@@ -674,10 +676,10 @@ static bool solo_duo_fits(const DevProblem &P)
 }
 
 // Which kernel advances the one-chain layout (state rows [unit][SG_COUNT][ds]) while `live` chains are running: the one-chain-per-
-// wave kernel from 2.5 live chains per CU on (measured at 81 x 161, profiles/r04/wave_sweep.txt: below that two 512-thread
-// workgroups per CU are faster per leapfrog, above it eight independent waves per CU are), up to the eight per CU it keeps
-// resident.  BDRT_WAVE=1 / 0: always / never.
-static bool wave_pays(int live, int n_cu) { return 2 * live > 5 * n_cu; }
+// wave kernel from more than two live chains per CU on (measured at 81 x 161, profiles/r05/kernel_sweep.txt: up to two per CU two
+// 512-thread workgroups finish a round in 9.4 us; a third chain on any CU is a second turn for them, 14.6 us, against 13.1 us of
+// the wave kernel), up to the eight per CU it keeps resident.  BDRT_WAVE=1 / 0: always / never.
+static bool wave_pays(int live, int n_cu) { return live > 2 * n_cu; }
 static int wave_max_units(int n_cu) { return 8 * n_cu; }      // (a ninth chain on any CU is a second turn of the machine: 31 us per round instead of 19)
 
 // liveness of every unit (1: the chain is still running), for the host's re-packing decision

@@ -24,7 +24,7 @@ struct Wide1Geom {
 __host__ __device__ inline Wide1Geom wide1_geometry(int nf, int K, int D, int nb)
 {
     Wide1Geom G;
-    G.g = solo_geometry(nf, K, D);
+    G.g = solo_geometry(nf, K, D, false);
     G.nb = nb;
     const SoloGeom &g = G.g;
     int o = 0;

@@ -78,7 +78,10 @@ if has map; then
   python tools/lbfgs_pin.py 2>&1 | grep -v amdgpu.ids > $OUT/lbfgs_pin.txt
 fi
 if has config5; then
-  python tools/bench_config5.py 4096 --phase-profile 2>&1 | grep -v amdgpu.ids > $OUT/config5.txt
+  python tools/bench_config5.py 4096 2>&1 | grep -v amdgpu.ids > $OUT/config5.txt                       # the rate (production kernel)
+  python tools/bench_config5.py 4096 --series-outliers 2>&1 | grep -v amdgpu.ids >> $OUT/config5.txt
+  echo '-- with the phase profile (profiling kernel, ~5 % slower):' >> $OUT/config5.txt
+  python tools/bench_config5.py 4096 --phase-profile 2>&1 | grep -v amdgpu.ids >> $OUT/config5.txt
   python tools/config5_run.py 2>&1 | grep -v amdgpu.ids > $OUT/config5_run.txt
   # the same load with fewer workgroups on the chip (16 chains each): what the row passes cost without the other CUs' traffic
   for n in 2048 1024 256; do
