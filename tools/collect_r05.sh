@@ -75,6 +75,7 @@ fi
 if has map; then
   python tools/map_timing.py > $OUT/map_timing.txt 2>&1
   python tools/map_suite_run.py > $OUT/map_suite.txt 2>&1
+  python tools/map_suite_many.py 2>&1 | grep -v amdgpu.ids > $OUT/map_suite_many.txt
   python tools/lbfgs_pin.py 2>&1 | grep -v amdgpu.ids > $OUT/lbfgs_pin.txt
 fi
 if has config5; then
