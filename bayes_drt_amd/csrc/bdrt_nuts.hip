@@ -195,14 +195,11 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
                 if (divergent) {
                     endt = 2;
                 } else {
-                    // log_sum_exp2(lsw_sub, w) and the acceptance test u < exp(w - lsw_new) from ONE exponential, t = exp(-|lsw_sub - w|):
-                    // lsw_new = max + log(1 + t) as in log_sum_exp2 (bit for bit), exp(w - lsw_new) = (w >= lsw_sub ? 1 : t) / (1 + t) --
-                    // the second exponential and the logarithm are off the path to the decision (three dependent transcendentals before)
-                    const double lsw_sub = s.lsw_sub, dd = lsw_sub - w;
-                    const double t = BDRT_NUTS_EXP(-fabs(dd));
                     const double u = lps_l[1];                          // drawn by wave 7 before the evaluation
-                    if (leaf_now == 0 || u * (1.0 + t) < (dd <= 0.0 ? 1.0 : t)) { copyq = true; s.lpq = lp; }
-                    s.lsw_sub = lsw_sub == -INFINITY ? w : fmax(lsw_sub, w) + ::bdrt::lean_log(1.0 + t);
+                    double lsw_new;
+                    const bool joins = nuts_leaf_joins(s.lsw_sub, w, u, lsw_new);           // (one exponential: bdrt_nuts_device.h)
+                    if (leaf_now == 0 || joins) { copyq = true; s.lpq = lp; }
+                    s.lsw_sub = lsw_new;
                     tree = true;
                     while ((leaf_now >> nm) & 1) ++nm;
                     last = leaf_now == s.nleaves - 1;

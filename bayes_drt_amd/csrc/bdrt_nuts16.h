@@ -448,10 +448,11 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
                         s.n_leap_iter = s.n_leap_iter + 1;
                         const double w = H0 - h;
                         s.sum_metro = s.sum_metro + (w > 0.0 ? 1.0 : BDRT_NUTS_EXP(w));
-                        const double lsw_new = log_sum_exp2(s.lsw_sub, w);
                         // uniform sampling inside the new subtree: keep leaf i with probability w_i / W_i
                         const double u = rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
-                        const bool copyq = leaf_now == 0 || u < BDRT_NUTS_EXP(w - lsw_new);
+                        double lsw_new;
+                        const bool joins = nuts_leaf_joins(s.lsw_sub, w, u, lsw_new);       // (bdrt_nuts_device.h)
+                        const bool copyq = leaf_now == 0 || joins;
                         s.lsw_sub = lsw_new;
                         s.leaf = leaf_now + 1;
                         if (copyq) {

@@ -97,6 +97,25 @@ __host__ __device__ inline double log_sum_exp2(double a, double b)
     return a > b ? a + BDRT_NUTS_LOG1P_EXP(b - a) : b + BDRT_NUTS_LOG1P_EXP(a - b);
 }
 
+// A leaf joins a subtree of log-weight lsw_sub with log-weight w: the subtree's new log-weight (log_sum_exp2(lsw_sub, w), bit for bit)
+// and whether the leaf replaces the subtree's proposal, u < exp(w - lsw_new) (Stan base_nuts::build_tree: multinomial sampling inside
+// the subtree).  Device code takes both from ONE exponential, t = exp(-|lsw_sub - w|): lsw_new = max + log(1 + t), and
+// exp(w - lsw_new) = (w >= lsw_sub ? 1 : t) / (1 + t) -- the second exponential and the logarithm are off the path to the decision
+// (three dependent transcendentals before; the decision can differ from the other form's only where u meets the probability to the
+// last bit).  Host code (the logic's unit tests) keeps the textbook form.
+__host__ __device__ inline bool nuts_leaf_joins(double lsw_sub, double w, double u, double &lsw_new)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double dd = lsw_sub - w;
+    const double t = BDRT_NUTS_EXP(-fabs(dd));
+    lsw_new = lsw_sub == -INFINITY ? w : fmax(lsw_sub, w) + ::bdrt::lean_log(1.0 + t);
+    return u * (1.0 + t) < (dd <= 0.0 ? 1.0 : t);
+#else
+    lsw_new = log_sum_exp2(lsw_sub, w);
+    return u < BDRT_NUTS_EXP(w - lsw_new);
+#endif
+}
+
 // chain phases
 enum { PH_INIT = 0, PH_EPS = 1, PH_TREE = 2, PH_DONE = 3, PH_FAILED = 4 };
 
@@ -242,9 +261,10 @@ __host__ __device__ inline void nuts_tree_leaf(S &s, const NutsParams &np, const
         endt = 2;               // transition ends, subtree discarded, divergent
         return;
     }
-    const double lsw_new = log_sum_exp2(s.lsw_sub, w);
     const double u = u_pre ? *u_pre : rng_uniform(rng, (uint32_t)leaf_now, RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
-    if (leaf_now == 0 || u < BDRT_NUTS_EXP(w - lsw_new)) { copyq = true; s.lpq = lp; }
+    double lsw_new;
+    const bool joins = nuts_leaf_joins(s.lsw_sub, w, u, lsw_new);
+    if (leaf_now == 0 || joins) { copyq = true; s.lpq = lp; }
     s.lsw_sub = lsw_new;
     tree = true;
     while ((leaf_now >> nm) & 1) ++nm;              // trailing ones = sub-subtrees ending here

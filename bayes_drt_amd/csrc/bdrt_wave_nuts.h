@@ -186,9 +186,10 @@ __global__ __launch_bounds__(WV_NT, 2) void nuts_wave_kernel(const DevProblem *_
                 if (divergent) {
                     endt = 2;
                 } else {
-                    const double lsw_new = log_sum_exp2(s.lsw_sub, w);
                     const double u = wv_bcast(uvec, __builtin_amdgcn_readfirstlane(leaf_now & 63));
-                    if (leaf_now == 0 || u < BDRT_NUTS_EXP(w - lsw_new)) { copyq = true; s.lpq = lp; }
+                    double lsw_new;
+                    const bool joins = nuts_leaf_joins(s.lsw_sub, w, u, lsw_new);           // (bdrt_nuts_device.h)
+                    if (leaf_now == 0 || joins) { copyq = true; s.lpq = lp; }
                     s.lsw_sub = lsw_new;
                     tree = true;
                     while ((leaf_now >> nm) & 1) ++nm;
