@@ -113,5 +113,8 @@ if has fuzz; then
   python -m tests.fuzz_parity --first 4000 --count 300 > $OUT/fuzz_parity.txt 2>&1
   python -m tests.fuzz_inverter --first 4000 --count 100 > $OUT/fuzz_inverter.txt 2>&1
 fi
-find $OUT gpurun_out/prof_r05_c5 gpurun_out/pmc_r05_c5 gpurun_out/pmc_r05_c5_FETCH_SIZE gpurun_out/pmc_r05_c5_WRITE_SIZE gpurun_out/prof_r05 gpurun_out/sq_r05 gpurun_out/prof_r05_wave gpurun_out/pmc_r05_1024 gpurun_out/pmc_r05_2048 -name '*.db' -size +20M -delete 2>/dev/null
+# (what travels back is limited to 64 MiB: the rocprofv3 databases stay on the box, their summaries are in $OUT)
+find gpurun_out -name '*.db' -delete 2>/dev/null
+find gpurun_out -name '*.csv' -size +1M -delete 2>/dev/null
+du -sh gpurun_out
 ls -la $OUT
