@@ -77,6 +77,7 @@ if has map; then
   python tools/map_suite_run.py > $OUT/map_suite.txt 2>&1
   python tools/map_suite_many.py 2>&1 | grep -v amdgpu.ids > $OUT/map_suite_many.txt
   python tools/lbfgs_pin.py 2>&1 | grep -v amdgpu.ids > $OUT/lbfgs_pin.txt
+  python tools/lbfgs_cap_seeds.py 2>&1 | grep -v amdgpu.ids > $OUT/lbfgs_cap_seeds.txt
 fi
 if has config5; then
   python tools/bench_config5.py 4096 2>&1 | grep -v amdgpu.ids > $OUT/config5.txt                       # the rate (production kernel)
