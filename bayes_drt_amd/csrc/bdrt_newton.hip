@@ -79,63 +79,65 @@ __device__ inline bool chol_blocked(double *M, int Dp, double *lds, NewtonProf &
     int *bad = reinterpret_cast<int *>(Pn + (size_t)Dp * 17);
     const int nblk = Dp / 16;
     if (tid == 0) *bad = 0;
-    __syncthreads();
-    for (int J = 0; J < nblk; ++J) {
-        const int j0 = 16 * J;
-        // (a) diagonal block -> LDS, factored by 16 threads of wave 0
-        if (tid < 256) Dg[(tid >> 4) * 17 + (tid & 15)] = M[(size_t)(j0 + (tid >> 4)) * Dp + j0 + (tid & 15)];
-        __syncthreads();
-        if (wave == 0) {
-            // lane i keeps row i of the block in registers.  Column j of the factor is read out of the lanes that own it
-            // (v_readlane -> SGPR operand of the multiply-add): no LDS round trips, no branches inside the 16 steps; a
-            // non-positive pivot poisons the block with NaNs and is reported after the last step.
-            const int i = lane & 15;
-            double row[16];
+    // Factor the 16 x 16 diagonal block that sits in Dg (row-major, stride 17) by the 16 rows' lanes of ONE wave, and the block J of the
+    // forward substitution with it.  Lane i keeps row i of the block in registers; column j of the factor is read out of the lanes that
+    // own it (v_readlane -> SGPR operand of the multiply-add): no LDS round trips, no branches inside the 16 steps; a non-positive pivot
+    // poisons the block with NaNs and is reported after the last step.
+    auto factor_diag = [&](int j0) {
+        const int i = lane & 15;
+        double row[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) row[k] = Dg[i * 17 + k];
-            bool okb = true;
+        for (int k = 0; k < 16; ++k) row[k] = Dg[i * 17 + k];
+        bool okb = true;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double d = bcast_lane(row[j], j);
-                okb = okb && d > 0.0 && isfinite(d);
-                double rs = __builtin_amdgcn_rsq(d);                      // 1 / sqrt(d): hardware estimate + two Newton steps
-                rs = rs * (1.5 - 0.5 * d * rs * rs);
-                rs = rs * (1.5 - 0.5 * d * rs * rs);
-                const double lij = i == j ? d * rs : row[j] * rs;
-                row[j] = lij;
+        for (int j = 0; j < 16; ++j) {
+            const double d = bcast_lane(row[j], j);
+            okb = okb && d > 0.0 && isfinite(d);
+            double rs = __builtin_amdgcn_rsq(d);                      // 1 / sqrt(d): hardware estimate + two Newton steps
+            rs = rs * (1.5 - 0.5 * d * rs * rs);
+            rs = rs * (1.5 - 0.5 * d * rs * rs);
+            const double lij = i == j ? d * rs : row[j] * rs;
+            row[j] = lij;
 #pragma unroll
-                for (int k = j + 1; k < 16; ++k) {
-                    const double lkj = bcast_lane(lij, k);                // L[k][j], owned by lane k
-                    row[k] -= (i > j && k <= i) ? lij * lkj : 0.0;
-                }
-            }
-            if (!okb) { if (lane == 0) *bad = 1; }
-            else {
-                // y_J = L11^-1 v_J: lane i holds row i of L11; y_k is broadcast as soon as it is known
-                const double rd = 1.0 / row[i];
-                double t = v[j0 + i];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const double c = t * rd;
-                    const double yk = bcast_lane(c, k);
-                    if (i > k) t -= row[k] * yk;
-                    if (i == k) t = yk * row[i];                          // keeps t / L[i][i] = y_i for the store below
-                }
-                if (lane < 16) {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) Dg[i * 17 + k] = row[k];
-                    rinv[i] = rd;
-                    v[j0 + i] = t * rd;
-                }
+            for (int k = j + 1; k < 16; ++k) {
+                const double lkj = bcast_lane(lij, k);                // L[k][j], owned by lane k
+                row[k] -= (i > j && k <= i) ? lij * lkj : 0.0;
             }
         }
-        __syncthreads();
-        pf.mark(NP_DIAG);
+        if (!okb) { if (lane == 0) *bad = 1; }
+        else {
+            // y_J = L11^-1 v_J: lane i holds row i of L11; y_k is broadcast as soon as it is known
+            const double rd = 1.0 / row[i];
+            double t = v[j0 + i];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const double c = t * rd;
+                const double yk = bcast_lane(c, k);
+                if (i > k) t -= row[k] * yk;
+                if (i == k) t = yk * row[i];                          // keeps t / L[i][i] = y_i for the store below
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) Dg[i * 17 + k] = row[k];
+                rinv[i] = rd;
+                v[j0 + i] = t * rd;
+            }
+        }
+    };
+    // block 0: from global memory; every later diagonal block is produced by the step before it (look-ahead, below)
+    if (tid < 256) Dg[(tid >> 4) * 17 + (tid & 15)] = M[(size_t)(tid >> 4) * Dp + (tid & 15)];
+    __syncthreads();
+    if (wave == 0) factor_diag(0);
+    __syncthreads();
+    pf.mark(NP_DIAG);
+    for (int J = 0; J < nblk; ++J) {
+        const int j0 = 16 * J;
         if (*bad) return false;
         if (tid < 256 && (tid & 15) <= (tid >> 4)) M[(size_t)(j0 + (tid >> 4)) * Dp + j0 + (tid & 15)] = Dg[(tid >> 4) * 17 + (tid & 15)];
         // (b) panel below the block: x L11^T = a, one row per thread.  The m x 16 panel moves between global memory and
         // LDS with coalesced accesses (16 lanes per 128-byte row segment); the solve itself works on the LDS copy.
         const int m = Dp - j0 - 16;
+        if (m == 0) break;
         {
             const double *src = M + (size_t)(j0 + 16 + (tid >> 4)) * Dp + j0 + (tid & 15);
             double *dst = Pn + (tid >> 4) * 17 + (tid & 15);
@@ -172,7 +174,10 @@ __device__ inline bool chol_blocked(double *M, int Dp, double *lds, NewtonProf &
         __syncthreads();
         for (int e = tid; e < m * 16; e += NW_NT) M[(size_t)(j0 + 16 + (e >> 4)) * Dp + j0 + (e & 15)] = Pn[(size_t)(e >> 4) * 17 + (e & 15)];
         pf.mark(NP_PANEL);
-        // (c) trailing update C -= P P^T on 16 x 16 tiles of the lower triangle (tiles on the diagonal are computed in full)
+        // (c) trailing update C -= P P^T on 16 x 16 tiles of the lower triangle (tiles on the diagonal are computed in full).
+        // Look-ahead: tile 0 is the next diagonal block -- wave 0 updates it into Dg (the panel above was the last reader of this
+        // step's factor) and factors it at once, while the other seven waves update the rest of the trailing matrix: the 16
+        // sequential steps of the diagonal block (8 k cycles, a quarter of the routine at D = 331) run in the shadow of the update.
         const int mb = m / 16, ntile = mb * (mb + 1) / 2;
         const int col = lane & 15, kq = lane >> 4;
         auto tile_of = [&](int t, int &I, int &Jc) {
@@ -181,33 +186,51 @@ __device__ inline bool chol_blocked(double *M, int Dp, double *lds, NewtonProf &
             while (I * (I + 1) / 2 > t) --I;
             Jc = t - I * (I + 1) / 2;
         };
-        // four tiles per trip and wavefront: the global loads of all four are in flight before the first MFMA issues
         constexpr int NWV = NW_NT / 64, TPT = 4;
-        for (int t = wave; t < ntile; t += TPT * NWV) {
-            double *C[TPT];
-            int Ib[TPT], Jb[TPT];
-            d4 acc[TPT];
+        if (wave == 0) {
+            const double *C = M + (size_t)(j0 + 16 + kq) * Dp + j0 + 16 + col;
+            d4 acc;
 #pragma unroll
-            for (int q = 0; q < TPT; ++q) {
-                const int tq = t + q * NWV;
-                tile_of(tq < ntile ? tq : t, Ib[q], Jb[q]);
-                C[q] = M + (size_t)(j0 + 16 + 16 * Ib[q] + kq) * Dp + j0 + 16 + 16 * Jb[q] + col;
-            }
+            for (int r = 0; r < 4; ++r) acc[r] = C[(size_t)(4 * r) * Dp];
 #pragma unroll
-            for (int q = 0; q < TPT; ++q)
+            for (int u = 0; u < 4; ++u) acc = mfma_f64(-Pn[(size_t)col * 17 + 4 * u + kq], Pn[(size_t)col * 17 + 4 * u + kq], acc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[q][r] = C[q][(size_t)(4 * r) * Dp];
+            for (int r = 0; r < 4; ++r) Dg[(kq + 4 * r) * 17 + col] = acc[r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            factor_diag(j0 + 16);
+        } else {
+            // four tiles per trip and wavefront: the global loads of all four are in flight before the first MFMA issues.
+            // (Measured and dropped: six or eight tiles per trip -- 270 -> 290 / 317 us per launch at D = 331 --; two trips in flight,
+            // the next one's loads requested before this one's MFMAs -- the registers it takes slow the panel and the substitutions
+            // by more than the update gains: 270 -> 326 us.)
+            for (int t = wave; t < ntile; t += TPT * (NWV - 1)) {
+                double *C[TPT];
+                int Ib[TPT], Jb[TPT];
+                d4 acc[TPT];
 #pragma unroll
-            for (int q = 0; q < TPT; ++q)
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    acc[q] = mfma_f64(-Pn[(size_t)(16 * Ib[q] + col) * 17 + 4 * u + kq], Pn[(size_t)(16 * Jb[q] + col) * 17 + 4 * u + kq], acc[q]);
-#pragma unroll
-            for (int q = 0; q < TPT; ++q)
-                if (q == 0 || t + q * NWV < ntile) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) C[q][(size_t)(4 * r) * Dp] = acc[q][r];
+                for (int q = 0; q < TPT; ++q) {
+                    const int tq = t + q * (NWV - 1);
+                    tile_of(tq < ntile ? tq : t, Ib[q], Jb[q]);
+                    C[q] = M + (size_t)(j0 + 16 + 16 * Ib[q] + kq) * Dp + j0 + 16 + 16 * Jb[q] + col;
                 }
+#pragma unroll
+                for (int q = 0; q < TPT; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[q][r] = C[q][(size_t)(4 * r) * Dp];
+#pragma unroll
+                for (int q = 0; q < TPT; ++q)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        acc[q] = mfma_f64(-Pn[(size_t)(16 * Ib[q] + col) * 17 + 4 * u + kq], Pn[(size_t)(16 * Jb[q] + col) * 17 + 4 * u + kq], acc[q]);
+#pragma unroll
+                for (int q = 0; q < TPT; ++q)
+                    if (q == 0 || t + q * (NWV - 1) < ntile) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) C[q][(size_t)(4 * r) * Dp] = acc[q][r];
+                    }
+            }
         }
         __syncthreads();
         pf.mark(NP_TRAIL);
