@@ -78,9 +78,11 @@ int bdrt_optimize(bdrt_problem *p, const double *init_theta, const int *spec, in
 
     const size_t MAXCOLS = 16384;                      // columns per launch (PCIe staging bounded to ~45 MB each way)
     int rc;
-    if ((rc = P.ensure_scratch(MAXCOLS))) return rc;
-    std::vector<double> h_theta(MAXCOLS * D), h_grad(MAXCOLS * D), h_lp(MAXCOLS);
-    std::vector<int> h_spec(MAXCOLS);
+    // staging of the host-driven loop: sized by the requests of a round, on the first round that has any -- the default path (no
+    // L-BFGS phase, or the device-resident one) has none, and 2 x 22 MB of zero-filled host vectors + as much device scratch per call
+    // were a third of a K = 81 fit (12 of 35 ms)
+    std::vector<double> h_theta;
+    std::vector<int> h_spec;
     std::vector<double> fit_lp, fit_grad;             // per-fit assembly buffers for multi-request phases
     const long long max_rounds = (long long)o.max_iter * 70 + (long long)o.newton_max_iter * 60 + 1000;
     for (long long round = 0; round < max_rounds; ++round) {
@@ -96,6 +98,11 @@ int bdrt_optimize(bdrt_problem *p, const double *init_theta, const int *spec, in
         for (int i = 0; i < n_fits; ++i) off[i + 1] = off[i] + (size_t)fits[i].nreq();
         fit_lp.resize(reqs.size());
         fit_grad.resize(reqs.size() * (size_t)D);
+        {
+            const size_t cols = std::min(MAXCOLS, reqs.size());
+            if ((rc = P.ensure_scratch(cols))) return rc;
+            if (h_theta.size() < cols * D) { h_theta.resize(cols * D); h_spec.resize(cols); }
+        }
         for (size_t base = 0; base < reqs.size(); base += MAXCOLS) {
             const int B = (int)std::min(MAXCOLS, reqs.size() - base);
             for (int k = 0; k < B; ++k) {

@@ -513,6 +513,7 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
 {
     const int D = P.dev.D, Dp = (D + 15) & ~15;
     BDRT_HIP(hipSetDevice(P.device));
+    const auto t_host0 = std::chrono::steady_clock::now();
     std::vector<void *> owned;
     auto cleanup = [&]() { for (void *p : owned) hipFree(p); };
 #define NW_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return -10; } } while (0)
@@ -550,6 +551,7 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
     NW_HIP(hipMemcpy(b.st, hst.data(), hst.size() * sizeof(NewtonState), hipMemcpyHostToDevice));
     NW_HIP(hipMemcpy(b.x, x0, nD, hipMemcpyHostToDevice));
     hipStream_t st = P.stream;
+    const auto t_host1 = std::chrono::steady_clock::now();
     // evaluation at the start points
     std::vector<int> hspec((size_t)n_fits), hact((size_t)n_fits), hspecp, sp1((size_t)n_fits * NW_TRY);
     for (int i = 0; i < n_fits; ++i) hspec[i] = spec ? spec[i] : 0;
@@ -613,7 +615,14 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
                 hp[NP_WALL] / n / 100.0);
     }
 #undef NW_HIP
+    const auto t_host2 = std::chrono::steady_clock::now();
     cleanup();
+    if (prof_env && prof_env[0] == '1') {
+        const auto t_host3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        fprintf(stderr, "[bdrt newton prof] host: allocations + uploads %.0f us, iteration %.0f us, frees %.0f us\n", us(t_host0, t_host1), us(t_host1, t_host2),
+                us(t_host2, t_host3));
+    }
     return 0;
 }
 
