@@ -190,6 +190,13 @@ def _check_basis_freq(basis_freq):
                       'and quantities integrated over ln(tau) (predict_Rp) change sign for an ascending one')
 
 
+class _DeferredRidgeStart:
+    """A ridge starting point of a MAP fit, set up but not solved yet (see `Inverter._resolve_deferred_ridge_starts`)."""
+    def __init__(self, st, z_scale, frequencies, Z, nonneg, inductance_scale, max_iter):
+        self.st, self.z_scale, self.frequencies, self.Z = st, z_scale, frequencies, Z
+        self.nonneg, self.inductance_scale, self.max_iter = nonneg, inductance_scale, max_iter
+
+
 class Inverter:
     def __init__(self, basis_freq=None, basis='gaussian', epsilon=None, fit_inductance=True,
                  distributions={'DRT': {'kernel': 'DRT'}}):
@@ -861,6 +868,7 @@ class Inverter:
         base = self
         for Z in Z_list:
             inv = copy.copy(base)
+            inv._defer_ridge_start = mode == 'optimize'
             job = inv._fit_prepare(frequencies, np.asarray(Z), part, scale_Z, nonneg, outliers, init_from_ridge, ridge_kw, sigma_min,
                                    inductance_scale, outlier_lambda, mode, add_stan_data, model_str, False, False, False, n_starts)
             views.append(inv); jobs.append(job)
@@ -911,6 +919,7 @@ class Inverter:
         except ImportError:
             pass
         if mode == 'optimize':
+            Inverter._resolve_deferred_ridge_starts(views, jobs)
             # rows: for each spectrum its designated start, then its extra starts -- the rows `optimizing` builds for one fit
             rows, owner = [], []
             for i, job in enumerate(jobs):
@@ -983,6 +992,41 @@ class Inverter:
                                                 diag[u0:u1], chains, n_draws)
 
     @staticmethod
+    def _resolve_deferred_ridge_starts(views, jobs):
+        """The ridge starting points that `_map_extra_starts` set up without solving (fit_many): all of them in one launch of
+        bdrt_ridge -- a workgroup per spectrum instead of a 2.4 ms launch per spectrum (61 of them were 145 ms of the published MAP
+        study's 0.5 s) --, then per spectrum what `_get_init_from_ridge` does with a finished ridge fit.  Each solve performs the
+        arithmetic of the stand-alone call (`_ridge_solve_device`), so the starting points are those of separate `fit` calls."""
+        pend = [(inv, job, k) for inv, job in zip(views, jobs) for k, e in enumerate(job['extra_inits']) if isinstance(e, _DeferredRidgeStart)]
+        if not pend:
+            return
+        d0 = pend[0][1]['extra_inits'][pend[0][2]]
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            res = pend[0][0]._ridge_solve_device([job['extra_inits'][k].st for _, job, k in pend], list(range(len(pend))), [1] * len(pend),
+                                                 True, 5, None, None, 1e-3, d0.max_iter)
+            for (inv, job, k), r in zip(pend, res):
+                d = job['extra_inits'][k]
+                keys = inv._RIDGE_SIDE_EFFECTS + ('_Z_scale',)
+                saved = {a: getattr(inv, a) for a in keys if hasattr(inv, a)}
+                try:
+                    inv.distribution_fits = {}
+                    inv._Z_scale = d.z_scale
+                    inv._ridge_finish(d.st, r, True, False, d.max_iter)
+                    job['extra_inits'][k] = inv._init_values_from_ridge_fit(d.frequencies, d.Z, d.nonneg, False, d.inductance_scale)
+                except Exception as e:                   # the ridge candidate is optional (as in `_map_extra_starts`)
+                    warnings.warn('ridge starting point not available (%s): MAP from the random start only' % e)
+                    job['extra_inits'][k] = None
+                finally:
+                    for a in keys:
+                        if a in saved:
+                            setattr(inv, a, saved[a])
+                        elif hasattr(inv, a):
+                            delattr(inv, a)
+        for _, job, _k in pend:
+            job['extra_inits'] = [e for e in job['extra_inits'] if e is not None]
+
+    @staticmethod
     def _fit_argument_checks(part, mode, fitY, SA, SASY, n_starts, algorithm):
         if fitY or SA or SASY:
             raise NotImplementedError('fitY / SA / SASY are experimental flags of the reference ("for testing only") and '
@@ -1018,7 +1062,17 @@ class Inverter:
                 #  the full ridge solve -- 19 ms at K = 81, 57 ms at K = 161, one workgroup -- was 40 % of the whole MAP fit)
                 with warnings.catch_warnings():
                     warnings.simplefilter('ignore')
-                    extra.append(self._get_init_from_ridge(frequencies, Z, 'optimize', nonneg=nonneg, outliers=outliers,
+                    if getattr(self, '_defer_ridge_start', False) and not ridge_kw and not outliers and \
+                            not os.environ.get('BDRT_HOST_LAMBDA_LOOP'):
+                        # fit_many: set the ridge problem up now, solve it with the other spectra's in ONE launch of bdrt_ridge
+                        # right before the batch of MAP fits starts (`_resolve_deferred_ridge_starts`); same arguments as the
+                        # ridge_fit call of `_get_init_from_ridge` makes
+                        self.distribution_fits = {}
+                        st = self._ridge_setup(frequencies, np.asarray(Z), 'both', 'integral', 2, 0, True, True, 'modulus', False)
+                        extra.append(_DeferredRidgeStart(st, self._Z_scale, frequencies, Z, nonneg, inductance_scale,
+                                                         int(os.environ.get('BDRT_RIDGE_START_ITER', 3))))
+                    else:
+                      extra.append(self._get_init_from_ridge(frequencies, Z, 'optimize', nonneg=nonneg, outliers=outliers,
                                                            inductance_scale=inductance_scale,
                                                            ridge_kw=dict({'max_iter': int(os.environ.get('BDRT_RIDGE_START_ITER', 3))}, **ridge_kw)))
             except Exception as e:                       # the ridge candidate is optional: the random start remains
@@ -1095,10 +1149,14 @@ class Inverter:
     def _get_init_from_ridge(self, frequencies, Z, mode, nonneg, outliers, inductance_scale, ridge_kw):
         """Initial values from a deliberately under-fitted hyper-ridge solution (reference :1616-1682).  Returns the
         callable Stan's `init=` takes; it yields constrained values on the scaled-Z problem."""
-        name = next(iter(self.distributions))
         settings = dict(penalty='integral', hyper_lambda=True, lambda_0=1, hl_beta=5, weights='modulus')
         settings.update(ridge_kw)                       # user settings win
         self.ridge_fit(frequencies, Z, **settings)
+        return self._init_values_from_ridge_fit(frequencies, Z, nonneg, outliers, inductance_scale)
+
+    def _init_values_from_ridge_fit(self, frequencies, Z, nonneg, outliers, inductance_scale):
+        """The second half of `_get_init_from_ridge`: Stan `init=` values from the ridge fit this instance holds."""
+        name = next(iter(self.distributions))
         zs = self._Z_scale
         coef = self.distribution_fits[name]['coef']
         series = self.distributions[name]['dist_type'] == 'series'
