@@ -371,6 +371,29 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
         xs_term = -xs_raw * P.x_sum_invscale * P.x_sum_invscale;
     }
 
+    // ---- scalar gradients, the waves' shares of lp: everything they need is complete here; in front of the backward pass they run beside
+    //      its first operand phase instead of behind the last chain rule with two barriers of their own --------------------------------
+    if (sj >= 0) {
+        double gsc;
+        if (sidx < 6) {
+            const double t = ered[sidx] + ered[32 + sidx];
+            double dl;
+            if (sidx == 0) dl = 100.0 * t;
+            else if (sidx == 1) dl = P.induc_scale * t;
+            else dl = 0.05 * 2.0 * (0.05 * sraw) * t;
+            gsc = sraw * (dl - sraw) + jac;
+        } else {
+            const int q = 8 + (sidx - 6);                  // slot 8 + 3 b + i
+            const double sv = ered[q] + ered[32 + q] + ered[64 + q];
+            gsc = -0.5 * sraw * sv - 6.0 + 5.0 * lean_rcp(sraw) + jac;
+        }
+        GR[sj] = gsc;
+    }
+    {
+        const double wl = solo_wave_sum(lp);
+        if (lane == 0) ered[wave * 32 + 21] = wl;
+    }
+
     // ================================================= backward, block by block ==================================================
 #pragma unroll
     for (int b = 0; b < W1_MAXB; ++b) {
@@ -417,28 +440,7 @@ __device__ inline void wide1_eval(const DevProblem &P, const Wide1Geom &G, doubl
         BDRT_W1_PROF(8);
     }
 
-    // ---- scalar gradients, lp ----------------------------------------------------------------------------------------------------
-    if (sj >= 0) {
-        double gsc;
-        if (sidx < 6) {
-            const double t = ered[sidx] + ered[32 + sidx];
-            double dl;
-            if (sidx == 0) dl = 100.0 * t;
-            else if (sidx == 1) dl = P.induc_scale * t;
-            else dl = 0.05 * 2.0 * (0.05 * sraw) * t;
-            gsc = sraw * (dl - sraw) + jac;
-        } else {
-            const int q = 8 + (sidx - 6);                  // slot 8 + 3 b + i
-            const double sv = ered[q] + ered[32 + q] + ered[64 + q];
-            gsc = -0.5 * sraw * sv - 6.0 + 5.0 * lean_rcp(sraw) + jac;
-        }
-        GR[sj] = gsc;
-    }
-    {
-        const double wl = solo_wave_sum(lp);
-        if (lane == 0) ered[wave * 32 + 21] = wl;
-    }
-    __syncthreads();
+    // ---- lp (the scalar gradients and the waves' shares of lp were formed in front of the backward pass) ---------------------------
     if (tid == 0) {
         double s = lpx;
 #pragma unroll
