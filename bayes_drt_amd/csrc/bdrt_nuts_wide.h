@@ -44,6 +44,25 @@ template <int N>
 __device__ inline void wide_block_sum(double (&v)[N], int n, double *scr, int tid)      // only v[0 .. n) are summed (n uniform)
 {
     const int lane = tid & 63, wave = tid >> 6;
+    if (N >= 8 && n <= 8) {
+        // up to eight values (a leaf that closes at most two sub-subtrees: seven of eight): ONE butterfly puts sum j of the wave in lane j,
+        // one barrier, then every wave adds the eight waves' partials itself -- lane l reads partial l (wave l >> 3, value l & 7), three
+        // exchanges -- instead of a wave reduction per value, a second barrier and n broadcast reads per thread (bdrt_solo.h)
+        const double q[8] = {v[0], v[1], v[2], v[3], v[4 % N], v[5 % N], v[6 % N], v[7 % N]};
+        double t = sum32_by_lane<8>(q, lane);
+        t += __shfl_xor(t, 32);
+        if (lane < 8) scr[wave * 8 + lane] = t;
+        __syncthreads();
+        double u = scr[lane];
+        u += dpp_perm<0x128>(u);
+        u += swizzle_xor16(u);
+        u += __shfl_xor(u, 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < N) v[i] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(u), i), __builtin_amdgcn_readlane(__double2loint(u), i));
+        __syncthreads();                                // (scr may be reused by the next call at once)
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         if (i < n) {
