@@ -24,7 +24,7 @@ struct Wide1Geom {
 __host__ __device__ inline Wide1Geom wide1_geometry(int nf, int K, int D, int nb)
 {
     Wide1Geom G;
-    G.g = solo_geometry(nf, K, D, false);
+    G.g = solo_geometry(nf, K, D);             // (forward products on the waves behind the K-threads, beside the prior chain: bdrt_solo.h)
     G.nb = nb;
     const SoloGeom &g = G.g;
     int o = 0;
@@ -70,7 +70,8 @@ __device__ __forceinline__ Wide1Regs wide1_setup(const DevProblem &P, const Wide
     const int n = tid < g.nf ? tid : 0;
     const double *Zm = P.Z + (size_t)spec * 2 * g.nf;
     er.zre = Zm[n]; er.zim = Zm[g.nf + n]; er.wn = P.w[n];
-    er.fpart = tid / g.RG; er.frg = tid - er.fpart * g.RG;
+    const int pt = tid - g.FP0;
+    er.fpart = pt >= 0 ? pt / g.RG : g.NP; er.frg = pt - er.fpart * g.RG;
     er.bpart = tid / g.MG; er.bmg = tid - er.bpart * g.MG;
     return er;
 }
