@@ -876,6 +876,21 @@ struct bdrt_sampler {
     bdrt::Sampler impl;
 };
 
+// test probe (tests/test_gpu_lean_math.py): a leaf's acceptance decision and new log-weight in the device form of nuts_leaf_joins (one
+// exponential) and in the textbook form (log_sum_exp2, u < exp(w - lsw_new)) -- both with the device's lean exp / log
+__global__ void leaf_joins_probe_kernel(const double *lsw_sub, const double *w, const double *u, int n, double *lsw_dev, int *join_dev,
+                                        double *lsw_ref, int *join_ref, double *prob_ref)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double l;
+    join_dev[i] = nuts_leaf_joins(lsw_sub[i], w[i], u[i], l) ? 1 : 0;
+    lsw_dev[i] = l;
+    const double lr = log_sum_exp2(lsw_sub[i], w[i]);
+    const double pr = BDRT_NUTS_EXP(w[i] - lr);
+    lsw_ref[i] = lr; prob_ref[i] = pr; join_ref[i] = u[i] < pr ? 1 : 0;
+}
+
 extern "C" {
 
 void bdrt_nuts_defaults(bdrt_nuts_control *c)
@@ -1641,6 +1656,28 @@ int bdrt_debug_wide1_logp_grad(bdrt_problem *p, const double *theta, const int *
     if (e == hipSuccess && grad) e = hipMemcpy(grad, dg, nbytes, hipMemcpyDeviceToHost);
     hipFree(dth); hipFree(dg); hipFree(dlp); hipFree(dsp);
     if (e != hipSuccess) { set_error("bdrt_debug_wide1_logp_grad: %s", hipGetErrorString(e)); return -10; }
+    return 0;
+}
+
+int bdrt_debug_leaf_joins(const double *lsw_sub, const double *w, const double *u, int n, double *lsw_dev, int *join_dev, double *lsw_ref,
+                          int *join_ref, double *prob_ref)
+{
+    if (!lsw_sub || !w || !u || n < 1) { set_error("bdrt_debug_leaf_joins: bad arguments"); return -1; }
+    double *d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int *di[2] = {nullptr, nullptr};
+    for (auto &q : d) BDRT_HIP(hipMalloc((void **)&q, (size_t)n * sizeof(double)));
+    for (auto &q : di) BDRT_HIP(hipMalloc((void **)&q, (size_t)n * sizeof(int)));
+    BDRT_HIP(hipMemcpy(d[0], lsw_sub, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    BDRT_HIP(hipMemcpy(d[1], w, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    BDRT_HIP(hipMemcpy(d[2], u, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(leaf_joins_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d[0], d[1], d[2], n, d[3], di[0], d[4], di[1], d[5]);
+    BDRT_HIP(hipMemcpy(lsw_dev, d[3], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    BDRT_HIP(hipMemcpy(join_dev, di[0], (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    BDRT_HIP(hipMemcpy(lsw_ref, d[4], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    BDRT_HIP(hipMemcpy(join_ref, di[1], (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    BDRT_HIP(hipMemcpy(prob_ref, d[5], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    for (auto q : d) hipFree(q);
+    for (auto q : di) hipFree(q);
     return 0;
 }
 

@@ -97,7 +97,7 @@ __host__ __device__ inline double log_sum_exp2(double a, double b)
     return a > b ? a + BDRT_NUTS_LOG1P_EXP(b - a) : b + BDRT_NUTS_LOG1P_EXP(a - b);
 }
 
-// A leaf joins a subtree of log-weight lsw_sub with log-weight w: the subtree's new log-weight (log_sum_exp2(lsw_sub, w), bit for bit)
+// A leaf joins a subtree of log-weight lsw_sub with log-weight w: the subtree's new log-weight (log_sum_exp2(lsw_sub, w): its own formula)
 // and whether the leaf replaces the subtree's proposal, u < exp(w - lsw_new) (Stan base_nuts::build_tree: multinomial sampling inside
 // the subtree).  Device code takes both from ONE exponential, t = exp(-|lsw_sub - w|): lsw_new = max + log(1 + t), and
 // exp(w - lsw_new) = (w >= lsw_sub ? 1 : t) / (1 + t) -- the second exponential and the logarithm are off the path to the decision
@@ -109,7 +109,8 @@ __host__ __device__ inline bool nuts_leaf_joins(double lsw_sub, double w, double
     const double dd = lsw_sub - w;
     const double t = BDRT_NUTS_EXP(-fabs(dd));
     lsw_new = lsw_sub == -INFINITY ? w : fmax(lsw_sub, w) + ::bdrt::lean_log(1.0 + t);
-    return u * (1.0 + t) < (dd <= 0.0 ? 1.0 : t);
+    // (an empty subtree -- lsw_sub = -inf, the lean exponential's argument is not finite -- takes its first leaf whatever u is)
+    return lsw_sub == -INFINITY || u * (1.0 + t) < (dd <= 0.0 ? 1.0 : t);
 #else
     lsw_new = log_sum_exp2(lsw_sub, w);
     return u < BDRT_NUTS_EXP(w - lsw_new);

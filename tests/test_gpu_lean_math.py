@@ -82,3 +82,43 @@ def test_one_butterfly_for_eight_sums():
         # every lane that shares a quantity holds the same bits
         for j in range(8):
             assert len({out[0, 32 * half + l] for l in range(32) if l & 7 == j}) == 1
+
+
+def test_leaf_acceptance_from_one_exponential_equals_the_textbook_form():
+    """nuts_leaf_joins (bdrt_nuts_device.h): the device kernels take a leaf's new subtree log-weight and its acceptance decision
+    u < exp(w - lsw_new) from ONE exponential, t = exp(-|lsw_sub - w|): lsw_new = max + log(1 + t) -- log_sum_exp2's own formula -- and
+    exp(w - lsw_new) = (w >= lsw_sub ? 1 : t) / (1 + t).  Against the textbook form on the device (same lean exp / log): the log-weights
+    agree (to the bit in all but a few cases per million), the decisions differ only where u meets the probability to rounding."""
+    from bayes_drt_amd import _lib
+    lib = _lib.require_gpu()
+    fn = lib.bdrt_debug_leaf_joins
+    fn.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5; fn.restype = C.c_int
+    rng = np.random.default_rng(7)
+    n = 1_000_000
+    lsw = rng.uniform(-60.0, 20.0, n)
+    lsw[: n // 50] = -np.inf                                    # the first leaf of a subtree
+    w = np.where(rng.random(n) < 0.5, lsw + rng.normal(0.0, 3.0, n), rng.uniform(-80.0, 10.0, n))
+    w[~np.isfinite(w)] = rng.uniform(-5.0, 5.0, int((~np.isfinite(w)).sum()))
+    u = rng.random(n)
+    # a share of the cases right at the boundary: u = the probability itself, and its neighbours
+    m = np.maximum(lsw, w)
+    p_np = np.exp(w - (m + np.log1p(np.exp(-np.abs(lsw - w)))))
+    k = n // 10
+    u[-k:] = np.clip(p_np[-k:] * (1.0 + rng.integers(-2, 3, k) * 2.0 ** -52), 0.0, 1.0)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    lsw, w, u = f64(lsw), f64(w), f64(u)
+    ld, lr, pr = np.empty(n), np.empty(n), np.empty(n)
+    jd, jr = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+    assert fn(lsw.ctypes.data, w.ctypes.data, u.ctypes.data, n, ld.ctypes.data, jd.ctypes.data, lr.ctypes.data, jr.ctypes.data,
+              pr.ctypes.data) == 0
+    ul = np.abs(ld - lr) / np.spacing(np.abs(lr))
+    print('lsw_new: %d of %d differ, largest %.1f ulp; decisions differ in %d' % ((ul > 0).sum(), n, ul.max(), (jd != jr).sum()))
+    # log_sum_exp2 itself, up to how the compiler contracts its last multiply-add at the two call sites: a handful of cases in a million,
+    # where max + log(1 + t) cancels, differ in the last bits of the larger operand
+    assert (ul > 0).sum() <= n // 10000 and np.all(np.abs(ld - lr) <= 2 * np.spacing(np.maximum(np.abs(lr), np.abs(m))))
+    diff = jd != jr
+    # where the two forms decide differently, u is within a few ulp of the probability (8 ulp: the lean exp's 1.5 ulp on either side
+    # and the divisions)
+    assert np.all(np.abs(u[diff] - pr[diff]) <= 8 * np.spacing(pr[diff])), (u[diff][:5], pr[diff][:5])
+    assert diff.sum() <= k                                      # only among the planted boundary cases
+    assert (jd[: n // 50] == 1).all()                           # an empty subtree always takes its first leaf
