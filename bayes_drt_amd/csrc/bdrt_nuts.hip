@@ -33,11 +33,11 @@
 namespace bdrt {
 
 // one-chain-per-wave sampler / evaluator (bdrt_wave.hip)
-size_t wave_lds_request(const WaveGeom &g, int n_wg, int n_cu, int *nhot);
+size_t wave_lds_request(const WaveGeom &g, int n_wg, int n_cu, int *nhot, int max_per_cu);
 int launch_wave_nuts(const DevProblem *dp, const NutsParams &np, const NutsArgs &args, const WaveGeom &g, int nhot, int n_wg, size_t lds,
-                     hipStream_t stream);
+                     hipStream_t stream, int outlier_model);
 int launch_wave_eval(const DevProblem *dp, const WaveGeom &g, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
-                     double *d_grad, int n_wg, size_t lds, hipStream_t stream);
+                     double *d_grad, int n_wg, size_t lds, hipStream_t stream, int outlier_model);
 
 }  // namespace bdrt
 #include "bdrt_nuts16.h"
@@ -681,7 +681,7 @@ static bool solo_duo_fits(const DevProblem &P)
 // 512-thread workgroups finish a round in 9.4 us; a third chain on any CU is a second turn for them, 14.6 us, against 13.1 us of
 // the wave kernel), up to the eight per CU it keeps resident.  BDRT_WAVE=1 / 0: always / never.
 static bool wave_pays(int live, int n_cu) { return live > 2 * n_cu; }
-static int wave_max_units(int n_cu) { return 8 * n_cu; }      // (a ninth chain on any CU is a second turn of the machine: 31 us per round instead of 19)
+static int wave_max_units(int n_cu, const DevProblem &P) { return wave_chains_per_cu(P) * n_cu; }      // (a ninth chain on any CU is a second turn of the machine: 31 us per round instead of 19)
 
 // liveness of every unit (1: the chain is still running), for the host's re-packing decision
 __global__ void nuts_live_kernel(const ChainState *states, int n, int *live)
@@ -968,11 +968,14 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
     if (getenv("BDRT_WIDE1") && atoi(getenv("BDRT_WIDE1")) == 0 && !solo_capable(P.dev)) S.may_migrate = false;
     // one chain per wave (bdrt_wave.h) for the one-chain layout: BDRT_WAVE=1 whenever the problem allows, 0 never
     S.solo_ok = solo_capable(P.dev);
+    // (families without the LDS-resident one-chain kernel -- the outlier error models: up to one chain per CU the general one-chain kernel
+    //  is the faster one, 12.9 against 16.9 us per round at 256 units; from there to four per CU the wave kernel, 53 against 29 M evals/s
+    //  at 1024 units: profiles/r05/wave_outliers.txt)
     S.wave = wave_capable(P.dev);
     if (const char *e = getenv("BDRT_WAVE")) { S.wave_force = atoi(e) != 0; S.wave = S.wave && S.wave_force; }
     if (getenv("BDRT_CHAINS_PER_WG")) S.wave = false;                                           // (a forced packing means the 16-chain kernel)
     if (getenv("BDRT_SOLO") && S.wave_force != 1) S.wave = false;                                // (BDRT_SOLO=0 / 1: the 16-chain kernel / the 512-thread one-chain kernels, forced)
-    if (S.wave && !getenv("BDRT_SOLO") && (S.wave_force == 1 || (n_units <= wave_max_units(n_cu) && (wave_pays(n_units, n_cu) || !S.solo_ok)))) {
+    if (S.wave && !getenv("BDRT_SOLO") && (S.wave_force == 1 || (n_units <= wave_max_units(n_cu, P.dev) && (wave_pays(n_units, n_cu) || (!S.solo_ok && (n_units > n_cu || !wide1_capable(P.dev))))))) {
         S.solo = true;                                                                          // start in the one-chain layout
         S.may_migrate = false;
     }
@@ -1209,8 +1212,8 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
         {
             // LDS share (= chains per CU) by the chains still running: finished ones leave their wave at once
             int nhot = 0;
-            const size_t lds = wave_lds_request(S.geomw, std::max(1, std::min(S.live, S.n_solo)), S.n_cu, &nhot);
-            if (launch_wave_nuts(dp, S.np, S.args, S.geomw, nhot, S.n_solo, lds, S.stream)) return -10;
+            const size_t lds = wave_lds_request(S.geomw, std::max(1, std::min(S.live, S.n_solo)), S.n_cu, &nhot, wave_chains_per_cu(S.prob->dev));
+            if (launch_wave_nuts(dp, S.np, S.args, S.geomw, nhot, S.n_solo, lds, S.stream, S.prob->dev.outlier_mode != 0)) return -10;
             S.wave_last = true;
         }
         else if (S.solo)
@@ -1368,7 +1371,7 @@ static int maybe_migrate_tail(Sampler &S, int active)
     // live chains per CU when two of its workgroups fit a CU (else ~3.5), the general one below ~2.75
     const bool to_solo = solo_capable(S.prob->dev) || S.wave;
     // (the one-chain-per-wave kernel runs eight chains per CU at 108 M evals/s against 73 M of half-empty tiles: profiles/r04/wave_sweep.txt)
-    const int limit = S.wave ? 8 * S.n_cu : (to_solo ? (solo_duo_fits(S.prob->dev) ? (19 * S.n_cu) / 4 : (7 * S.n_cu) / 2) : (11 * S.n_cu) / 4);
+    const int limit = S.wave ? wave_chains_per_cu(S.prob->dev) * S.n_cu : (to_solo ? (solo_duo_fits(S.prob->dev) ? (19 * S.n_cu) / 4 : (7 * S.n_cu) / 2) : (11 * S.n_cu) / 4);
     if (active <= 0 || active > limit) return 0;
     std::vector<ChainState> hs((size_t)S.n_units);
     BDRT_HIP(hipMemcpy(hs.data(), S.args.states, hs.size() * sizeof(ChainState), hipMemcpyDeviceToHost));
@@ -1623,7 +1626,7 @@ int bdrt_debug_wave_logp_grad(bdrt_problem *p, const double *theta, const int *s
     BDRT_HIP(hipMalloc((void **)&dth, nb)); BDRT_HIP(hipMalloc((void **)&dg, nb)); BDRT_HIP(hipMalloc((void **)&dlp, B * sizeof(double)));
     BDRT_HIP(hipMemcpy(dth, theta, nb, hipMemcpyHostToDevice));
     if (spec) { BDRT_HIP(hipMalloc((void **)&dsp, B * sizeof(int))); BDRT_HIP(hipMemcpy(dsp, spec, B * sizeof(int), hipMemcpyHostToDevice)); }
-    int rc = launch_wave_eval((const DevProblem *)P.d_dev, g, dth, dsp, B, jacobian, dlp, dg, std::min(B, 2048), lds, 0);
+    int rc = launch_wave_eval((const DevProblem *)P.d_dev, g, dth, dsp, B, jacobian, dlp, dg, std::min(B, 2048), lds, 0, P.dev.outlier_mode != 0);
     hipError_t e = rc ? hipErrorUnknown : hipDeviceSynchronize();
     if (e == hipSuccess && lp) e = hipMemcpy(lp, dlp, B * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess && grad) e = hipMemcpy(grad, dg, nb, hipMemcpyDeviceToHost);

@@ -89,11 +89,15 @@ __host__ __device__ constexpr int wave_hot_rank(int v)
 __host__ __device__ inline size_t wave_lds_bytes(const WaveGeom &g, int nhot) { return ((size_t)g.total0 + (size_t)nhot * g.DSS) * sizeof(double) + 64; }
 
 // can this problem take the one-chain-per-wave path?  (host)
+// (the outlier error models -- two further parameters per frequency, bdrt_tile_hw.h -- take the same kernel with 2 NS more slots per lane
+//  and one wave per SIMD: wave_chains_per_cu)
 inline bool wave_capable(const DevProblem &P)
 {
-    return P.fast_s1 && P.outlier_mode == 0 && P.blk[0].tg != nullptr && P.blk[0].K >= 2 * MAXBW + 3 && P.blk[0].K <= 192 &&
-           P.nf <= 128 && P.D == 2 * P.blk[0].K + 9;
+    return P.fast_s1 && P.blk[0].tg != nullptr && P.blk[0].K >= 2 * MAXBW + 3 && P.blk[0].K <= 192 &&
+           P.nf <= 128 && P.D == 2 * P.blk[0].K + 9 + (P.outlier_mode ? 2 * P.nf : 0);
 }
+// chains a CU keeps resident: two waves per SIMD for the headline family, one with the outlier parameters in registers too
+inline int wave_chains_per_cu(const DevProblem &P) { return P.outlier_mode ? 4 : 8; }
 
 typedef const __attribute__((address_space(4))) double *wv_cptr;      // uniform read-only data: scalar loads
 
@@ -265,21 +269,28 @@ __device__ __forceinline__ void wave_eval_init(const DevProblem &P, const WaveGe
 
 // D-index of this lane's slot u: slots 0 .. KS-1 x[l + 64 u], KS .. 2KS-1 ups[l + 64 u], slot 2 KS the nine scalars (lanes 0..8:
 // Rinf_raw, induc_raw, sigma_res_raw, alpha_prop_raw, alpha_re_raw, alpha_im_raw, d0, d1, d2); -1: no element
-template <int KS>
+// With the outlier error model (OM): slots 2 KS + 1 .. 2 KS + NS the first outlier parameter of rows n = l + 64 s, the NS after them the second.
+template <int KS, int NS = 0, bool OM = false>
 __device__ __forceinline__ int wave_slot_index(const DevProblem &P, int K, int u, int lane)
 {
     const DevBlock &B = P.blk[0];
     if (u < KS) return lane + 64 * u < K ? B.o_x + lane + 64 * u : -1;
     if (u < 2 * KS) return lane + 64 * (u - KS) < K ? B.o_ups + lane + 64 * (u - KS) : -1;
-    return lane < 2 ? lane : (lane < 6 ? P.o_err + (lane - 2) : (lane < 9 ? B.o_d + (lane - 6) : -1));
+    if (u == 2 * KS) return lane < 2 ? lane : (lane < 6 ? P.o_err + (lane - 2) : (lane < 9 ? B.o_d + (lane - 6) : -1));
+    if constexpr (OM) {
+        const int s = u - (2 * KS + 1), h = s >= NS ? 1 : 0, n = lane + 64 * (s - h * NS);
+        return n < P.nf ? P.o_so + h * P.nf + n : -1;
+    }
+    return -1;
 }
+template <int KS, int NS, bool OM> constexpr int wave_slots() { return 2 * KS + 1 + (OM ? 2 * NS : 0); }
 
 // log-posterior + gradient of the chain at theta (registers, slot order above) -> gradient (registers), returns lp (uniform).
 // Formulas: bdrt_solo.h / bdrt_tile_s1.h (same model code, other thread mapping).  `jac`: 1.0 with the Jacobian of the
 // lower = 0 transforms (sampling), 0.0 without (optimisation).
-template <int KS, int NS>
-__device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom &g, double *lds, const double (&th)[2 * KS + 1],
-                                            double (&gr)[2 * KS + 1], const WaveEvalRegs<NS> &er, const double jac, int lane_,
+template <int KS, int NS, bool OM = false>
+__device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom &g, double *lds, const double (&th)[wave_slots<KS, NS, OM>()],
+                                            double (&gr)[wave_slots<KS, NS, OM>()], const WaveEvalRegs<NS> &er, const double jac, int lane_,
                                             long long *prof = nullptr)
 {
     int lane = lane_;
@@ -440,7 +451,16 @@ __device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom 
             for (int p = 0; p < g.NP; ++p) { zr += zp[(size_t)(2 * p) * g.R4 + nn]; zi += zp[(size_t)(2 * p + 1) * g.R4 + nn]; }
             zr += Rinf; zi += induc * er.wn[s];
             const double common = ar2 * zr * zr + ai2 * zi * zi;
-            const double s2_re = c0 + ap2 * zr * zr + common, s2_im = c0 + ap2 * zi * zi + common;
+            // outlier error model (formulas of bdrt_tile_hw.h): sigma_out enters the variances; its two parameters per row are this lane's
+            [[maybe_unused]] double so_re = 0.0, so_im = 0.0, r0 = 0.0, r1 = 0.0, t0 = 0.0, t1 = 0.0;
+            if constexpr (OM) {
+                t0 = th[2 * KS + 1 + s]; t1 = th[2 * KS + 1 + NS + s];
+                r0 = lean_exp(t0); r1 = lean_exp(t1);
+                if (P.outlier_mode == 1) so_re = so_im = 0.05 * r0 * r1;
+                else { so_re = 0.05 * r0; so_im = 0.05 * r1; }
+            }
+            double s2_re = c0 + ap2 * zr * zr + common, s2_im = c0 + ap2 * zi * zi + common;
+            if constexpr (OM) { s2_re += so_re * so_re; s2_im += so_im * so_im; }
             const double e_re = er.zre[s] - zr, e_im = er.zim[s] - zi;
             const double prod = s2_re * s2_im, ip = lean_rcp(prod);
             const double w_re = s2_im * ip, w_im = s2_re * ip;
@@ -449,6 +469,21 @@ __device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom 
             const double h_im = -0.5 * w_im + 0.5 * e_im * e_im * w_im * w_im;
             const double gzr = e_re * w_re + 2.0 * zr * (h_re * (ap2 + ar2) + h_im * ar2);
             const double gzi = e_im * w_im + 2.0 * zi * (h_im * (ap2 + ai2) + h_re * ai2);
+            if constexpr (OM) {
+                double g0 = 0.0, g1 = 0.0, lpo = 0.0;
+                if (P.outlier_mode == 1) {
+                    const double dso = 2.0 * so_re * (h_re + h_im), ir1 = lean_rcp(r1);
+                    g0 = r0 * (0.05 * r1 * dso - P.so_lambda) + jac;
+                    g1 = 0.05 * r0 * r1 * dso - (P.so_alpha + 1.0) + P.so_beta * ir1 + jac;
+                    lpo = -P.so_lambda * r0 - (P.so_alpha + 1.0) * t1 - P.so_beta * ir1 + jac * (t0 + t1);
+                } else {
+                    g0 = r0 * (0.05 * 2.0 * so_re * h_re - P.so_lambda) + jac;
+                    g1 = r1 * (0.05 * 2.0 * so_im * h_im - P.so_lambda) + jac;
+                    lpo = -P.so_lambda * (r0 + r1) + jac * (t0 + t1);
+                }
+                gr[2 * KS + 1 + s] = nv ? g0 : 0.0; gr[2 * KS + 1 + NS + s] = nv ? g1 : 0.0;
+                lp += nv ? lpo : 0.0;
+            }
             if (nv) {                                          // (zeros from the set-up on [nf, NLP): the backward product's padding)
                 gz[n] = gzr; gz[g.NLP + n] = gzi;
                 lp += lpn;

@@ -27,7 +27,9 @@ static hipError_t wave_set_lds_limit(size_t bytes)
 #define BDRT_WV_ATTR(KS_, NS_)                                                                                                        \
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nuts_wave_kernel<KS_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nuts_wave_kernel<KS_, NS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)wave_eval_kernel<KS_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nuts_wave_kernel<KS_, NS_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)wave_eval_kernel<KS_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)wave_eval_kernel<KS_, NS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         BDRT_WV_ATTR(1, 1) BDRT_WV_ATTR(1, 2) BDRT_WV_ATTR(2, 1) BDRT_WV_ATTR(2, 2) BDRT_WV_ATTR(3, 1) BDRT_WV_ATTR(3, 2)
 #undef BDRT_WV_ATTR
         return e;
@@ -37,11 +39,11 @@ static hipError_t wave_set_lds_limit(size_t bytes)
 // LDS request of a launch with `n_wg` chains on `n_cu` CUs: the chain's share of its CU (the request doubles as a placement
 // hint: the dispatcher fills a CU as far as the resources allow before it goes to the next), at most eight chains per CU;
 // *nhot: the rows that fit beside the evaluator's scratch
-size_t wave_lds_request(const WaveGeom &g, int n_wg, int n_cu, int *nhot)
+size_t wave_lds_request(const WaveGeom &g, int n_wg, int n_cu, int *nhot, int max_per_cu)
 {
     int c = (n_wg + n_cu - 1) / n_cu;
     if (const char *e = getenv("BDRT_WAVE_PER_CU")) c = atoi(e);          // diagnostics: force the packing
-    c = c < 1 ? 1 : (c > 8 ? 8 : c);
+    c = c < 1 ? 1 : (c > max_per_cu ? max_per_cu : c);
     const size_t need0 = wave_lds_bytes(g, 0);
     // (LDS is allocated in granules -- 1280 bytes assumed: a share that rounds up past its c-th of the CU costs a whole turn of the
     //  machine, measured at 3 chains per CU: 28.8 us per round instead of 14.4)
@@ -57,26 +59,32 @@ size_t wave_lds_request(const WaveGeom &g, int n_wg, int n_cu, int *nhot)
 }
 
 int launch_wave_nuts(const DevProblem *dp, const NutsParams &np, const NutsArgs &args, const WaveGeom &g, int nhot, int n_wg, size_t lds,
-                     hipStream_t stream)
+                     hipStream_t stream, int outlier_model)
 {
     BDRT_HIP(wave_set_lds_limit(lds));
 #define BDRT_WV_CALL(KS_, NS_) hipLaunchKernelGGL((nuts_wave_kernel<KS_, NS_>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, np, args, g, nhot)
 #define BDRT_WV_CALL_PROF(KS_, NS_) hipLaunchKernelGGL((nuts_wave_kernel<KS_, NS_, true>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, np, args, g, nhot)
-    if (args.prof) BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL_PROF);
+#define BDRT_WV_CALL_OM(KS_, NS_) hipLaunchKernelGGL((nuts_wave_kernel<KS_, NS_, false, true>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, np, args, g, nhot)
+    if (outlier_model) BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL_OM);     // (no profiling instantiation of the outlier variant)
+    else if (args.prof) BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL_PROF);
     else BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL);
 #undef BDRT_WV_CALL
 #undef BDRT_WV_CALL_PROF
+#undef BDRT_WV_CALL_OM
     BDRT_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_wave_eval(const DevProblem *dp, const WaveGeom &g, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
-                     double *d_grad, int n_wg, size_t lds, hipStream_t stream)
+                     double *d_grad, int n_wg, size_t lds, hipStream_t stream, int outlier_model)
 {
     BDRT_HIP(wave_set_lds_limit(lds));
 #define BDRT_WV_CALL(KS_, NS_) hipLaunchKernelGGL((wave_eval_kernel<KS_, NS_>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, g, d_theta, d_spec, B, jacobian, d_lp, d_grad)
-    BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL);
+#define BDRT_WV_CALL_OM(KS_, NS_) hipLaunchKernelGGL((wave_eval_kernel<KS_, NS_, true>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, g, d_theta, d_spec, B, jacobian, d_lp, d_grad)
+    if (outlier_model) BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL_OM);
+    else BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL);
 #undef BDRT_WV_CALL
+#undef BDRT_WV_CALL_OM
     BDRT_HIP(hipGetLastError());
     return 0;
 }

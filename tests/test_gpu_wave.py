@@ -173,3 +173,93 @@ def test_wave_long_run_statistics_match_the_16_chain_kernel():
     assert np.median(r) < 0.15 and np.quantile(r, 0.9) < 0.5 and np.max(r) < 3.0, (np.median(r), np.quantile(r, 0.9), np.max(r))
     assert sum(d['n_divergent'] for d in da) < 10 and np.mean([d['mean_accept'] for d in da]) > 0.7
     prob.close()
+
+
+def _outlier_problem(tag, om_mode):
+    """Series_pos with the outlier error model (two further parameters per frequency; bdrt_tile_hw.h): mode 1 = the Stan files' form
+    (sigma_out = raw x scale), mode 2 = one parameter per part."""
+    from bayes_drt_amd.model import Problem
+    from oracle import oracle as orc
+    d = load('dat_sample_2ZARC_uniform_0.25_%s' % tag)
+    so = load('dat_sample_outlier_scalars')
+    blk = dict(A=d['A'], L0=d['L0'], L1=d['L1'], L2=d['L2'], nonneg=True)
+    kw = dict(sigma_min=float(d['sigma_min']), ups_alpha=float(d['ups_alpha']), ups_beta=float(d['ups_beta']),
+              induc_scale=float(d['induc_scale']), outlier_mode=om_mode, so_lambda=float(so['sigma_out_lambda']),
+              so_alpha=float(so['sigma_out_alpha']), so_beta=float(so['sigma_out_beta']))
+    return Problem([blk], d['Z'], d['freq'], **kw), orc.OracleModel([blk], d['Z'], d['freq'], **kw)
+
+
+@pytest.mark.parametrize('tag', ['K161', 'K81'])
+@pytest.mark.parametrize('om_mode', [1, 2])
+def test_wave_evaluator_with_the_outlier_model_matches_oracle(tag, om_mode):
+    prob, om = _outlier_problem(tag, om_mode)
+    rng = np.random.default_rng(5)
+    theta = rng.uniform(-2, 2, (40, prob.D))
+    for jac in (True, False):
+        lp, g = _wave_logp_grad(prob, theta, jac)
+        lp16, g16 = prob.logp_grad(theta, jacobian=jac)
+        for i in range(0, len(theta), 5):
+            lp_ref, g_ref = om.logp_grad(theta[i], jac)
+            assert abs(lp[i] - lp_ref) <= 1e-10 * max(1.0, abs(lp_ref)), (i, lp[i], lp_ref)
+            assert np.max(np.abs(g[i] - g_ref)) <= 1e-10 * max(1.0, np.max(np.abs(g_ref))), i
+        assert np.allclose(lp, lp16, rtol=1e-11, atol=1e-9) and np.allclose(g, g16, rtol=1e-9, atol=1e-9)
+    prob.close()
+
+
+@pytest.mark.parametrize('om_mode', [1, 2])
+def test_wave_nuts_with_the_outlier_model_matches_oracle_and_the_16_chain_kernel(om_mode):
+    """Mid-occupancy runs of the outlier models (what a batch of a few hundred spectra x 4 chains is) take the one-chain-per-wave kernel
+    with the outlier parameters as further slots of the lanes, four chains per CU: draw by draw the oracle's chains."""
+    from bayes_drt_amd.engine import Sampler, sample_units
+    from oracle import oracle as orc
+    prob, om = _outlier_problem('K161', om_mode)
+    ctrl = _ctrl(prob._lib, max_treedepth=6)
+    warm, nd = 20, 6
+    with _env(BDRT_WAVE='1', BDRT_SOLO=None, BDRT_WIDE1=None):
+        with Sampler(prob, 5, warm, nd, 4321, ctrl) as smp:
+            assert smp.kind() == 3
+            smp.run()
+            draws, lp, diag = smp.results()
+    with _env(BDRT_WAVE=None, BDRT_SOLO=None, BDRT_WIDE1=None):
+        # the default choice for this family: the general one-chain kernel up to one chain per CU, the wave kernel from there to four
+        with Sampler(prob, 5, 2, 2, 4321, ctrl) as few:
+            assert few.kind() == 2
+        with Sampler(prob, 300, 2, 2, 4321, ctrl) as mid:
+            assert mid.kind() == 3
+    with _env(BDRT_WAVE='0', BDRT_SOLO='0', BDRT_WIDE1='0'):
+        d16, lp16, dg16 = sample_units(prob, 5, warm, nd, 4321, ctrl)
+    octrl = orc.nuts_control(max_treedepth=6)
+    for c in range(5):
+        ref, lpr, dr = orc.nuts_sample(om, c, 4321, warm, nd, control=octrl)
+        assert dr['n_leapfrog'] == diag[c]['n_leapfrog'] == dg16[c]['n_leapfrog'], (c, dr, diag[c], dg16[c])
+        assert dr['n_divergent'] == diag[c]['n_divergent']
+        assert np.max(np.abs(draws[c] - ref)) < 1e-6 * np.max(np.abs(ref)), c
+        assert np.max(np.abs(draws[c] - d16[c])) < 1e-6 * np.max(np.abs(ref)), c
+        assert np.allclose(lp[c], lpr, rtol=1e-8, atol=1e-6)
+    prob.close()
+
+
+def test_tail_of_a_large_run_of_an_outlier_model_moves_to_the_wave_kernel(monkeypatch):
+    """More than four chains per CU of the outlier family start on the 16-chain kernel; `bdrt_sampler_run` hands the last live chains
+    (<= four per CU) to the one-chain-per-wave kernel.  The run equals the one without the hand-over chain by chain."""
+    from bayes_drt_amd.engine import Sampler
+    prob, om = _outlier_problem('K81', 1)
+    ctrl = _ctrl(prob._lib, max_treedepth=5)
+    n_units = 1200
+
+    def run():
+        with Sampler(prob, n_units, 16, 8, 3, ctrl) as smp:
+            kind0 = smp.kind()
+            smp.run()
+            return smp.results() + (kind0, smp.kind(), smp.tail_units())
+
+    d1, lp1, g1, k0, k1, tail1 = run()
+    assert k0 == 0 and k1 == 3 and 0 < tail1 <= 1024, (k0, k1, tail1)
+    monkeypatch.setenv('BDRT_TAIL_MIGRATION', '0')
+    d0, lp0, g0, k0b, k1b, tail0 = run()
+    assert k1b == 0 and tail0 == 0
+    assert np.all(np.isfinite(d1))
+    err = np.max(np.abs(d1 - d0), axis=(1, 2)) / np.max(np.abs(d0))
+    assert np.mean(err < 1e-6) > 0.9, np.mean(err < 1e-6)
+    assert [x['n_leapfrog'] for x in g1[:50]] == [x['n_leapfrog'] for x in g0[:50]]
+    prob.close()
