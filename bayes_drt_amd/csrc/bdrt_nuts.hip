@@ -979,7 +979,7 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         S.solo = true;                                                                          // start in the one-chain layout
         S.may_migrate = false;
     }
-    if (S.wave) S.geomw = wave_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
+    if (S.wave) S.geomw = wave_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D, P.dev.nblocks);
     if (S.solo) S.geom = solo_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
     // chains per workgroup: fill every CU with one workgroup before putting a second chain on any wave
     {
@@ -1618,7 +1618,7 @@ int bdrt_debug_wave_logp_grad(bdrt_problem *p, const double *theta, const int *s
     Problem &P = p->impl;
     if (!wave_capable(P.dev)) { set_error("problem does not take the one-chain-per-wave path"); return -2; }
     BDRT_HIP(hipSetDevice(P.device));
-    const WaveGeom g = wave_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
+    const WaveGeom g = wave_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D, P.dev.nblocks);
     const size_t lds = wave_lds_bytes(g, 0);
     double *dth = nullptr, *dlp = nullptr, *dg = nullptr;
     int *dsp = nullptr;

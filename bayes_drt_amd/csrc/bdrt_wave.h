@@ -35,6 +35,7 @@ struct WaveGeom {
     int MG, KP, NLP;          // backward product: 6-column groups per part, 6 * MG, nf padded to a multiple of 8
     int S, GQ;                // generator: logical index n - m + S, quarter length of one part's swizzled table
     int KZ;                   // x is kept zero on [K, KZ): what the forward product reads beyond the basis
+    int nb;                   // blocks (distributions) of the model: a generator table each
     int XL;                   // halo-padded K-row
     int DSS;                  // row stride of the D-vectors (as bdrt_solo.h)
     int o_xs, o_us, o_w, o_gen, o_zp, o_gz, o_state, o_hot, total0;      // LDS offsets (doubles); total0: without hot rows
@@ -42,10 +43,10 @@ struct WaveGeom {
 
 constexpr int WV_MAXPARTS = 8;            // m-parts of the forward product at most
 
-__host__ __device__ inline WaveGeom wave_geometry(int nf, int K, int D)
+__host__ __device__ inline WaveGeom wave_geometry(int nf, int K, int D, int nb = 1)
 {
     WaveGeom g;
-    g.nf = nf; g.K = K; g.D = D;
+    g.nf = nf; g.K = K; g.D = D; g.nb = nb;
     g.KS = (K + 63) / 64; g.NS = (nf + 63) / 64;
     g.RGb = (nf + 3) / 4; g.R4 = 4 * g.RGb;
     int np = WV_NT / g.RGb;
@@ -67,7 +68,7 @@ __host__ __device__ inline WaveGeom wave_geometry(int nf, int K, int D)
     g.o_xs = o; o += g.XL;
     g.o_us = o; o += g.XL;
     g.o_w = o; o += 3 * g.XL;
-    g.o_gen = o; o += 2 * 4 * g.GQ;
+    g.o_gen = o; o += nb * 2 * 4 * g.GQ;
     const int zp = g.NP * 2 * g.R4, gk = 2 * g.KP;
     g.o_zp = o; o += ((zp > gk ? zp : gk) + 1) & ~1;
     g.o_gz = o; o += 2 * g.NLP + 8;
@@ -91,13 +92,20 @@ __host__ __device__ inline size_t wave_lds_bytes(const WaveGeom &g, int nhot) { 
 // can this problem take the one-chain-per-wave path?  (host)
 // (the outlier error models -- two further parameters per frequency, bdrt_tile_hw.h -- take the same kernel with 2 NS more slots per lane
 //  and one wave per SIMD: wave_chains_per_cu)
+// (and the models of several distributions -- Series-Parallel, Series-2Parallel, any mix of series and parallel blocks with one basis
+//  length on a log-uniform grid, with or without the x_sum prior and the outlier models: wave_eval_nb)
 inline bool wave_capable(const DevProblem &P)
 {
-    return P.fast_s1 && P.blk[0].tg != nullptr && P.blk[0].K >= 2 * MAXBW + 3 && P.blk[0].K <= 192 &&
-           P.nf <= 128 && P.D == 2 * P.blk[0].K + 9 + (P.outlier_mode ? 2 * P.nf : 0);
+    const int K = P.blk[0].K;
+    if (P.nblocks < 1 || P.nblocks > 3 || K < 2 * MAXBW + 3 || K > 192 || P.nf > 128) return false;
+    if (P.nblocks > 1 && K <= 64) return false;            // (instantiated for two or three slots of basis functions per lane: bdrt_wave_nb.hip)
+    for (int b = 0; b < P.nblocks; ++b)
+        if (P.blk[b].K != K || P.blk[b].tg == nullptr || !P.blk[b].toep) return false;
+    if (P.nblocks == 1 && !P.fast_s1) return false;
+    return P.D == P.nblocks * (2 * K + 3) + 6 + (P.outlier_mode ? 2 * P.nf : 0);
 }
-// chains a CU keeps resident: two waves per SIMD for the headline family, one with the outlier parameters in registers too
-inline int wave_chains_per_cu(const DevProblem &P) { return P.outlier_mode ? 4 : 8; }
+// chains a CU keeps resident: two waves per SIMD for the headline family, one with more parameters per lane than that
+inline int wave_chains_per_cu(const DevProblem &P) { return (P.outlier_mode || P.nblocks > 1) ? 4 : 8; }
 
 typedef const __attribute__((address_space(4))) double *wv_cptr;      // uniform read-only data: scalar loads
 
@@ -257,12 +265,13 @@ __device__ __forceinline__ void wave_eval_init(const DevProblem &P, const WaveGe
 {
     for (int i = lane; i < g.o_gen; i += WV_NT) lds[i] = (i >= g.o_us && i < g.o_us + g.XL) ? 1.0 : 0.0;
     for (int i = lane; i < 2 * g.NLP + 8; i += WV_NT) lds[g.o_gz + i] = 0.0;
-    const double *tg = P.blk[0].tg;                                                  // [2][nf + K - 1]: c_b[n - m + K - 1]
     const int glen = g.nf + g.K - 1;
-    for (int i = lane; i < 2 * 4 * g.GQ; i += WV_NT) {
-        const int b = i / (4 * g.GQ), r = i - b * 4 * g.GQ, rho = r / g.GQ, q = r - rho * g.GQ;
+    for (int i = lane; i < g.nb * 2 * 4 * g.GQ; i += WV_NT) {
+        const int blk = i / (2 * 4 * g.GQ), i2 = i - blk * 2 * 4 * g.GQ;
+        const int b = i2 / (4 * g.GQ), r = i2 - b * 4 * g.GQ, rho = r / g.GQ, q = r - rho * g.GQ;
         const int e = 4 * q + rho;                                                   // logical index: n - m + S
         const int src = e - g.S + g.K - 1;
+        const double *tg = P.blk[blk].tg;                                            // [2][nf + K - 1]: c_b[n - m + K - 1]
         lds[g.o_gen + i] = (src >= 0 && src < glen) ? tg[(size_t)b * glen + src] : 0.0;
     }
 }
@@ -587,6 +596,344 @@ __device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom 
     BDRT_WV_PROF(5);
 #undef BDRT_WV_PROF
     return T[6];
+}
+
+// ---- several distributions ------------------------------------------------------------------------------------------------------------
+// NB blocks of one basis length (series or parallel, each with its own generator table, band coefficients, sign constraint and scale),
+// the x_sum prior of the mixed models, the outlier error models: the formulas of bdrt_tile_hw.h / bdrt_solo_wide.h on the lane mapping of
+// wave_eval.  Slots of a lane: per block KS x-slots and KS ups-slots, then the scalars (lanes 0..5 the global ones, lane 6 + 3 b + i the
+// penalty strength d_i of block b), then the outlier parameters.  One wave per SIMD (512 registers).
+template <int KS, int NS, bool OM, int NB> constexpr int wave_slots_nb() { return 2 * KS * NB + 1 + (OM ? 2 * NS : 0); }
+
+template <int KS, int NS, bool OM, int NB>
+__device__ __forceinline__ int wave_slot_index_nb(const DevProblem &P, int K, int u, int lane)
+{
+    if (u < 2 * KS * NB) {
+        const int b = u / (2 * KS), r = u - b * 2 * KS;
+        const DevBlock &B = P.blk[b];
+        if (r < KS) return lane + 64 * r < K ? B.o_x + lane + 64 * r : -1;
+        return lane + 64 * (r - KS) < K ? B.o_ups + lane + 64 * (r - KS) : -1;
+    }
+    if (u == 2 * KS * NB)
+        return lane < 2 ? lane : (lane < 6 ? P.o_err + (lane - 2) : (lane < 6 + 3 * NB ? P.blk[(lane - 6) / 3].o_d + (lane - 6) % 3 : -1));
+    if constexpr (OM) {
+        const int s = u - (2 * KS * NB + 1), h = s >= NS ? 1 : 0, n = lane + 64 * (s - h * NS);
+        return n < P.nf ? P.o_so + h * P.nf + n : -1;
+    }
+    return -1;
+}
+
+template <int KS, int NS, bool OM, int NB>
+__device__ __forceinline__ double wave_eval_nb(const DevProblem &P, const WaveGeom &g, double *lds, const double (&th)[wave_slots_nb<KS, NS, OM, NB>()],
+                                               double (&gr)[wave_slots_nb<KS, NS, OM, NB>()], const WaveEvalRegs<NS> &er, const double jac, int lane_)
+{
+    int lane = lane_;
+    __asm__ volatile("" : "+v"(lane));
+    constexpr int SC = 2 * KS * NB, SO = SC + 1;
+    const int nf = g.nf, K = g.K;
+    double *xs = lds + g.o_xs, *us = lds + g.o_us, *wr = lds + g.o_w;
+    double *zp = lds + g.o_zp, *gz = lds + g.o_gz;
+    double lp = 0.0;
+
+    // ---- scalars --------------------------------------------------------------------------------------------------------------
+    const double st = th[SC];
+    const double sraw = lean_exp(st);
+    lp += lane < 6 + 3 * NB ? (lane < 6 ? -0.5 * sraw * sraw : -6.0 * st - 5.0 * lean_rcp(sraw)) + jac * st : 0.0;
+    double sc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sc[i] = wv_bcast(sraw, i);
+
+    double xk[NB][KS], gup[NB][KS], gl[NB][KS], yr[NB][NS], yi[NB][NS], Ssum[NB][3];
+    bool kv[KS];
+#pragma unroll
+    for (int u = 0; u < KS; ++u) kv[u] = lane + 64 * u < K;
+    double xsum_p = 0.0;
+
+    // ================================================= forward, block by block ===========================================================
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const DevBlock &B = P.blk[b];
+        const double *gen = lds + g.o_gen + b * 2 * 4 * g.GQ;
+        double uu[KS];
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            const int k = lane + 64 * u;
+            const double tx = th[b * 2 * KS + u], tu = th[b * 2 * KS + KS + u];
+            const double ex = lean_exp(tx);
+            xk[b][u] = kv[u] ? (B.is_pos ? ex : tx) : 0.0;
+            uu[u] = kv[u] ? 0.15 * lean_exp(tu) : 1.0;
+            lp += (kv[u] && B.is_pos) ? jac * tx : 0.0;
+            xsum_p += xk[b][u];
+            if (k < g.KZ || kv[u]) xs[MAXBW + k] = xk[b][u];
+            if (kv[u]) us[2 + k] = uu[u];
+        }
+        wv_sync();
+        // forward product partials (A_b x_raw; the block's scale is applied to the sums)
+        {
+            const int part = er.fpart, rg = lane - part * g.RGb;
+            if (part < g.NP) {
+                const int n0 = 4 * rg, m0 = part * g.ML;
+                double ar[4] = {0.0, 0.0, 0.0, 0.0}, ai[4] = {0.0, 0.0, 0.0, 0.0};
+                wave_toep_fwd(gen, g.GQ, n0 - m0 + g.S, xs + MAXBW + m0, g.ML, ar, ai);
+                double *o = zp + (size_t)(2 * part) * g.R4 + n0;
+                *reinterpret_cast<double2 *>(o) = make_double2(ar[0], ar[1]); *reinterpret_cast<double2 *>(o + 2) = make_double2(ar[2], ar[3]);
+                o += g.R4;
+                *reinterpret_cast<double2 *>(o) = make_double2(ai[0], ai[1]); *reinterpret_cast<double2 *>(o + 2) = make_double2(ai[2], ai[3]);
+            }
+        }
+        // prior chain x -> L x -> w (as wave_eval)
+        double sv0 = 0.0, sv1 = 0.0, sv2 = 0.0;
+        {
+            const double d0 = wv_bcast(sraw, 6 + 3 * b), d1 = wv_bcast(sraw, 7 + 3 * b), d2 = wv_bcast(sraw, 8 + 3 * b);
+            double v0[KS], v1[KS], v2[KS];
+#pragma unroll
+            for (int u = 0; u < KS; ++u) { v0[u] = 0.0; v1[u] = 0.0; v2[u] = 0.0; }
+            {
+                constexpr int NT13 = 2 * MAXBW + 1, CB = 4;
+                wv_cptr Tc = (wv_cptr)&B.T[0][0];
+                __asm__ volatile("" : "+s"(Tc));
+                const double *xl = xs + (kv[0] ? lane : 0);
+                double xa[CB][KS], xb[CB][KS];
+                auto ld = [&](double (&xv)[CB][KS], int dd0) {
+#pragma unroll
+                    for (int j = 0; j < CB; ++j)
+#pragma unroll
+                        for (int u = 0; u < KS; ++u) xv[j][u] = xl[(kv[u] ? 64 * u : 0) + dd0 + j];
+                };
+                auto mac = [&](const double (&xv)[CB][KS], int dd0) {
+#pragma unroll
+                    for (int j = 0; j < CB; ++j) {
+                        const int d = dd0 + j, dd = d < NT13 ? d : NT13 - 1;
+                        const bool in = d < NT13;
+                        const double t0 = in ? Tc[dd] : 0.0, t1 = in ? Tc[NT13 + dd] : 0.0, t2 = in ? Tc[2 * NT13 + dd] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < KS; ++u) {
+                            v0[u] = fma(t0, xv[j][u], v0[u]); v1[u] = fma(t1, xv[j][u], v1[u]); v2[u] = fma(t2, xv[j][u], v2[u]);
+                        }
+                    }
+                };
+                ld(xa, 0);
+#pragma unroll 1
+                for (int dd0 = 0; dd0 < NT13; dd0 += 2 * CB) {
+                    ld(xb, dd0 + CB);
+                    mac(xa, dd0);
+                    ld(xa, dd0 + 2 * CB);
+                    mac(xb, dd0 + CB);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+                const int k = lane + 64 * u;
+                const int kc = kv[u] ? k : 0;
+                const double um2 = us[kc], um1 = us[kc + 1], up1 = us[kc + 3], up2 = us[kc + 4];
+                const double uk = uu[u], tu = th[b * 2 * KS + KS + u];
+                const double iu = lean_rcp(uk), iu2 = iu * iu;
+                const double q2 = d0 * v0[u] * v0[u] + d1 * v1[u] * v1[u] + d2 * v2[u] * v2[u];
+                const double ir = 0.15 * iu;
+                double lpk = -(tu + LOG_015) - 0.5 * q2 * iu2 - (P.ups_alpha + 1.0) * tu - P.ups_beta * ir + jac * tu;
+                double gu = -iu + q2 * iu2 * iu;
+                if (k >= 1 && k + 1 < K) {
+                    const double du = 0.5 * (uk - 0.5 * (um1 + up1)) * iu;
+                    lpk += -0.5 * du * du;
+                    gu += -du * 0.25 * (um1 + up1) * iu2;
+                }
+                if (k >= 2 && kv[u]) {
+                    const double i0 = lean_rcp(um1);
+                    const double du = 0.5 * (um1 - 0.5 * (um2 + uk)) * i0;
+                    gu += du * 0.25 * i0;
+                }
+                if (k + 2 < K) {
+                    const double i0 = lean_rcp(up1);
+                    const double du = 0.5 * (up1 - 0.5 * (uk + up2)) * i0;
+                    gu += du * 0.25 * i0;
+                }
+                lp += kv[u] ? lpk : 0.0;
+                sv0 += kv[u] ? v0[u] * v0[u] * iu2 : 0.0; sv1 += kv[u] ? v1[u] * v1[u] * iu2 : 0.0; sv2 += kv[u] ? v2[u] * v2[u] * iu2 : 0.0;
+                gup[b][u] = uk * gu - (P.ups_alpha + 1.0) + P.ups_beta * ir + jac;
+                if (kv[u]) {
+                    wr[MAXBW + k] = -d0 * v0[u] * iu2;
+                    wr[g.XL + MAXBW + k] = -d1 * v1[u] * iu2;
+                    wr[2 * g.XL + MAXBW + k] = -d2 * v2[u] * iu2;
+                }
+            }
+        }
+        {
+            const double q[4] = {sv0, sv1, sv2, 0.0};
+            double t = sum32_by_lane<4>(q, lane);
+            t += wv_xor32(t);
+            Ssum[b][0] = wv_bcast(t, 0); Ssum[b][1] = wv_bcast(t, 1); Ssum[b][2] = wv_bcast(t, 2);
+        }
+        wv_sync();
+        // Y_b at this lane's rows; sum_i L_i^T w_i at this lane's k
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int n = lane + 64 * s, nn = n < nf ? n : 0;
+            double zr = 0.0, zi = 0.0;
+#pragma unroll 1
+            for (int p = 0; p < g.NP; ++p) { zr += zp[(size_t)(2 * p) * g.R4 + nn]; zi += zp[(size_t)(2 * p + 1) * g.R4 + nn]; }
+            yr[b][s] = zr * B.x_scale; yi[b][s] = zi * B.x_scale;
+        }
+        {
+#pragma unroll
+            for (int u = 0; u < KS; ++u) gl[b][u] = 0.0;
+            constexpr int NT13 = 2 * MAXBW + 1;
+            wv_cptr Tc = (wv_cptr)&B.T[0][0];
+            __asm__ volatile("" : "+s"(Tc));
+#pragma unroll 1
+            for (int i = 0; i < 3; ++i) {
+                const double *wl = wr + i * g.XL + 2 * MAXBW;
+#pragma unroll
+                for (int j = 0; j < NT13; ++j) {
+                    const double c = Tc[i * NT13 + j];
+#pragma unroll
+                    for (int u = 0; u < KS; ++u) gl[b][u] = fma(c, wl[(kv[u] ? lane + 64 * u : 0) - j], gl[b][u]);
+                }
+            }
+        }
+        wv_sync();                                         // (the next block reuses the x, ups, w rows and the partial sums)
+    }
+
+    // ================================================= x_sum prior, likelihood ===========================================================
+    double xs_term = 0.0;
+    bool rej = false;
+    if (P.use_x_sum) {
+        const double xs_raw = wv_sum(xsum_p);
+        const double xsn = xs_raw * P.x_sum_invscale;
+        lp += lane == 0 ? -0.5 * xsn * xsn : 0.0;
+        rej = xs_raw < 0.0;
+        xs_term = -xs_raw * P.x_sum_invscale * P.x_sum_invscale;
+    }
+    double T[7], gzr_[NS], gzi_[NS];
+    {
+        double sR = 0, sL = 0, sH = 0, sHz2 = 0, sHzr2 = 0, sHzi2 = 0;
+        const double Rinf = 100.0 * sc[0], induc = sc[1] * P.induc_scale;
+        const double s_res = 0.05 * sc[2], a_p = 0.05 * sc[3], a_r = 0.05 * sc[4], a_i = 0.05 * sc[5];
+        const double c0 = P.sigma_min * P.sigma_min + s_res * s_res;
+        const double ap2 = a_p * a_p, ar2 = a_r * a_r, ai2 = a_i * a_i;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int n = lane + 64 * s;
+            const bool nv = n < nf;
+            double zr = Rinf, zi = induc * er.wn[s];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (!P.blk[b].is_parallel) { zr += yr[b][s]; zi += yi[b][s]; }
+                else {
+                    const double idn = lean_rcp(yr[b][s] * yr[b][s] + yi[b][s] * yi[b][s]);
+                    zr += yr[b][s] * idn;                   // Z_hat_p = conj(Y) / |Y|^2 (Parallel_modelcode.txt:47)
+                    zi += -yi[b][s] * idn;
+                }
+            }
+            const double common = ar2 * zr * zr + ai2 * zi * zi;
+            [[maybe_unused]] double so_re = 0.0, so_im = 0.0, r0 = 0.0, r1 = 0.0, t0 = 0.0, t1 = 0.0;
+            if constexpr (OM) {
+                t0 = th[SO + s]; t1 = th[SO + NS + s];
+                r0 = lean_exp(t0); r1 = lean_exp(t1);
+                if (P.outlier_mode == 1) so_re = so_im = 0.05 * r0 * r1;
+                else { so_re = 0.05 * r0; so_im = 0.05 * r1; }
+            }
+            double s2_re = c0 + ap2 * zr * zr + common, s2_im = c0 + ap2 * zi * zi + common;
+            if constexpr (OM) { s2_re += so_re * so_re; s2_im += so_im * so_im; }
+            const double e_re = er.zre[s] - zr, e_im = er.zim[s] - zi;
+            const double prod = s2_re * s2_im, ip = lean_rcp(prod);
+            const double w_re = s2_im * ip, w_im = s2_re * ip;
+            const double lpn = -0.5 * lean_log(prod) - 0.5 * e_re * e_re * w_re - 0.5 * e_im * e_im * w_im;
+            const double h_re = -0.5 * w_re + 0.5 * e_re * e_re * w_re * w_re;
+            const double h_im = -0.5 * w_im + 0.5 * e_im * e_im * w_im * w_im;
+            const double gzr = e_re * w_re + 2.0 * zr * (h_re * (ap2 + ar2) + h_im * ar2);
+            const double gzi = e_im * w_im + 2.0 * zi * (h_im * (ap2 + ai2) + h_re * ai2);
+            gzr_[s] = nv ? gzr : 0.0; gzi_[s] = nv ? gzi : 0.0;
+            if constexpr (OM) {
+                double g0 = 0.0, g1 = 0.0, lpo = 0.0;
+                if (P.outlier_mode == 1) {
+                    const double dso = 2.0 * so_re * (h_re + h_im), ir1 = lean_rcp(r1);
+                    g0 = r0 * (0.05 * r1 * dso - P.so_lambda) + jac;
+                    g1 = 0.05 * r0 * r1 * dso - (P.so_alpha + 1.0) + P.so_beta * ir1 + jac;
+                    lpo = -P.so_lambda * r0 - (P.so_alpha + 1.0) * t1 - P.so_beta * ir1 + jac * (t0 + t1);
+                } else {
+                    g0 = r0 * (0.05 * 2.0 * so_re * h_re - P.so_lambda) + jac;
+                    g1 = r1 * (0.05 * 2.0 * so_im * h_im - P.so_lambda) + jac;
+                    lpo = -P.so_lambda * (r0 + r1) + jac * (t0 + t1);
+                }
+                gr[SO + s] = nv ? g0 : 0.0; gr[SO + NS + s] = nv ? g1 : 0.0;
+                lp += nv ? lpo : 0.0;
+            }
+            if (nv) {
+                lp += lpn;
+                sR += gzr; sL += gzi * er.wn[s]; sH += h_re + h_im; sHz2 += h_re * zr * zr + h_im * zi * zi;
+                sHzr2 += (h_re + h_im) * zr * zr; sHzi2 += (h_re + h_im) * zi * zi;
+            }
+        }
+        const double q[8] = {sR, sL, sH, sHz2, sHzr2, sHzi2, lp, 0.0};
+        double t = sum32_by_lane<8>(q, lane);
+        t += wv_xor32(t);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) T[i] = wv_bcast(t, i);
+    }
+
+    // ================================================= backward, block by block ==========================================================
+    double *gk = zp;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const DevBlock &B = P.blk[b];
+        const double *gen = lds + g.o_gen + b * 2 * 4 * g.GQ;
+        // operand of A_b^T: g_Zhat, or J^T g_Zhat through Z_hat_p = conj(Y)/|Y|^2 (times the block's scale) for a parallel block
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int n = lane + 64 * s;
+            double rr = gzr_[s], ri = gzi_[s];
+            if (B.is_parallel) {
+                const double a = yr[b][s], c = yi[b][s];
+                const double dn = a * a + c * c, id2 = lean_rcp(dn * dn);
+                const double dd = (c * c - a * a) * id2, doff = 2.0 * a * c * id2;
+                rr = gzr_[s] * dd + gzi_[s] * doff;
+                ri = -gzr_[s] * doff + gzi_[s] * dd;
+            }
+            if (n < nf) { gz[n] = rr * B.x_scale; gz[g.NLP + n] = ri * B.x_scale; }
+        }
+        wv_sync();
+        {
+            const int h = lane >> 5, mg = lane & 31;
+            if (mg < g.MG) {
+                double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                wave_toep_bwd(gen + h * 4 * g.GQ, g.GQ, g.S - 6 * mg, gz + h * g.NLP, g.NLP, acc);
+                double *o = gk + h * g.KP + 6 * mg;
+                *reinterpret_cast<double2 *>(o) = make_double2(acc[0], acc[1]);
+                *reinterpret_cast<double2 *>(o + 2) = make_double2(acc[2], acc[3]);
+                *reinterpret_cast<double2 *>(o + 4) = make_double2(acc[4], acc[5]);
+            }
+        }
+        wv_sync();
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            const int k = lane + 64 * u;
+            const int kk = kv[u] ? k : 0;
+            const double graw = gl[b][u] + gk[kk] + gk[g.KP + kk] + xs_term;
+            gr[b * 2 * KS + u] = kv[u] ? (B.is_pos ? xk[b][u] * graw + jac : graw) : 0.0;
+            gr[b * 2 * KS + KS + u] = kv[u] ? gup[b][u] : 0.0;
+        }
+        wv_sync();                                         // (the next block's operand and product reuse gz and the partial sums)
+    }
+    {
+        double gsc = 0.0;
+        if (lane < 6) {
+            const double t = lane == 0 ? T[0] : lane == 1 ? T[1] : lane == 2 ? T[2] : lane == 3 ? T[3] : lane == 4 ? T[4] : T[5];
+            double dl;
+            if (lane == 0) dl = 100.0 * t;
+            else if (lane == 1) dl = P.induc_scale * t;
+            else dl = 0.05 * 2.0 * (0.05 * sraw) * t;
+            gsc = sraw * (dl - sraw) + jac;
+        } else if (lane < 6 + 3 * NB) {
+            double svs = 0.0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) svs = lane == 6 + 3 * b + i ? Ssum[b][i] : svs;
+            gsc = -0.5 * sraw * svs - 6.0 + 5.0 * lean_rcp(sraw) + jac;
+        }
+        gr[SC] = gsc;
+    }
+    return rej ? -INFINITY : T[6];
 }
 
 }  // namespace bdrt

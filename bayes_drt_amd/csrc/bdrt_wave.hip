@@ -19,6 +19,11 @@ namespace bdrt {
         else { CALL(3, 2); }                                               \
     } while (0)
 
+int launch_wave_nuts_nb(const DevProblem *dp, const NutsParams &np, const NutsArgs &args, const WaveGeom &g, int nhot, int n_wg, size_t lds,
+                        hipStream_t stream, int outlier_model);
+int launch_wave_eval_nb(const DevProblem *dp, const WaveGeom &g, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
+                        double *d_grad, int n_wg, size_t lds, hipStream_t stream, int outlier_model);
+
 static hipError_t wave_set_lds_limit(size_t bytes)
 {
     static LdsAttrCache cache;
@@ -61,6 +66,7 @@ size_t wave_lds_request(const WaveGeom &g, int n_wg, int n_cu, int *nhot, int ma
 int launch_wave_nuts(const DevProblem *dp, const NutsParams &np, const NutsArgs &args, const WaveGeom &g, int nhot, int n_wg, size_t lds,
                      hipStream_t stream, int outlier_model)
 {
+    if (g.nb > 1) return launch_wave_nuts_nb(dp, np, args, g, nhot, n_wg, lds, stream, outlier_model);     // (bdrt_wave_nb.hip)
     BDRT_HIP(wave_set_lds_limit(lds));
 #define BDRT_WV_CALL(KS_, NS_) hipLaunchKernelGGL((nuts_wave_kernel<KS_, NS_>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, np, args, g, nhot)
 #define BDRT_WV_CALL_PROF(KS_, NS_) hipLaunchKernelGGL((nuts_wave_kernel<KS_, NS_, true>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, np, args, g, nhot)
@@ -78,6 +84,7 @@ int launch_wave_nuts(const DevProblem *dp, const NutsParams &np, const NutsArgs 
 int launch_wave_eval(const DevProblem *dp, const WaveGeom &g, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp,
                      double *d_grad, int n_wg, size_t lds, hipStream_t stream, int outlier_model)
 {
+    if (g.nb > 1) return launch_wave_eval_nb(dp, g, d_theta, d_spec, B, jacobian, d_lp, d_grad, n_wg, lds, stream, outlier_model);
     BDRT_HIP(wave_set_lds_limit(lds));
 #define BDRT_WV_CALL(KS_, NS_) hipLaunchKernelGGL((wave_eval_kernel<KS_, NS_>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, g, d_theta, d_spec, B, jacobian, d_lp, d_grad)
 #define BDRT_WV_CALL_OM(KS_, NS_) hipLaunchKernelGGL((wave_eval_kernel<KS_, NS_, true>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, g, d_theta, d_spec, B, jacobian, d_lp, d_grad)

@@ -12,10 +12,11 @@ typedef __attribute__((address_space(1))) double wv_glb_d;
 
 // PROF: the instantiation that fills the phase profile (a kernel of its own: see nuts_kernel, bdrt_nuts16.h)
 // OM: the outlier error model's parameters (two per frequency) are slots of the lanes too; one wave per SIMD then (512 registers)
-template <int KS, int NS, bool PROF = false, bool OM = false>
-__global__ __launch_bounds__(WV_NT, OM ? 1 : 2) void nuts_wave_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, WaveGeom g, int nhot)
+// NB: distributions of the model (wave_eval_nb from two on)
+template <int KS, int NS, bool PROF = false, bool OM = false, int NB = 1>
+__global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : 2) void nuts_wave_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, WaveGeom g, int nhot)
 {
-    constexpr int NJ = wave_slots<KS, NS, OM>();
+    constexpr int NJ = wave_slots_nb<KS, NS, OM, NB>();
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevProblem &P = *Pp;
     const int lane = threadIdx.x;
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(WV_NT, OM ? 1 : 2) void nuts_wave_kernel(const DevP
     int jx[NJ];                                            // D-index of each slot, clamped; ok[u]: the slot holds an element
     bool ok[NJ];
 #pragma unroll
-    for (int u = 0; u < NJ; ++u) { const int j = wave_slot_index<KS, NS, OM>(P, g.K, u, lane); ok[u] = j >= 0; jx[u] = j >= 0 ? j : 0; }
+    for (int u = 0; u < NJ; ++u) { const int j = (NB == 1 ? wave_slot_index<KS, NS, OM>(P, g.K, u, lane) : wave_slot_index_nb<KS, NS, OM, NB>(P, g.K, u, lane)); ok[u] = j >= 0; jx[u] = j >= 0 ? j : 0; }
 
     // row access: a row is LDS-resident when its rank is below nhot (uniform), else it is read / written where it is in HBM
     auto load_row = [&](int v, double (&o)[NJ]) {
@@ -125,14 +126,16 @@ __global__ __launch_bounds__(WV_NT, OM ? 1 : 2) void nuts_wave_kernel(const DevP
             u_iter = s.iter; u_depth = s.depth; u_blk = s.leaf >> 6;
             uvec = rng_uniform(rng, (uint32_t)(64 * u_blk + lane), RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
         }
-        const double lp = wave_eval<KS, NS, OM>(P, g, smem, th, gq, er, 1.0, lane, prof);
+        double lp;
+        if constexpr (NB == 1) lp = wave_eval<KS, NS, OM>(P, g, smem, th, gq, er, 1.0, lane, prof);
+        else lp = wave_eval_nb<KS, NS, OM, NB>(P, g, smem, th, gq, er, 1.0, lane);
         {
             // the slot indices from a lane number the optimiser cannot see through: otherwise every row's per-slot address
             // (37 rows x NJ) is computed once in front of the loop and spilled.  After the evaluation: not live across it.
             int ln = lane;
             __asm__ volatile("" : "+v"(ln));
 #pragma unroll
-            for (int u = 0; u < NJ; ++u) { const int j = wave_slot_index<KS, NS, OM>(P, g.K, u, ln); ok[u] = j >= 0; jx[u] = j >= 0 ? j : 0; }
+            for (int u = 0; u < NJ; ++u) { const int j = (NB == 1 ? wave_slot_index<KS, NS, OM>(P, g.K, u, ln) : wave_slot_index_nb<KS, NS, OM, NB>(P, g.K, u, ln)); ok[u] = j >= 0; jx[u] = j >= 0 ? j : 0; }
         }
         long long tsp = prof ? clock64() : 0;
 #define BDRT_WV_NPROF(slot) do { if (prof) { const long long t_ = clock64(); if (lane == 0) prof[slot] += t_ - tsp; tsp = t_; } } while (0)
@@ -395,11 +398,11 @@ __global__ __launch_bounds__(WV_NT, OM ? 1 : 2) void nuts_wave_kernel(const DevP
 }
 
 // evaluator of the one-chain-per-wave path on its own (parity tests; few-point batches): a wave per point, grid-stride
-template <int KS, int NS, bool OM = false>
-__global__ __launch_bounds__(WV_NT, OM ? 1 : 2) void wave_eval_kernel(const DevProblem *__restrict__ Pp, WaveGeom g, const double *theta,
+template <int KS, int NS, bool OM = false, int NB = 1>
+__global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : 2) void wave_eval_kernel(const DevProblem *__restrict__ Pp, WaveGeom g, const double *theta,
                                                              const int *spec, int B, int jacobian, double *lp, double *grad)
 {
-    constexpr int NJ = wave_slots<KS, NS, OM>();
+    constexpr int NJ = wave_slots_nb<KS, NS, OM, NB>();
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevProblem &P = *Pp;
     const int lane = threadIdx.x;
@@ -408,13 +411,15 @@ __global__ __launch_bounds__(WV_NT, OM ? 1 : 2) void wave_eval_kernel(const DevP
     int jx[NJ];
     bool ok[NJ];
 #pragma unroll
-    for (int u = 0; u < NJ; ++u) { const int j = wave_slot_index<KS, NS, OM>(P, g.K, u, lane); ok[u] = j >= 0; jx[u] = j >= 0 ? j : 0; }
+    for (int u = 0; u < NJ; ++u) { const int j = (NB == 1 ? wave_slot_index<KS, NS, OM>(P, g.K, u, lane) : wave_slot_index_nb<KS, NS, OM, NB>(P, g.K, u, lane)); ok[u] = j >= 0; jx[u] = j >= 0 ? j : 0; }
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         double th[NJ], gr[NJ];
 #pragma unroll
         for (int u = 0; u < NJ; ++u) { const double t = theta[(size_t)b * g.D + jx[u]]; th[u] = ok[u] ? t : 0.0; }
         const WaveEvalRegs<NS> er = wave_eval_setup<NS>(P, g, spec ? spec[b] : 0, lane);
-        const double v = wave_eval<KS, NS, OM>(P, g, smem, th, gr, er, jacobian ? 1.0 : 0.0, lane);
+        double v;
+        if constexpr (NB == 1) v = wave_eval<KS, NS, OM>(P, g, smem, th, gr, er, jacobian ? 1.0 : 0.0, lane);
+        else v = wave_eval_nb<KS, NS, OM, NB>(P, g, smem, th, gr, er, jacobian ? 1.0 : 0.0, lane);
         if (grad) {
 #pragma unroll
             for (int u = 0; u < NJ; ++u) if (ok[u]) grad[(size_t)b * g.D + jx[u]] = gr[u];

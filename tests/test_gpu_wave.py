@@ -263,3 +263,67 @@ def test_tail_of_a_large_run_of_an_outlier_model_moves_to_the_wave_kernel(monkey
     assert np.mean(err < 1e-6) > 0.9, np.mean(err < 1e-6)
     assert [x['n_leapfrog'] for x in g1[:50]] == [x['n_leapfrog'] for x in g0[:50]]
     prob.close()
+
+
+# ---- several distributions (wave_eval_nb, bdrt_wave_nb.hip) ---------------------------------------------------------------------------------
+MULTI = ['series_parallel', 'series_parallel_outliers', 'kat_2parallel']        # (two blocks, two blocks + outlier model = BASELINE config 5's, three blocks)
+
+
+def _multi(name):
+    from bayes_drt_amd.model import Problem
+    from oracle import oracle as orc
+    from tests.test_gpu_solo_wide import _family
+    args = _family(name)
+    return Problem(**args), orc.OracleModel(**args)
+
+
+@pytest.mark.parametrize('name', MULTI)
+def test_wave_evaluator_of_the_multi_distribution_models_matches_oracle(name):
+    """Series-Parallel (two blocks, +- the outlier model: BASELINE config 5's model) and Series-2Parallel (three blocks) on the lane
+    mapping of the one-chain-per-wave kernel: lp and gradient against the oracle and the tile evaluator."""
+    prob, om = _multi(name)
+    rng = np.random.default_rng(9)
+    theta = rng.uniform(-2, 2, (24, prob.D))
+    for jac in (True, False):
+        lp, g = _wave_logp_grad(prob, theta, jac)
+        lp16, g16 = prob.logp_grad(theta, jacobian=jac)
+        for i in range(0, len(theta), 4):
+            lp_ref, g_ref = om.logp_grad(theta[i], jac)
+            if not np.isfinite(lp_ref):
+                assert not np.isfinite(lp[i])                # (x_sum_raw < 0: rejected point)
+                continue
+            assert abs(lp[i] - lp_ref) <= 1e-10 * max(1.0, abs(lp_ref)), (i, lp[i], lp_ref)
+            assert np.max(np.abs(g[i] - g_ref)) <= 1e-10 * max(1.0, np.max(np.abs(g_ref))), (i, np.max(np.abs(g[i] - g_ref)))
+        fin = np.isfinite(lp16)
+        assert np.array_equal(fin, np.isfinite(lp))
+        assert np.allclose(lp[fin], lp16[fin], rtol=1e-11, atol=1e-9) and np.allclose(g[fin], g16[fin], rtol=1e-9, atol=1e-9)
+    prob.close()
+
+
+@pytest.mark.parametrize('name', ['series_parallel', 'series_parallel_outliers', 'kat_2parallel'])
+def test_wave_nuts_of_the_multi_distribution_models_matches_oracle_and_the_16_chain_kernel(name):
+    from bayes_drt_amd.engine import Sampler, sample_units
+    from oracle import oracle as orc
+    prob, om = _multi(name)
+    ctrl = _ctrl(prob._lib, max_treedepth=5)
+    warm, nd = 12, 5
+    with _env(BDRT_WAVE='1', BDRT_SOLO=None, BDRT_WIDE1=None):
+        with Sampler(prob, 3, warm, nd, 77, ctrl) as smp:
+            assert smp.kind() == 3
+            smp.run()
+            draws, lp, diag = smp.results()
+    with _env(BDRT_WAVE='0', BDRT_SOLO='0', BDRT_WIDE1='0'):
+        d16, lp16, dg16 = sample_units(prob, 3, warm, nd, 77, ctrl)
+    octrl = orc.nuts_control(max_treedepth=5)
+    for c in range(3):
+        ref, lpr, dr = orc.nuts_sample(om, c, 77, warm, nd, control=octrl)
+        assert dr['n_leapfrog'] == diag[c]['n_leapfrog'] == dg16[c]['n_leapfrog'], (c, dr, diag[c], dg16[c])
+        assert dr['n_divergent'] == diag[c]['n_divergent']
+        assert np.max(np.abs(draws[c] - ref)) < 1e-6 * np.max(np.abs(ref)), c
+        assert np.max(np.abs(draws[c] - d16[c])) < 1e-6 * np.max(np.abs(ref)), c
+    with _env(BDRT_WAVE=None, BDRT_SOLO=None, BDRT_WIDE1=None):
+        with Sampler(prob, 3, 2, 2, 77, ctrl) as few:
+            assert few.kind() == 2                           # up to one chain per CU: the general one-chain kernel
+        with Sampler(prob, 400, 2, 2, 77, ctrl) as mid:
+            assert mid.kind() == 3                           # from there to four per CU: one chain per wave
+    prob.close()
