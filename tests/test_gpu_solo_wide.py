@@ -123,15 +123,19 @@ def test_few_chains_take_the_one_chain_kernel_and_equal_the_16_chain_kernel(fami
     prob.close()
 
 
-def test_tail_of_a_large_run_of_a_general_model_moves_to_the_one_chain_kernel(monkeypatch):
-    """More than 2.75 chains per CU of the config 5 model start on the 16-chain kernel; `bdrt_sampler_run` hands the last live
-    chains to the kernel of bdrt_solo_wide.h.  The run equals the one without the hand-over chain by chain."""
+@pytest.mark.parametrize('wave', [False, True])
+def test_tail_of_a_large_run_of_a_general_model_moves_to_the_one_chain_kernels(wave, monkeypatch):
+    """A large run of the config 5 model starts on the 16-chain kernel; `bdrt_sampler_run` hands the last live chains to a one-chain
+    kernel: the one-chain-per-wave kernel (<= four chains per CU, round 5) or -- without it, BDRT_WAVE=0 -- the kernel of
+    bdrt_solo_wide.h (<= 2.75 per CU).  The run equals the one without the hand-over chain by chain."""
     from bayes_drt_amd.engine import Sampler
     from bayes_drt_amd.model import Problem
     from bayes_drt_amd._lib import NutsControl
+    if not wave:
+        monkeypatch.setenv('BDRT_WAVE', '0')
     prob = Problem(**_family('series_parallel_outliers'))
     ctrl = NutsControl(); prob._lib.bdrt_nuts_defaults(C.byref(ctrl)); ctrl.max_treedepth = 5
-    n_units = 900
+    n_units = 1200 if wave else 900
 
     def run():
         with Sampler(prob, n_units, 16, 8, 3, ctrl) as smp:
@@ -140,11 +144,14 @@ def test_tail_of_a_large_run_of_a_general_model_moves_to_the_one_chain_kernel(mo
             return smp.results() + (kind0, smp.kind(), smp.tail_units())
 
     d1, lp1, g1, k0, k1, tail1 = run()
-    assert k0 == 0 and k1 == 2 and 0 < tail1 <= 704, (k0, k1, tail1)
+    assert k0 == 0 and k1 == (3 if wave else 2) and 0 < tail1 <= (1024 if wave else 704), (k0, k1, tail1)
     monkeypatch.setenv('BDRT_TAIL_MIGRATION', '0')
     d0, lp0, g0, k0b, k1b, tail0 = run()
     assert k1b == 0 and tail0 == 0
     assert np.all(np.isfinite(d1))
     err = np.max(np.abs(d1 - d0), axis=(1, 2)) / np.max(np.abs(d0))
-    assert np.mean(err < 1e-6) > 0.9, np.mean(err < 1e-6)
+    # (the chains that were handed over continue in another summation order: the longer the stretch on the other kernel -- the wave
+    #  kernel takes over at 1024 live chains, the workgroup kernel at 704 --, the more of them drift past 1e-6 in these 24 iterations)
+    assert np.mean(err < 1e-6) > (0.8 if wave else 0.9), np.mean(err < 1e-6)
+    assert np.median(err) < 1e-12
     prob.close()
