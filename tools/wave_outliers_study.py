@@ -1,6 +1,6 @@
 """Statistical check of the one-chain-per-wave kernel with the outlier error model in the shape it is used: a batch of spectra x 4 chains
 through Inverter.fit_many(outliers=True) at mid occupancy (100 noise realisations of the 2-ZARC spectrum x 4 chains = 400 units: the wave
-kernel by default), against the same call with BDRT_WAVE=0 (the 16-chain kernel for this many units).  Long chains are not expected to agree
+kernel by default), against the same call with BDRT_WAVE=0 (the general one-chain-per-workgroup kernel takes this many units then, in two turns).  Long chains are not expected to agree
 draw by draw (another summation order); the posterior means of the two runs agree within their Monte-Carlo error, which the difference
 between the two halves of the chains of ONE run measures.
 Usage: wave_outliers_study.py [n_spectra]"""
@@ -39,7 +39,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 res = {}
-for tag, env in (('default (one chain per wave)', {}), ('BDRT_WAVE=0 (16-chain kernel)', {'BDRT_WAVE': '0'})):
+for tag, env in (('default (one chain per wave)', {}), ('BDRT_WAVE=0 (general one-chain kernel)', {'BDRT_WAVE': '0'})):
     p = subprocess.run([sys.executable, __file__, 'child', str(n)], env=dict(os.environ, **env), capture_output=True, text=True)
     line = [l for l in p.stdout.splitlines() if l.startswith('{')]
     assert line, p.stderr[-2000:]
