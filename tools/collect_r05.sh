@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 measurement batch on the GPU box: everything DESIGN.md section 7 (round 4) quotes.  Writes gpurun_out/r05/.
-# Usage: tools/collect_r05.sh [part ...]   parts: bench trace sq wave soak map config5 hmc fuzz   (default: bench trace sq wave soak config5)
+# Usage: tools/collect_r05.sh [part ...]   parts: bench trace sq wave soak map config5 waveom hmc fuzz   (default: bench trace sq wave soak config5)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r05
@@ -106,6 +106,16 @@ PY
   done
   bash tools/profile_pmc.sh r05_c5 nuts_kernel tools/bench_config5.py 4096 > $OUT/config5_sq.log 2>&1
   grep -v "simple_timer\|amdgpu.ids" gpurun_out/pmc_r05_c5/summary.txt > $OUT/config5_sq.txt
+fi
+if has waveom; then
+  # the one-chain-per-wave kernel with the outlier models / several distributions against what those unit counts took before
+  for fam in --series-outliers ""; do
+    for n in 4 256 512 768 1024 1536; do
+      python tools/bench_config5.py $n $fam 2>&1 | grep -v amdgpu.ids | head -1
+      BDRT_WAVE=0 python tools/bench_config5.py $n $fam 2>&1 | grep -v amdgpu.ids | head -1 | sed "s/^/   BDRT_WAVE=0: /"
+    done
+  done > $OUT/wave_outliers_sweep.txt
+  python tools/wave_outliers_study.py 100 2>&1 | grep -v amdgpu.ids > $OUT/wave_outliers_study.txt
 fi
 if has hmc; then
   python tools/hmc_suite_many.py 2>&1 | grep -v amdgpu.ids > $OUT/hmc_suite_many.txt
