@@ -780,10 +780,14 @@ class Inverter:
     _NUTS_CONTROL = {'adapt_delta': 0.9, 'adapt_t0': 10}        # reference :1221
 
     def _fit_prepare(self, frequencies, Z, part, scale_Z, nonneg, outliers, init_from_ridge, ridge_kw, sigma_min,
-                     inductance_scale, outlier_lambda, mode, add_stan_data, model_str, fitY, SA, SASY, n_starts):
+                     inductance_scale, outlier_lambda, mode, add_stan_data, model_str, fitY, SA, SASY, n_starts,
+                     defer_ridge_start=False):
         """Everything `fit` does on the host before the engine runs (reference :1153-1214): initial values, matrices, model
         selection, the Stan data dict.  Sets the training attributes of this instance; returns the job description that
-        `fit` hands to one engine call and `fit_many` to one batched call for all spectra."""
+        `fit` hands to one engine call and `fit_many` to one batched call for all spectra.  `defer_ridge_start` (fit_many
+        only): the ridge starting point of a MAP fit is set up here and solved with the other spectra's in one launch
+        (`_resolve_deferred_ridge_starts`) -- an argument of this call, never a property of the instance, so that a later
+        `fit` on a view that `fit_many` returned solves its own ridge start."""
         _validate_spectrum(frequencies, Z)
         init = 'random'
         if init_from_ridge:
@@ -795,7 +799,7 @@ class Inverter:
         extra_inits = []
         if mode == 'optimize':
             extra_inits = self._map_extra_starts(n_starts, init_from_ridge, model_str, frequencies, Z, nonneg, outliers,
-                                                 inductance_scale, ridge_kw)
+                                                 inductance_scale, ridge_kw, defer_ridge_start)
         frequencies, Z_scaled, dist_mat, outliers = self._bayes_matrices(frequencies, Z, part, scale_Z, outliers,
                                                                          init_from_ridge, ridge_kw)
         if model_str is None:
@@ -841,6 +845,11 @@ class Inverter:
 
         Arguments as `fit`.  Each spectrum is scaled and weighted exactly as `fit` does it, and the random streams depend on
         (random_seed, chain) only: the result of spectrum i equals that of a separate `fit` call (same draws, same MAP).
+        `frequencies` is one grid for all spectra or a list with one grid per spectrum (the reference's truncated-spectrum
+        study, Run fits.ipynb cells 13-14: spectra of 53 and 91 frequencies through one loop); `sigma_min`, `nonneg`, `outliers`,
+        `inductance_scale` and `outlier_lambda` take one value or a list with one per spectrum (the same study: sigma_min = 0.005
+        for the noiseless spectrum, 0.002 otherwise).  Spectra that share grid, basis, model and options are one batch -- one
+        problem in HBM, one engine call --, the others further batches of the same call; the list comes back in input order.
         Returns a list of Inverter objects (shallow copies of this one) carrying the fit attributes of `fit`, readable
         through `predict_*`, `coef_percentile`, ...; this instance itself is left as it was."""
         self._fit_argument_checks(part, mode, False, False, False, n_starts, algorithm)
@@ -848,31 +857,75 @@ class Inverter:
                                        inductance_scale, outlier_lambda, mode, add_stan_data, model_str, n_starts)
         if not views:
             return []
-        # spectra that resolve to the same model (outliers='auto' may choose differently per spectrum) share a batch
+        # one engine call per group of spectra that share everything but Z: the model (outliers='auto' may choose differently per
+        # spectrum), the frequency grid and basis (hence the matrices) and every Stan data entry the options decide; results stay
+        # in input order
         order = {}
         for i, job in enumerate(jobs):
-            order.setdefault(job['model_str'], []).append(i)
-        for name, idx in order.items():
+            order.setdefault(self._batch_key(job), []).append(i)
+        for idx in order.values():
             self._fit_batch([views[i] for i in idx], [jobs[i] for i in idx], mode, random_seed, max_iter, warmup, samples,
                             chains, algorithm, group)
         for inv, job in zip(views, jobs):
-            inv._fit_finish(job, mode, sigma_min, check_outliers)
+            inv._fit_finish(job, mode, job['sigma_min'], check_outliers)
         return views
+
+    @staticmethod
+    def _batch_key(job):
+        """Spectra with equal keys share one problem in HBM: the model file, the frequency grid (hence, on this instance's basis,
+        the matrices) and the options that enter the Stan data apart from 'Z' (`_stack_stan_data` verifies the entries)."""
+        return job['batch_key']
+
+    @staticmethod
+    def _per_spectrum(value, n, name):
+        """An option of `fit_many` given once (every spectrum) or as a list / array of one value per spectrum."""
+        if isinstance(value, (list, tuple, np.ndarray)):
+            if len(value) != n:
+                raise ValueError('fit_many: %s has %d entries for %d spectra' % (name, len(value), n))
+            return list(value)
+        return [value] * n
 
     def _batch_jobs(self, frequencies, Z_list, part, scale_Z, nonneg, outliers, init_from_ridge, ridge_kw, sigma_min,
                     inductance_scale, outlier_lambda, mode, add_stan_data, model_str, n_starts):
-        """`_fit_prepare` for every spectrum of a batch, each on a shallow copy of this instance (the copies share the matrix
-        cache of the common grid: nothing is built twice).  Returns (views, jobs)."""
+        """`_fit_prepare` for every spectrum of a batch, each on a shallow copy of this instance.  The copies of one frequency
+        grid share a matrix cache (nothing is built twice); every grid has a cache of its own, seeded from this instance's and
+        detached from it, so that neither this instance nor the views of another grid ever see matrices of a grid they were
+        not built for.  `frequencies`: one grid for all spectra, or a list with one grid per spectrum; `sigma_min`, `nonneg`,
+        `outliers`, `inductance_scale`, `outlier_lambda`: one value, or a list with one per spectrum.  Returns (views, jobs)."""
         import copy
-        views, jobs = [], []
-        base = self
-        for Z in Z_list:
-            inv = copy.copy(base)
-            inv._defer_ridge_start = mode == 'optimize'
-            job = inv._fit_prepare(frequencies, np.asarray(Z), part, scale_Z, nonneg, outliers, init_from_ridge, ridge_kw, sigma_min,
-                                   inductance_scale, outlier_lambda, mode, add_stan_data, model_str, False, False, False, n_starts)
+        Z_list = [np.asarray(Z) for Z in Z_list]
+        n = len(Z_list)
+        per_grid = isinstance(frequencies, (list, tuple)) and n > 0 and len(frequencies) == n and \
+            all(np.ndim(f) == 1 for f in frequencies)
+        if isinstance(frequencies, np.ndarray) and frequencies.ndim == 2:
+            per_grid = True
+            if len(frequencies) != n:
+                raise ValueError('fit_many: %d frequency grids for %d spectra' % (len(frequencies), n))
+        freqs = [np.asarray(f, dtype=float) for f in frequencies] if per_grid else [frequencies] * n
+        opt = {k: self._per_spectrum(v, n, k) for k, v in (('sigma_min', sigma_min), ('nonneg', nonneg), ('outliers', outliers),
+                                                          ('inductance_scale', inductance_scale),
+                                                          ('outlier_lambda', outlier_lambda))}
+        views, jobs, last_of_grid = [], [], {}
+        for i, (f, Z) in enumerate(zip(freqs, Z_list)):
+            fa = np.asarray(f, dtype=float)
+            key = rel_round(np.sort(fa)[::-1], 10).tobytes() if fa.ndim == 1 and len(fa) > 1 and np.all(np.isfinite(fa)) and \
+                np.all(fa > 0) else None
+            base = last_of_grid.get(key)
+            if base is None:
+                inv = copy.copy(self)
+                inv.distribution_matrices = {name: dict(st, **({'_penalty': dict(st['_penalty'])} if '_penalty' in st else {}))
+                                             for name, st in self.distribution_matrices.items()}
+            else:
+                inv = copy.copy(base)
+            job = inv._fit_prepare(f, Z, part, scale_Z, opt['nonneg'][i], opt['outliers'][i], init_from_ridge, ridge_kw,
+                                   opt['sigma_min'][i], opt['inductance_scale'][i], opt['outlier_lambda'][i], mode, add_stan_data,
+                                   model_str, False, False, False, n_starts, defer_ridge_start=(mode == 'optimize'))
+            job['sigma_min'] = opt['sigma_min'][i]
+            job['batch_key'] = (job['model_str'], key, repr(opt['sigma_min'][i]), repr(opt['inductance_scale'][i]),
+                                repr(opt['outlier_lambda'][i]))
             views.append(inv); jobs.append(job)
-            base = inv
+            if key is not None:
+                last_of_grid[key] = inv
         return views, jobs
 
     @staticmethod
@@ -881,11 +934,10 @@ class Inverter:
         d0 = jobs[0]['dat']
         for job in jobs[1:]:
             if set(job['dat']) != set(d0):
-                raise ValueError('fit_many: the spectra do not share one model')
+                raise ValueError('the spectra of one batch do not share one model')
             for k, v in job['dat'].items():
                 if k != 'Z' and not np.array_equal(np.asarray(v), np.asarray(d0[k])):
-                    raise ValueError('fit_many: the spectra do not share the Stan data entry %r (one frequency grid, one '
-                                     'basis and one set of options per call)' % k)
+                    raise ValueError('the spectra of one batch do not share the Stan data entry %r' % k)
         dat = dict(d0)
         dat['Z'] = np.vstack([np.asarray(job['dat']['Z'], dtype=float).reshape(1, -1) for job in jobs])
         return dat
@@ -896,8 +948,8 @@ class Inverter:
         and weighted as `fit` does it (reference :1153-1214).  For callers that drive the engine themselves (bench.py)."""
         _, jobs = self._batch_jobs(frequencies, Z_list, part, scale_Z, nonneg, outliers, False, {}, sigma_min, inductance_scale,
                                    outlier_lambda, mode, add_stan_data, None, 1)
-        if len({job['model_str'] for job in jobs}) != 1:
-            raise ValueError('batch_stan_data: the spectra resolve to different models')
+        if len({self._batch_key(job) for job in jobs}) != 1:
+            raise ValueError('batch_stan_data: the spectra do not share one model, one grid and one set of options')
         return jobs[0]['model_str'], self._stack_stan_data(jobs)
 
     @staticmethod
@@ -1040,7 +1092,8 @@ class Inverter:
         if algorithm not in (None, 'LBFGS', 'LBFGS+Newton'):
             raise ValueError("algorithm must be None, 'LBFGS' or 'LBFGS+Newton'")
 
-    def _map_extra_starts(self, n_starts, init_from_ridge, model_str, frequencies, Z, nonneg, outliers, inductance_scale, ridge_kw):
+    def _map_extra_starts(self, n_starts, init_from_ridge, model_str, frequencies, Z, nonneg, outliers, inductance_scale, ridge_kw,
+                          defer_ridge_start=False):
         """Further MAP starting points next to the designated one (see `fit`).  The hierarchical posterior has poor local
         maxima -- everything explained as noise, or a huge Z_hat with a proportionally huge error -- that a single random
         start reaches on sparse or outlier-ridden spectra; the starts run as one batch in lock-step on the GPU, the
@@ -1062,7 +1115,7 @@ class Inverter:
                 #  the full ridge solve -- 19 ms at K = 81, 57 ms at K = 161, one workgroup -- was 40 % of the whole MAP fit)
                 with warnings.catch_warnings():
                     warnings.simplefilter('ignore')
-                    if getattr(self, '_defer_ridge_start', False) and not ridge_kw and not outliers and \
+                    if defer_ridge_start and not ridge_kw and not outliers and \
                             not os.environ.get('BDRT_HOST_LAMBDA_LOOP'):
                         # fit_many: set the ridge problem up now, solve it with the other spectra's in ONE launch of bdrt_ridge
                         # right before the batch of MAP fits starts (`_resolve_deferred_ridge_starts`); same arguments as the
@@ -1332,29 +1385,38 @@ class Inverter:
             fb = 1 / (2 * np.pi * tau)
             # (the penalty matrices depend on the basis grid only: kept with the A matrices while the grid stands -- a batch of
             # spectra on one grid, `fit_many`, builds them once)
-            pen_cached = (not self._recalc_mat) and store.get('_penalty') == (penalty, self.basis, float(epsilon), len(tau),
-                                                                             float(tau[0]), float(tau[-1]))
-            if pen_cached:
-                for k_ in (('M0', 'M1', 'M2') if penalty == 'integral' else ('L0', 'L1', 'L2') if penalty == 'discrete' else
-                           ('M0', 'M1', 'M2', 'L0', 'L1', 'L2')):
-                    dist_mat[name][k_] = store[k_]
-            elif penalty == 'integral':
-                for o in (0, 1, 2):
-                    dist_mat[name]['M%d' % o] = construct_M(fb, basis=self.basis, order=o, epsilon=epsilon)
-            elif penalty == 'discrete':
-                for o in (0, 1, 2):
-                    dist_mat[name]['L%d' % o] = construct_L(fb, tau=tau, basis=self.basis, epsilon=epsilon, order=o)
-            elif penalty == 'cholesky':
-                # M = L^T L with L upper triangular, so that x^T M x = ||L x||^2 (reference :2309-2317)
-                from scipy.linalg import cholesky
-                for o in (0, 1, 2):
-                    M = construct_M(fb, basis=self.basis, order=o, epsilon=epsilon)
-                    dist_mat[name]['M%d' % o] = M
-                    dist_mat[name]['L%d' % o] = cholesky(M)
-            else:
+            pen_key = (self.basis, float(epsilon), len(tau), float(tau[0]), float(tau[-1]))
+            pen_names = {'integral': ('M0', 'M1', 'M2'), 'discrete': ('L0', 'L1', 'L2'),
+                         'cholesky': ('M0', 'M1', 'M2', 'L0', 'L1', 'L2')}
+            if penalty not in pen_names:
                 raise ValueError(f'Invalid penalty argument {penalty}. Options are integral, discrete, and cholesky')
-            store.update(dist_mat[name])
-            store['_penalty'] = (penalty, self.basis, float(epsilon), len(tau), float(tau[0]), float(tau[-1]))
+            if self._recalc_mat:
+                store.pop('_penalty', None)
+            # one cache entry per penalty kind (a MAP batch alternates 'integral' -- its ridge start -- and 'discrete'); the
+            # arrays are handed out as copies, like A_re / A_im, so that nothing downstream can edit the store of all views
+            cache = store.setdefault('_penalty', {})
+            hit = cache.get(penalty)
+            if hit is not None and hit[0] == pen_key:
+                mats = hit[1]
+            else:
+                mats = {}
+                if penalty == 'integral':
+                    for o in (0, 1, 2):
+                        mats['M%d' % o] = construct_M(fb, basis=self.basis, order=o, epsilon=epsilon)
+                elif penalty == 'discrete':
+                    for o in (0, 1, 2):
+                        mats['L%d' % o] = construct_L(fb, tau=tau, basis=self.basis, epsilon=epsilon, order=o)
+                else:
+                    # M = L^T L with L upper triangular, so that x^T M x = ||L x||^2 (reference :2309-2317)
+                    from scipy.linalg import cholesky
+                    for o in (0, 1, 2):
+                        M = construct_M(fb, basis=self.basis, order=o, epsilon=epsilon)
+                        mats['M%d' % o] = M
+                        mats['L%d' % o] = cholesky(M)
+                cache[penalty] = (pen_key, mats)
+            for k_ in pen_names[penalty]:
+                dist_mat[name][k_] = mats[k_].copy()
+            store.update(mats)
             dist_mat[name].update({'A_re': A_re, 'A_im': A_im, 'WA_re': W_re @ A_re, 'WA_im': W_im @ A_im, 'B': B})
         self._recalc_mat = False
         self._cached_distributions = self.distributions.copy()

@@ -277,6 +277,16 @@ def sample_sharded(problem_kwargs, n_spectra, chains, warmup, n_draws, seed=1234
                 init_theta = np.ascontiguousarray(np.asarray(init_theta, dtype=np.float64))
                 if init_theta.ndim != 2 or init_theta.shape[0] != n_spectra * chains:
                     raise ValueError('sample_sharded: init_theta must be [n_spectra * chains, D]')
+                # the width is checked HERE too: a wrong one would only surface inside `worker.run` on the ranks that own
+                # units, while ranks without units wait in the gathers (layout of include/bdrt.h: 2 offsets, x per block,
+                # 4 error parameters, 2 Nf outlier parameters, ups per block, 3 penalty strengths per block)
+                n_blk = int(flat0['n_blocks'])
+                D0 = 6 + sum(2 * flat0['b%d_A' % b].shape[1] + 3 for b in range(n_blk))
+                if int(np.asarray(flat0.get('kw_outlier_mode', 0))):
+                    D0 += Zfull.shape[1]
+                if init_theta.shape[1] != D0:
+                    raise ValueError('sample_sharded: init_theta has %d columns, the model has D = %d parameters'
+                                     % (init_theta.shape[1], D0))
             if whole:
                 flat0.pop('kw_Z')
                 flat0['Z_width'] = np.array(Zfull.shape[1])

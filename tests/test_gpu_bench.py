@@ -117,3 +117,24 @@ def test_bare_gpus_2_launches_its_own_ranks():
     env.pop('BDRT_BENCH_ONE_DEVICE')
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith('{')]
+
+
+@pytest.mark.timeout(1800)
+def test_bench_eight_ranks_on_the_one_device():
+    """`bench.py --gpus 8` under the driver's launcher with all eight ranks on the box's single GPU over gloo: the 8-way partition
+    of the weak-scaling job (8 spectra x 8 chains = 64 units per rank), the `strong_scaling` leg (the same 64 spectra in total: 64
+    units per rank, one chain per workgroup) and the sharded round trip over 8 ranks.  Bookkeeping, not a rate."""
+    env = dict(os.environ, BDRT_BENCH_ONE_DEVICE='1', BDRT_BENCH_ROUNDTRIP_TIMEOUT='600')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr',
+           '127.0.0.1', '--master-port', '29547', os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2',
+           '--warmup', '1', '--rounds', '30', '--no-cpu-baseline', '--spectra', '8']
+    d = _line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500))
+    c = d['config']
+    assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and 'test_mode' in c
+    assert c['ranks_seen'] == 8 and c['rccl']['device_ids'] == [0] * 8
+    assert c['units_per_gpu'] == 64 and c['evals_in_timed_region'] == 8 * 64 * 30 * 2
+    ss = c['strong_scaling']
+    assert '64 spectra' in ss['workload'] and '(64 units per GPU)' in ss['workload'] and ss['sampler_kind_rank0'] == 1
+    assert ss['value'] > 1e4 and ss['steps'] >= 2
+    rt = c['dist_roundtrip']
+    assert 'error' not in rt and rt['finite'] and rt['spectra'] == 64

@@ -140,3 +140,77 @@ def test_fit_many_sharded_over_two_ranks_equals_one_process(mode):
                     assert np.array_equal(np.asarray(x), np.asarray(y))
                 else:
                     assert np.allclose(np.asarray(x), np.asarray(y), rtol=1e-9, atol=1e-12)
+
+
+def test_view_returned_by_fit_many_can_be_refitted():
+    """A view of fit_many(mode='optimize') is an ordinary Inverter: a later `fit` on it solves its own ridge starting point
+    (the deferral of the batch is an argument of the batch's prepare step, not a property left on the views)."""
+    from bayes_drt_amd.inversion import Inverter
+    f, zs = _spectra(2)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        views = Inverter(basis_freq=f).fit_many(f, zs, nonneg=True, mode='optimize')
+        coef = views[0].distribution_fits['DRT']['coef'].copy()
+        assert not hasattr(views[0], '_defer_ridge_start')
+        views[0].fit(f, zs[0], nonneg=True, mode='optimize')
+        assert len(views[0]._opt_report['starts']) == 2
+        assert np.allclose(views[0].distribution_fits['DRT']['coef'], coef, rtol=1e-9, atol=1e-12)
+        views[1].fit(f, zs[0], nonneg=True, mode='optimize')
+        assert np.allclose(views[1].distribution_fits['DRT']['coef'], coef, rtol=1e-9, atol=1e-12)
+
+
+def _truncated_study():
+    """The reference's truncated-spectrum study (code_EchemActa/Run fits.ipynb cells 12-14): spectra of 53 frequencies and the
+    full-range one of 91 on the basis of 81, sigma_min = 0.005 for the noiseless spectra and 0.002 otherwise."""
+    names = ['trunc_uniform_0.25', 'trunc_noiseless', 'trunc_noiseless_FullRange', 'trunc_Orazem_1.0', 'trunc_Macdonald_2.5']
+    fs, zs, sm = [], [], []
+    for n in names:
+        d = load('kat_' + n)
+        fs.append(np.array(d['data_freq'], dtype=float)); zs.append(np.array(d['data_Z']))
+        sm.append(0.005 if 'noiseless' in n else 0.002)
+    return names, fs, zs, sm
+
+
+@pytest.mark.parametrize('mode', ['optimize', 'sample'])
+def test_fit_many_over_mixed_grids_and_options_equals_separate_fit_calls(mode):
+    """One call for spectra of different lengths and options: grouped by (grid, basis, model, options), one batch per group,
+    results in input order and equal to the separate `fit` calls of the notebook's loop."""
+    from bayes_drt_amd.inversion import Inverter
+    names, fs, zs, sm = _truncated_study()
+    assert sorted({len(f) for f in fs}) == [53, 91]
+    kw = dict(mode='optimize') if mode == 'optimize' else dict(mode='sample', warmup=30, samples=20, chains=2, random_seed=11)
+    basis = np.logspace(6, -2, 81)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        base = Inverter(basis_freq=basis)
+        views = base.fit_many(fs, zs, sigma_min=sm, nonneg=False, **kw)
+        assert len(views) == len(names) and np.array_equal(np.atleast_1d(base.f_train), np.atleast_1d(Inverter(basis_freq=basis).f_train))
+        for f, Z, s, v in zip(fs, zs, sm, views):
+            one = Inverter(basis_freq=basis)
+            one.fit(f, Z, sigma_min=s, nonneg=False, **kw)
+            assert len(v.f_train) == len(f) and v._stan_input['sigma_min'] == s
+            if mode == 'sample':
+                assert np.array_equal(v._sample_result.theta, one._sample_result.theta)
+                assert np.array_equal(v.predict_distribution('DRT', eval_tau=TAU_PLOT, percentile=97.5),
+                                      one.predict_distribution('DRT', eval_tau=TAU_PLOT, percentile=97.5))
+            else:
+                assert v._opt_report['start'] == one._opt_report['start']
+                assert np.allclose(v.distribution_fits['DRT']['coef'], one.distribution_fits['DRT']['coef'], rtol=1e-8, atol=1e-11)
+            assert np.allclose(v.predict_Z(f), one.predict_Z(f), rtol=1e-8)
+            assert np.allclose(v.error_fit['sigma_min'], one.error_fit['sigma_min'])
+
+
+def test_fit_many_leaves_a_fitted_instance_and_its_matrix_cache_alone():
+    """`fit_many` on another grid must not leave matrices of that grid in the cache of the instance it was called on."""
+    from bayes_drt_amd.inversion import Inverter
+    f, zs = _spectra(1)
+    _, fs, zt, _ = _truncated_study()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        inv = Inverter(basis_freq=f)
+        inv.fit(f, zs[0], nonneg=True, mode='optimize')
+        A0 = inv.distribution_matrices['DRT']['A_re'].copy()
+        zhat = inv.predict_Z(f)
+        inv.fit_many([fs[0]], [zt[0]], nonneg=True, mode='optimize', n_starts=1)
+        assert np.array_equal(inv.distribution_matrices['DRT']['A_re'], A0)
+        assert np.array_equal(inv.predict_Z(f), zhat)

@@ -64,36 +64,73 @@ def test_2rc_4x1000_run_matches_the_published_run_and_its_diagnostics():
 
 SUITE = ['2RC_Orazem_0.25', '2RC_uniform_1.0', '2ZARC_uniform_0.25', '2ZARC_Macdonald_1.0', 'Gerischer_noiseless',
          'Gerischer_uniform_0.25', 'Gerischer_Orazem_2.5', 'ZARC_Orazem_0.25', 'ZARC-RL_Macdonald_1.0', 'RC_uniform_0.25']
+STUDY_SEEDS = (1234, 1, 2, 3, 4)
+_STUDY = {}
+
+
+def _study_runs():
+    """The whole published study (60 spectra, Run fits.ipynb cell 5: 2 chains x (200 + 200), random init) once per seed of
+    STUDY_SEEDS, each seed ONE `Inverter.fit_many` call with per-spectrum option lists (nonneg is off for the ZARC-RL spectra,
+    sigma_min is 0.005 for the noiseless ones: four batches inside the call).  Cached for the module: the per-spectrum test and the
+    whole-study test read the same runs.  Returns dict(err [seed, spectrum, 3], sat / div [seed, spectrum], leap, wall [seed])."""
+    if _STUDY:
+        return _STUDY
+    import time
+    from bayes_drt_amd.inversion import Inverter
+    S = load('hmc_suite')
+    stems = [str(s_) for s_ in S['stems']]
+    f = S['Z'][0][:, 0]
+    assert all(np.array_equal(S['Z'][i][:, 0], f) for i in range(len(stems)))
+    Z = [S['Z'][i][:, 1] + 1j * S['Z'][i][:, 2] for i in range(len(stems))]
+    nonneg = [not s_.startswith('ZARC-RL') for s_ in stems]
+    smin = [0.005 if 'noiseless' in s_ else 0.002 for s_ in stems]
+    n = len(stems)
+    out = dict(err=np.zeros((len(STUDY_SEEDS), n, 3)), sat=np.zeros((len(STUDY_SEEDS), n), dtype=int), div=np.zeros((len(STUDY_SEEDS), n), dtype=int),
+               leap=np.zeros((len(STUDY_SEEDS), n), dtype=np.int64), wall=[], stems=stems)
+    for a, seed in enumerate(STUDY_SEEDS):
+        t0 = time.time()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            views = Inverter(basis_freq=f).fit_many(f, Z, nonneg=nonneg, sigma_min=smin, mode='sample', warmup=200, samples=200, chains=2,
+                                                    random_seed=seed)
+        out['wall'].append(time.time() - t0)
+        for i, v in enumerate(views):
+            fit, ref = v._sample_result, S['Gout_bayes'][i]
+            assert v.stan_model_name == ('Series_pos' if nonneg[i] else 'Series') + '_StanModel.pkl' and v._stan_input['sigma_min'] == smin[i]
+            out['err'][a, i] = [rel_l2(v.predict_distribution('DRT', eval_tau=TAU_PLOT), ref[:, 1])] + \
+                               [rel_l2(v.predict_distribution('DRT', eval_tau=TAU_PLOT, percentile=p_), ref[:, k_]) for p_, k_ in ((2.5, 2), (97.5, 3))]
+            out['sat'][a, i], out['div'][a, i], out['leap'][a, i] = fit.n_max_treedepth, fit.n_divergent, fit.n_leapfrog
+    _STUDY.update(out)
+    return _STUDY
 
 
 @pytest.mark.parametrize('stem', SUITE)
 def test_suite_spectrum_matches_stored_curves_and_saturation_class(stem):
-    """Run fits.ipynb cell 5 settings (2 chains x (200 + 200), random init, seed 1234).  Saturation is a per-chain outcome
-    (the reference's counts cluster at multiples of 200 = whole chains), so the CLASS is compared: spectra on which the
-    reference never saturated must not saturate here, spectra on which it (nearly) always did must do so in at least one
-    chain here."""
-    S = load('hmc_suite')
-    i = [str(s) for s in S['stems']].index(stem)
-    f, Z = S['Z'][i][:, 0], S['Z'][i][:, 1] + 1j * S['Z'][i][:, 2]
-    ref, d = S['Gout_bayes'][i], S['diag'][i]
-    fit, g, lo, hi = _fit(f, Z, stem, 2, 200, 200)
-    e = rel_l2(g, ref[:, 1]), rel_l2(lo, ref[:, 2]), rel_l2(hi, ref[:, 3])
-    print('%s: gamma mean %.4f lo %.4f hi %.4f; saturated %d (reference %d) divergent %d (reference %d)'
-          % ((stem,) + e + (fit.n_max_treedepth, int(d[0]), fit.n_divergent, int(d[1]))))
-    # 400 draws on either side: over the study's 60 spectra and five seeds the mean curve's error has median 1.6 %, 90th percentile
-    # 3-4 %, two to four spectra per run above 4 % (largest 5.9 %); the 97.5 % curve's: median 4 %, 90th percentile 7-9 %, two to
-    # four per run above 10 % (profiles/r05/hmc_suite_seeds.txt).  Which spectra a run puts in its tail changes with any change of
-    # rounding in the kernels, so the bands are those of the tail.
-    assert e[0] <= 0.06, e
-    assert e[2] <= 0.15, e
+    """Run fits.ipynb cell 5 settings (2 chains x (200 + 200), random init).  Saturation is a per-chain outcome (the reference's
+    counts cluster at multiples of 200 = whole chains), so the CLASS is compared: spectra on which the reference never saturated
+    must not saturate here, spectra on which it (nearly) always did must do so in at least one chain here.
+
+    Asserted on the MEDIAN over the five seeds of STUDY_SEEDS, like the 4 x 1000 run above: with 400 draws on either side a single
+    run puts two to ten of the 60 spectra in the tail of its error distribution, and which ones changes with the seed and with any
+    change of rounding in the kernels (profiles/r06/divergence_study.txt: twelve seeds; seed 1 freezes a chain on ten spectra).
+    The per-spectrum median is stable, and the bands are those of round 4 again: posterior mean <= 4 %, 97.5 % curve <= 10 %
+    (the reference's own run-to-run scatter is 0.8 % / 1.8 % between a 2 x 200 and a 4 x 500 run)."""
+    S, R = load('hmc_suite'), _study_runs()
+    i = R['stems'].index(stem)
+    d = S['diag'][i]
+    e = np.median(R['err'][:, i], axis=0)
+    sat, div = R['sat'][:, i], R['div'][:, i]
+    print('%s over seeds %s: gamma mean %s (median %.4f), 97.5 %% curve %s (median %.4f); saturated %s (reference %d), divergent %s (reference %d)'
+          % (stem, list(STUDY_SEEDS), np.round(R['err'][:, i, 0], 4).tolist(), e[0], np.round(R['err'][:, i, 2], 4).tolist(), e[2],
+             sat.tolist(), int(d[0]), div.tolist(), int(d[1])))
+    assert np.all(R['leap'][:, i] >= 1023 * sat)                   # a saturated iteration is 1023 leapfrogs
+    assert e[0] <= 0.04, R['err'][:, i]
+    assert e[2] <= 0.10, R['err'][:, i]
     if d[0] <= 5:
-        # (a saturated chain is 200: below half a chain.  A run whose warm-up ends on small step sizes saturates a few dozen
-        # iterations -- 48 for seed 1234 of 2RC_uniform_1.0 since round 5's change of summation order in the one-chain kernel,
-        # 0 - 6 for nine other seeds, 3 - 4 for seed 1234 before: profiles/r05/seeds_2RC_uniform_1.0.txt)
-        assert fit.n_max_treedepth <= 100, (fit.n_max_treedepth, d[0])
+        assert np.median(sat) <= 40, (sat, d[0])                    # (a saturated chain is 200)
     if d[0] >= 380:
-        assert fit.n_max_treedepth >= 190, (fit.n_max_treedepth, d[0])
-    assert fit.n_divergent <= 20
+        assert np.median(sat) >= 190, (sat, d[0])
+    assert np.median(div) <= 20, div
 
 
 RC_FAMILY = [('RC_Macdonald_0.25', 200, None), ('RC_Orazem_0.25', 174, 0.01), ('RC_noiseless', 200, 0.01), ('RC_uniform_0.25', 200, 0.01)]
@@ -300,50 +337,32 @@ def test_other_families_match_the_published_hmc_curves(stem, model, bounds):
     assert fit.n_divergent <= 20
 
 
-def test_the_whole_published_study_in_three_fit_many_calls():
-    """All 60 spectra of Run fits.ipynb cell 5 on the CURRENT binary (the per-spectrum tests above cover 14 of them): the spectra
-    that share their options are one `Inverter.fit_many` batch (45 + 5 + 9 + 1; the notebook: 60 `fit` calls of 32-180 s each).
-    Per spectrum: posterior mean within 4 % of the stored curve (RC_Macdonald_0.25: see the mixture test), the saturation CLASS of
-    the reference, few divergent iterations; in total: saturated iterations in the reference's range (3035 of 24 000 there; ours
-    2400-3000 depending on which chains freeze), wall time of the whole study."""
-    import time
-    from bayes_drt_amd.inversion import Inverter
-    S = load('hmc_suite')
-    stems = [str(s_) for s_ in S['stems']]
-    f = S['Z'][0][:, 0]
-    groups = {}
-    for i, stem in enumerate(stems):
-        assert np.array_equal(S['Z'][i][:, 0], f)
-        groups.setdefault((not stem.startswith('ZARC-RL'), 0.005 if 'noiseless' in stem else 0.002), []).append(i)
-    assert sorted(len(v) for v in groups.values()) == [1, 5, 9, 45]
-    views = {}
-    t0 = time.time()
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        for (nonneg, smin), idx in groups.items():
-            out = Inverter(basis_freq=f).fit_many(f, [S['Z'][i][:, 1] + 1j * S['Z'][i][:, 2] for i in idx], nonneg=nonneg, mode='sample',
-                                                  warmup=200, samples=200, chains=2, sigma_min=smin)
-            views.update(zip(idx, out))
-    wall = time.time() - t0
-    sat = div = 0
+def test_the_whole_published_study_one_fit_many_call_per_seed():
+    """All 60 spectra of Run fits.ipynb cell 5 on the CURRENT binary, five seeds (`_study_runs`; the notebook: 60 `fit` calls of
+    32-180 s each, here one `fit_many` call of ~8 s per seed).  Per spectrum, on the MEDIAN over the seeds: posterior mean within
+    4 % of the stored curve (RC_Macdonald_0.25: see the mixture test), the saturation CLASS of the reference, few divergent
+    iterations -- at most 3 of the 60 spectra outside.  In total (median over the seeds): saturated iterations in the reference's
+    range (3035 of 24 000 there), divergent iterations of its order (15 there; ours 8 ... 144 over twelve seeds, median 37:
+    profiles/r06/divergence_study.txt), the wall time of a whole study."""
+    S, R = load('hmc_suite'), _study_runs()
+    stems = R['stems']
+    e = np.median(R['err'][:, :, 0], axis=0)
+    sat, div = np.median(R['sat'], axis=0), np.median(R['div'], axis=0)
     bad = []
     for i, stem in enumerate(stems):
-        v, ref, d = views[i], S['Gout_bayes'][i], S['diag'][i]
-        fit = v._sample_result
-        e = rel_l2(v.predict_distribution('DRT', eval_tau=TAU_PLOT), ref[:, 1])
-        sat += fit.n_max_treedepth; div += fit.n_divergent
-        assert fit.n_leapfrog >= 1023 * fit.n_max_treedepth
-        ok = (e <= 0.04 or stem == 'RC_Macdonald_0.25') and fit.n_divergent <= 20
+        d = S['diag'][i]
+        ok = (e[i] <= 0.04 or stem == 'RC_Macdonald_0.25') and div[i] <= 20
         if d[0] <= 5:
-            ok = ok and fit.n_max_treedepth <= 200          # (at most one chain frozen where the reference had none)
+            ok = ok and sat[i] <= 200          # (at most one chain frozen where the reference had none)
         if d[0] >= 380:
-            ok = ok and fit.n_max_treedepth >= 190
+            ok = ok and sat[i] >= 190
         if not ok:
-            bad.append((stem, round(e, 4), fit.n_max_treedepth, int(d[0]), fit.n_divergent))
-    print('published HMC study, 60 spectra in %d fit_many calls: %.1f s; saturated %d (reference %d of 24000), divergent %d (reference %d); outside the bands: %s'
-          % (len(groups), wall, sat, int(S['diag'][:, 0].sum()), div, int(S['diag'][:, 1].sum()), bad))
-    # (2 x 200 draws against 2 x 200: two to four spectra per run sit above 4 %, another one or two draw a chain that diverges
-    # in a few dozen iterations -- five seeds in profiles/r05/hmc_suite_seeds.txt, 4 of 60 in round 3's record of 60 fit calls)
-    assert len(bad) <= 5, bad
-    assert 1800 <= sat <= 3800 and div <= 80
-    assert wall <= 30.0
+            bad.append((stem, round(float(e[i]), 4), int(sat[i]), int(d[0]), int(div[i])))
+    tot_sat, tot_div = R['sat'].sum(axis=1), R['div'].sum(axis=1)
+    print('published HMC study, 60 spectra, seeds %s: %s s per study; saturated %s (reference %d of 24000), divergent %s (reference %d); '
+          'spectra above 4 %% per seed %s; outside the bands on the per-spectrum median: %s'
+          % (list(STUDY_SEEDS), np.round(R['wall'], 1).tolist(), tot_sat.tolist(), int(S['diag'][:, 0].sum()), tot_div.tolist(),
+             int(S['diag'][:, 1].sum()), (R['err'][:, :, 0] > 0.04).sum(axis=1).tolist(), bad))
+    assert len(bad) <= 3, bad
+    assert 1800 <= np.median(tot_sat) <= 3800 and np.median(tot_div) <= 80
+    assert min(R['wall']) <= 30.0

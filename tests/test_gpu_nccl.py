@@ -107,3 +107,13 @@ def test_the_same_rank_program_on_one_device_over_gloo(tmp_path):
     got = _run_ranks('gloo', 2, tmp_path)
     assert [int(i) for i in got['device_ids']] == [0, 0]
     _check_against_direct_run(got, 2)
+
+
+@pytest.mark.timeout(1800)
+def test_the_same_rank_program_with_eight_ranks_on_one_device_over_gloo(tmp_path):
+    """World size 8 -- the size of the node the driver scales to -- on the 1-GPU box: 5 spectra x 2 chains and 1 spectrum x 4
+    chains leave ranks with one unit or none (idle ranks must walk through every collective), `fit_many` shards 3 spectra
+    (6 units, 6 MAP rows) over 8 ranks.  Same assertions as with two ranks: everything equals one direct run."""
+    got = _run_ranks('gloo', 8, tmp_path)
+    assert [int(i) for i in got['device_ids']] == [0] * 8
+    _check_against_direct_run(got, 8)

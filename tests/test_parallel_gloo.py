@@ -256,3 +256,35 @@ def test_a_bad_argument_on_rank_0_fails_on_every_rank_instead_of_hanging():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert set(got) == {0, 1} and all('Z has 3 spectra' in m for m in got.values())
+
+
+def _worker_bad_width(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        pk = _problem(1) if rank == 0 else None
+        it = np.zeros((2, 2 * 4 + 9 + 1)) if rank == 0 else None      # one column too many
+        try:
+            par.sample_sharded(pk, 1, 2, 5, 4, seed=11, worker_cls=FakeWorker, init_theta=it)
+            q.put((rank, 'no error'))
+        except ValueError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_start_points_of_the_wrong_width_fail_on_every_rank_including_the_idle_one():
+    """the width of `init_theta` was only checked inside `worker.run`, i.e. on ranks that own units; a rank without
+    units (one spectrum x 2 chains on 3 ranks) went on into the gathers and waited for the process-group timeout."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bad_width, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert set(got) == {0, 1, 2} and all('18 columns' in m and 'D = 17' in m for m in got.values()), got
