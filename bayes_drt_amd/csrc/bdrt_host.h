@@ -111,6 +111,9 @@ int post_percentiles_device(const double *dX, int rows, int K, long ldx, const d
 int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fits, int max_iter, double tol, double *x_out,
                          double *lp_out, double *ginf_out, int *iters_out, int *rc_out, int *n_evals_out);
 
+// closed-form Hessian at one point (bdrt_newton_hess.h; tests): 1 when the problem has none
+int hessian_at_point(Problem &P, const double *theta, int spec, double *H_out);
+
 }  // namespace bdrt
 
 struct bdrt_problem {

@@ -173,4 +173,12 @@ int bdrt_optimize(bdrt_problem *p, const double *init_theta, const int *spec, in
     return 0;
 }
 
+// closed-form Hessian of the log-posterior (no Jacobian) at one unconstrained point, as the Newton iteration uses it (tests):
+// H_out [D x D] row-major; returns 1 when the model has no closed form here (the iteration then differences gradients)
+int bdrt_debug_hessian(bdrt_problem *p, const double *theta, int spec, double *H_out)
+{
+    if (!p || !theta || !H_out || spec < 0 || spec >= p->impl.dev.n_spectra) { set_error("bdrt_debug_hessian: bad arguments"); return -1; }
+    return hessian_at_point(p->impl, theta, spec, H_out);
+}
+
 }  // extern "C"

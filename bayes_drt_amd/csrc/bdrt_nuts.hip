@@ -520,8 +520,11 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
 // the reference accepts any grid (inversion.py:2127-2209).  State layout: that of nuts_wide1_kernel.
 // ---------------------------------------------------------------------------------------------------------------------------
 // NJX: elements of a parameter vector per thread of the cooperative stage, D <= 512 NJX (2: D <= 1024; 4: D <= 2048 -- three
-// distributions of 301 basis functions are 1821 parameters).  The stage's LDS scratch holds the D momentum normals behind its
-// 512 doubles of reduction scratch.
+// distributions of 301 basis functions are 1821 parameters; 8 and 16: D <= 4096 / 8192, one distribution of 1200 basis functions
+// is 2409 -- these two keep most of the stage's rows in scratch memory: the streamed path is the slow path either way).  The
+// stage's LDS scratch holds the D momentum normals behind its 512 doubles of reduction scratch.
+constexpr int BIG_MAX_D = 8192;
+__host__ __device__ inline int big_njx(int D) { return D <= 1024 ? 2 : (D <= 2048 ? 4 : (D <= 4096 ? 8 : 16)); }
 __host__ __device__ inline int big_scratch_doubles(int njx) { return njx <= 2 ? W1_SCRATCH : 512 + 512 * njx + 64; }
 __host__ __device__ inline size_t nuts_big_lds_bytes(int njx = 2) { return (size_t)(big_scratch_doubles(njx) + 2 + 9 * 8) * sizeof(double) + sizeof(ChainState) + 128; }
 
@@ -1025,16 +1028,16 @@ bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec,
         S.nhot1 = wide1_hot_rows(S.geom1, ds1);
         S.lds_bytes = std::max(S.lds_bytes, wide1_lds_bytes(S.geom1, ds1, S.nhot1));     // (one attribute value for every kernel)
     }
-    if (S.big) S.lds_bytes = nuts_big_lds_bytes(S.D <= 1024 ? 2 : 4);
+    if (S.big) S.lds_bytes = nuts_big_lds_bytes(big_njx(S.D));
     auto fail = [&](const char *msg) -> bdrt_sampler * { set_error("%s", msg); bdrt_sampler_destroy(s); return nullptr; };
     if (S.lds_bytes > 160 * 1024) return fail("bdrt_sampler_create: problem too large for the 160 KiB LDS budget");
     for (int u = 0; u < n_units; ++u)
         if (spec && (spec[u] < 0 || spec[u] >= P.dev.n_spectra)) return fail("bdrt_sampler_create: spectrum index out of range");
 
     // row stride of the state vectors = 32*NJ of the kernel instantiation; the solo kernel keeps [unit][row][ds] with one column
-    const int DS = S.solo ? S.geom.DSS : (S.use_s1 ? 32 * s1_nj(S.D) : (S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : (S.D <= 32 * 27 ? 32 * 27 : (S.D <= 1024 ? 1024 : 2048)))));
-    if (S.D > (S.big ? 2048 : 32 * 27)) {
-        set_error("bdrt_sampler_create: D = %d > %d not supported", S.D, S.big ? 2048 : 864); bdrt_sampler_destroy(s); return nullptr;
+    const int DS = S.solo ? S.geom.DSS : (S.use_s1 ? 32 * s1_nj(S.D) : (S.D <= 32 * 11 ? 32 * 11 : (S.D <= 32 * 16 ? 32 * 16 : (S.D <= 32 * 27 ? 32 * 27 : 512 * big_njx(S.D)))));
+    if (S.D > (S.big ? BIG_MAX_D : 32 * 27)) {
+        set_error("bdrt_sampler_create: D = %d > %d not supported", S.D, S.big ? BIG_MAX_D : 864); bdrt_sampler_destroy(s); return nullptr;
     }
     S.args.ds = DS;
     const int ncol = (S.solo || S.wide1) ? 1 : NC, nrow = S.solo ? (int)SG_COUNT : (int)V_COUNT;
@@ -1200,8 +1203,12 @@ int bdrt_sampler_advance(bdrt_sampler *s, int rounds, int *all_done)
         } while (0)
         if (S.big && S.D <= 1024)
             hipLaunchKernelGGL(nuts_big_kernel<2>, dim3(S.n_wg), dim3(SOLO_NT), nuts_big_lds_bytes(2), S.stream, dp, S.np, S.args);
-        else if (S.big)
+        else if (S.big && S.D <= 2048)
             hipLaunchKernelGGL(nuts_big_kernel<4>, dim3(S.n_wg), dim3(SOLO_NT), nuts_big_lds_bytes(4), S.stream, dp, S.np, S.args);
+        else if (S.big && S.D <= 4096)
+            hipLaunchKernelGGL(nuts_big_kernel<8>, dim3(S.n_wg), dim3(SOLO_NT), nuts_big_lds_bytes(8), S.stream, dp, S.np, S.args);
+        else if (S.big)
+            hipLaunchKernelGGL(nuts_big_kernel<16>, dim3(S.n_wg), dim3(SOLO_NT), nuts_big_lds_bytes(16), S.stream, dp, S.np, S.args);
         else if (S.wide1 && S.args.prof)
             hipLaunchKernelGGL(nuts_wide1_kernel<true>, dim3(S.n_wg), dim3(SOLO_NT), wide1_lds_bytes(S.geom1, S.args.ds, S.nhot1), S.stream, dp,
                                S.np, S.args, S.geom1, S.nhot1);
@@ -1665,22 +1672,29 @@ int bdrt_debug_wide1_logp_grad(bdrt_problem *p, const double *theta, const int *
 int bdrt_debug_leaf_joins(const double *lsw_sub, const double *w, const double *u, int n, double *lsw_dev, int *join_dev, double *lsw_ref,
                           int *join_ref, double *prob_ref)
 {
-    if (!lsw_sub || !w || !u || n < 1) { set_error("bdrt_debug_leaf_joins: bad arguments"); return -1; }
+    if (!lsw_sub || !w || !u || !lsw_dev || !join_dev || !lsw_ref || !join_ref || !prob_ref || n < 1) {
+        set_error("bdrt_debug_leaf_joins: bad arguments"); return -1;
+    }
+    // every device buffer is owned by this list: an error path frees what was allocated before it (the pattern of newton_polish_device)
+    std::vector<void *> owned;
+    auto cleanup = [&]() { for (void *q : owned) hipFree(q); };
+#define LJ_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return -10; } } while (0)
     double *d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int *di[2] = {nullptr, nullptr};
-    for (auto &q : d) BDRT_HIP(hipMalloc((void **)&q, (size_t)n * sizeof(double)));
-    for (auto &q : di) BDRT_HIP(hipMalloc((void **)&q, (size_t)n * sizeof(int)));
-    BDRT_HIP(hipMemcpy(d[0], lsw_sub, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    BDRT_HIP(hipMemcpy(d[1], w, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    BDRT_HIP(hipMemcpy(d[2], u, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    for (auto &q : d) { LJ_HIP(hipMalloc((void **)&q, (size_t)n * sizeof(double))); owned.push_back(q); }
+    for (auto &q : di) { LJ_HIP(hipMalloc((void **)&q, (size_t)n * sizeof(int))); owned.push_back(q); }
+    LJ_HIP(hipMemcpy(d[0], lsw_sub, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    LJ_HIP(hipMemcpy(d[1], w, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    LJ_HIP(hipMemcpy(d[2], u, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(leaf_joins_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d[0], d[1], d[2], n, d[3], di[0], d[4], di[1], d[5]);
-    BDRT_HIP(hipMemcpy(lsw_dev, d[3], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    BDRT_HIP(hipMemcpy(join_dev, di[0], (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    BDRT_HIP(hipMemcpy(lsw_ref, d[4], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    BDRT_HIP(hipMemcpy(join_ref, di[1], (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    BDRT_HIP(hipMemcpy(prob_ref, d[5], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    for (auto q : d) hipFree(q);
-    for (auto q : di) hipFree(q);
+    LJ_HIP(hipGetLastError());
+    LJ_HIP(hipMemcpy(lsw_dev, d[3], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    LJ_HIP(hipMemcpy(join_dev, di[0], (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    LJ_HIP(hipMemcpy(lsw_ref, d[4], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    LJ_HIP(hipMemcpy(join_ref, di[1], (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    LJ_HIP(hipMemcpy(prob_ref, d[5], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+#undef LJ_HIP
+    cleanup();
     return 0;
 }
 

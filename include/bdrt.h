@@ -187,8 +187,8 @@ typedef struct bdrt_sampler bdrt_sampler;
 /* n_units chains; unit u samples spectrum spec[u] (NULL: 0) with RNG stream (seed, chain_id[u]) (NULL: u);
  * init_theta [n_units x D] or NULL (random U(-r,r), retried until finite).
  * Size limits (NULL + bdrt_last_error beyond them): D <= 864 parameters for problems on the LDS-resident evaluators
- * (bdrt_problem_evaluator 0..4: twenty-seven elements per lane of a chain's half-wave), D <= 2048 for problems on the streamed
- * evaluator (code 5: every row in HBM, four elements per thread of the cooperative stage).  Stan has no limit
+ * (bdrt_problem_evaluator 0..4: twenty-seven elements per lane of a chain's half-wave), D <= 8192 for problems on the streamed
+ * evaluator (code 5: every row in HBM, up to sixteen elements per thread of the cooperative stage).  Stan has no limit
  * (reference bayes_drt/inversion.py:2127-2209); evaluation and MAP have none here either. */
 bdrt_sampler *bdrt_sampler_create(bdrt_problem *p, int n_units, const int *spec, const int *chain_id, int warmup,
                                   int n_draws, uint64_t seed, const double *init_theta, const bdrt_nuts_control *ctrl);

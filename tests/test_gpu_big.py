@@ -185,3 +185,26 @@ def test_sampler_beyond_1024_parameters_on_the_streamed_path():
         assert dr['n_leapfrog'] == diag[c]['n_leapfrog'], (c, dr, diag[c])
         assert np.max(np.abs(draws[c] - ref)) < 1e-6 * np.max(np.abs(ref)), c
     prob.close()
+
+
+@pytest.mark.parametrize('K,D', [(1200, 2409), (2100, 4209)])
+def test_sampler_beyond_2048_parameters_on_the_streamed_path(K, D):
+    """Round 6: the streamed path's sampler takes D <= 8192 (nuts_big_kernel<8> / <16>: eight / sixteen elements per thread of the
+    cooperative stage; 2048 until round 5) -- one distribution of 1200 basis functions is 2409 parameters, of 2100 it is 4209.
+    A short NUTS run equal to the oracle's, draw by draw."""
+    from bayes_drt_amd._lib import NutsControl
+    from bayes_drt_amd.engine import Sampler
+    from oracle import oracle as orc
+    prob, om, _ = _big_problem(nf=100, K=K)
+    assert prob.evaluator() == 5 and prob.D == D
+    ctrl = NutsControl(); prob._lib.bdrt_nuts_defaults(C.byref(ctrl)); ctrl.max_treedepth = 4
+    with Sampler(prob, 2, 6, 3, 1234, ctrl) as smp:
+        assert smp.kind() == 4
+        smp.run()
+        draws, lp, diag = smp.results()
+    octrl = orc.nuts_control(max_treedepth=4)
+    for c in range(2):
+        ref, lpr, dr = orc.nuts_sample(om, c, 1234, 6, 3, control=octrl)
+        assert dr['n_leapfrog'] == diag[c]['n_leapfrog'], (c, dr, diag[c])
+        assert np.max(np.abs(draws[c] - ref)) < 1e-6 * np.max(np.abs(ref)), c
+    prob.close()
