@@ -632,6 +632,18 @@ def main():
                                'passes need rocprofv3 around the process' % (pj.get('source', 'rocprofv3 --pmc passes'), args.rounds))
             except Exception:
                 traffic = None
+        # measured busy fraction of the fp64 pipe ((MFMA busy cycles + 4 x VALU instructions) / SIMD cycles) from the committed SQ-counter
+        # passes of this command (profiles/sq_counters.json, tools/profile_sq.sh + tools/make_sq_json.py): like `traffic`, PMC counters
+        # need rocprofv3 around the process, so the figure is that run's, labelled as such
+        pipe_busy, pipe_src, mfma_busy = None, None, None
+        sqj = os.path.join(ROOT, 'profiles', 'sq_counters.json')
+        if os.path.exists(sqj) and n_units == N_SPECTRA * CHAINS_PER_SPECTRUM:
+            try:
+                sj = json.load(open(sqj))
+                pipe_busy, mfma_busy = sj.get('pipe_busy'), sj.get('mfma_busy_frac')
+                pipe_src = '%s: launch %.3f ms there, %.3f ms here; not collected in this run' % (sj.get('source'), sj.get('avg_launch_ms', 0.0), avg_ms)
+            except Exception:
+                pipe_busy = None
         line = {
             'metric': 'HMC log-posterior+grad evals/sec (81 freq x 161 tau-basis)',
             'value': value, 'unit': 'evals/s', 'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
@@ -663,6 +675,7 @@ def main():
                          'mfma_flop_per_eval': mfma_flop,
                          'mfma_pipe_frac': achieved * mfma_flop / FLOP_PER_EVAL / PEAK_F64_MFMA_TFLOPS,
                          'traffic_source': traffic_src,
+                         'pipe_busy': pipe_busy, 'mfma_busy': mfma_busy, 'pipe_busy_measured': False, 'pipe_busy_source': pipe_src,
                          'executed_tflops_structured_path': achieved * flop_executed / FLOP_PER_EVAL},
         }
         if one_device:
