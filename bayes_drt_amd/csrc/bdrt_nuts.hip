@@ -77,7 +77,7 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
 
     // the chain's scalar state lives in LDS; every thread keeps its hot part in registers (identical updates)
     ChainState *cold = reinterpret_cast<ChainState *>(smem + g.o_state);
-    if (tid == 0) *cold = a.states[unit];
+    if (tid == 0) chain_state_copy(*cold, a.states[unit]);          // (member by member: a struct assignment goes through scratch)
 #pragma unroll 7
     for (int v = 0; v < SV_COUNT; ++v) {
         if (TRIM && solo_hot_slot(v) < 0) continue;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
     // one workgroup per CU: the whole state in registers (256 VGPRs to spend); two per CU: the hot part only
     typedef typename std::conditional<WPE == 2, ChainState, SoloHot>::type State;
     State s;
-    if constexpr (WPE == 2) s = *cold; else s.from(*cold);
+    if constexpr (WPE == 2) chain_state_copy(s, *cold); else s.from(*cold);
     const Philox rng = {np.seed_lo, np.seed_hi, (uint32_t)cold->chain_id};
     const SoloEvalRegs er = solo_eval_setup(P, g, cold->spec, tid);
     double *TH = row(SV_TH), *Pm = row(SV_P), *G = row(SV_G), *MI = row(SV_MINV);
@@ -98,12 +98,13 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
     auto with_full_state = [&](auto fn) {
         if constexpr (WPE == 2) return fn(s);
         else {
-            ChainState full = *cold;
+            ChainState full;
+            chain_state_copy(full, *cold);
             s.to(full);
             const int r = fn(full);
             s.from(full);
             __syncthreads();
-            if (tid == 0) *cold = full;
+            if (tid == 0) chain_state_copy(*cold, full);
             __syncthreads();
             return r;
         }
@@ -370,9 +371,10 @@ __global__ __launch_bounds__(SOLO_NT, WPE) void nuts_solo_kernel(const DevProble
     for (int v = 0; v < SV_COUNT; ++v)
         if (own && !(TRIM && solo_hot_slot(v) < 0)) Vg[(size_t)v * DS + j] = row(v)[j];
     if (tid == 0) {
-        ChainState full = *cold;
+        ChainState full;
+        chain_state_copy(full, *cold);
         if constexpr (WPE == 2) { const int k = full.kicked; full = s; full.kicked = k; } else s.to(full);
-        a.states[unit] = full;
+        chain_state_copy(a.states[unit], full);
         if (my_leaps) atomicAdd(a.leap_counter, my_leaps);
         const int ph = s.phase;
         if (!(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)) atomicAdd(a.done_counter, 1);
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
     double *V = a.vecs + (size_t)wg * V_COUNT * DS;       // this chain's rows [V_COUNT][ds]
     auto grow = [&](int v) -> double * { return V + (size_t)v * DS; };                                    // the row in HBM
     auto row = [&](int v) -> double * { const int h = hslot[v]; return h >= 0 ? hot + (size_t)h * DS : grow(v); };
-    if (tid == 0) sts[0] = a.states[unit];
+    if (tid == 0) chain_state_copy(sts[0], a.states[unit]);
     if (tid < V_COUNT) {
         int h = -1;
         for (int k = 0; k < nhot; ++k) if (W1_HOT_ORDER[k] == tid) h = k;
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_wide1_kernel(const DevProblem *_
         for (int j = tid; j < DS; j += SOLO_NT) dst[j] = hot[(size_t)k * DS + j];
     }
     if (tid == 0) {
-        a.states[unit] = sts[0];
+        chain_state_copy(a.states[unit], sts[0]);
         if (my_leaps) atomicAdd(a.leap_counter, my_leaps);
         const int ph = sts[0].phase;
         if (!(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)) atomicAdd(a.done_counter, 1);
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_big_kernel(const DevProblem *__r
     double *V = a.vecs + (size_t)wg * V_COUNT * DS;       // this chain's rows [V_COUNT][ds]
     double *ws = a.bigws + (size_t)wg * big_ws_doubles(P);
     auto row = [&](int v) -> double * { return V + (size_t)v * DS; };
-    if (tid == 0) sts[0] = a.states[unit];
+    if (tid == 0) chain_state_copy(sts[0], a.states[unit]);
     if (tid < V_COUNT) hslot[tid] = (signed char)-1;
     __syncthreads();
     const int spec = sts[0].spec;
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(SOLO_NT) void nuts_big_kernel(const DevProblem *__r
         __syncthreads();
     }
     if (tid == 0) {
-        a.states[unit] = sts[0];
+        chain_state_copy(a.states[unit], sts[0]);
         if (my_leaps) atomicAdd(a.leap_counter, my_leaps);
         const int ph = sts[0].phase;
         if (!(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)) atomicAdd(a.done_counter, 1);

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
     if (TA && MODE == 2) s1_toep_init(P, smem);
     if (tid < NC) {
         const int u = su[col_slot(tid)];
-        if (u >= 0) sts[tid] = a.states[u];
+        if (u >= 0) chain_state_copy(sts[tid], a.states[u]);      // (member by member: a struct assignment goes through scratch)
         else { memset(&sts[tid], 0, sizeof(ChainState)); sts[tid].phase = PH_DONE; }
         spec[tid] = u >= 0 ? sts[tid].spec : 0;
         thoff[tid] = (SPEC && sts[tid].thsel) ? TH2OFF : 0;
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(NT) void nuts_kernel(const DevProblem *__restrict__
             for (int m = 0; m < NJ; ++m) { const int j = l32 + 32 * m; Pm[j] = pr_[m]; }
         }
     }
-    if (l32 == 0 && valid) a.states[unit] = s;
+    if (l32 == 0 && valid) chain_state_copy(a.states[unit], s);
     {
         unsigned long long x = my_leaps;      // non-zero only in lane 0 of each half-wave
         x += __shfl_xor(x, 32);

@@ -145,6 +145,22 @@ struct ChainState {
     long long n_leap_total;
 };
 
+// member-by-member copy: `a = b` on this 200-byte struct between LDS / global memory and a local is lowered to a block copy through a
+// private (scratch) buffer that the optimiser does not split afterwards -- the 112 bytes of scratch every one-chain-per-wave kernel
+// carried in round 5.  (Template: source and destination keep their address spaces.)
+template <class DST, class SRC>
+__host__ __device__ inline void chain_state_copy(DST &d, const SRC &s)
+{
+    d.phase = s.phase; d.iter = s.iter; d.depth = s.depth; d.leaf = s.leaf; d.nleaves = s.nleaves; d.dir = s.dir;
+    d.init_attempt = s.init_attempt; d.eps_dir = s.eps_dir; d.eps_trials = s.eps_trials; d.n_leap_iter = s.n_leap_iter;
+    d.da_counter = s.da_counter; d.win_counter = s.win_counter; d.win_size = s.win_size; d.next_window = s.next_window; d.win_n = s.win_n;
+    d.init_buffer = s.init_buffer; d.term_buffer = s.term_buffer; d.base_window = s.base_window;
+    d.n_div = s.n_div; d.n_maxdepth = s.n_maxdepth; d.n_post = s.n_post; d.spec = s.spec; d.chain_id = s.chain_id;
+    d.kicked = s.kicked; d.z_iter = s.z_iter; d.thsel = s.thsel;
+    d.eps = s.eps; d.H0 = s.H0; d.lsw = s.lsw; d.lsw_sub = s.lsw_sub; d.lps = s.lps; d.lpq = s.lpq; d.sum_metro = s.sum_metro;
+    d.da_sbar = s.da_sbar; d.da_xbar = s.da_xbar; d.da_mu = s.da_mu; d.sum_accept = s.sum_accept; d.n_leap_total = s.n_leap_total;
+}
+
 struct NutsParams {
     int warmup, n_draws, max_depth;
     double delta, gamma, t0, kappa, init_radius, max_deltaH, stepsize0;

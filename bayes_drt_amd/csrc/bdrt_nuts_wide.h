@@ -94,7 +94,8 @@ __device__ inline void wide_coop_tail(const WideCtx &x, int hc, bool c_done, uns
     const int D = x.D, DS = x.DS;
     long long tw_ = (x.prof && tid == 0) ? clock64() : 0;
 #define BDRT_WIDE_PROF(slot) do { if (x.prof && tid == 0) { const long long t_ = clock64(); x.prof[slot] += t_ - tw_; tw_ = t_; } } while (0)
-    ChainState s = x.sts[hc];
+    ChainState s;
+    chain_state_copy(s, x.sts[hc]);                    // (member by member: a struct assignment goes through scratch)
     const Philox rng = {np.seed_lo, np.seed_hi, (uint32_t)s.chain_id};
     auto row = [&](int v) -> double * {
         if constexpr (HOT) { const int h = x.hot_slot[v]; if (h >= 0) return x.hot_base + (size_t)h * DS; }
@@ -423,7 +424,7 @@ __device__ inline void wide_coop_tail(const WideCtx &x, int hc, bool c_done, uns
     }
     // every thread holds the same new state; the rows written above are read next by the evaluator / the chain's own lanes
     // after the round barrier
-    if (tid == 0) x.sts[hc] = s;
+    if (tid == 0) chain_state_copy(x.sts[hc], s);
     BDRT_WIDE_PROF(14);
     if (x.prof && tid == 0) x.prof[15] += 1;
 #undef BDRT_WIDE_PROF

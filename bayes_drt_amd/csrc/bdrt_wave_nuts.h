@@ -68,7 +68,7 @@ __global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : 2) void nuts_wave_kerne
 
     // the chain's scalar state lives in LDS; the lanes keep its hot part in registers (identical updates)
     ChainState *cold = reinterpret_cast<ChainState *>(smem + g.o_state);
-    if (lane == 0) *cold = a.states[unit];
+    if (lane == 0) chain_state_copy(*cold, a.states[unit]);         // (member by member: a struct assignment goes through scratch)
     wave_eval_init(P, g, smem, lane);
     for (int v = 0; v < SV_COUNT; ++v) {                   // LDS-resident rows: copied in once
         const int r = wave_hot_rank(v);
@@ -86,12 +86,13 @@ __global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : 2) void nuts_wave_kerne
     for (int u = 0; u < NJ; ++u) mi[u] = ok[u] ? mi[u] : 1.0;
 
     auto with_full_state = [&](auto fn) {
-        ChainState full = *cold;
+        ChainState full;
+        chain_state_copy(full, *cold);
         s.to(full);
         const int r = fn(full);
         s.from(full);
         wv_sync();
-        if (lane == 0) *cold = full;
+        if (lane == 0) chain_state_copy(*cold, full);
         wv_sync();
         return r;
     };
@@ -388,9 +389,10 @@ __global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : 2) void nuts_wave_kerne
         for (int j = lane; j < D; j += WV_NT) Vg[(size_t)v * DS + j] = hot[(size_t)r * g.DSS + j];
     }
     if (lane == 0) {
-        ChainState full = *cold;
+        ChainState full;
+        chain_state_copy(full, *cold);
         s.to(full);
-        a.states[unit] = full;
+        chain_state_copy(a.states[unit], full);
         if (my_leaps) atomicAdd(a.leap_counter, my_leaps);
         const int ph = s.phase;
         if (!(ph == PH_INIT || ph == PH_EPS || ph == PH_TREE)) atomicAdd(a.done_counter, 1);
