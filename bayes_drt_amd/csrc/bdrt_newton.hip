@@ -490,12 +490,25 @@ __global__ __launch_bounds__(256) void newton_accept_kernel(NewtonBufs b, const 
     double *x = b.x + (size_t)f * D, *g = b.g + (size_t)f * D;
     if (tid == 0) { s_acc = 0; s_t = 0; S.n_evals += NW_TRY; }
     __syncthreads();
+    const bool lin = b.analytic && S.lin;
+    const double floor_x = lin ? b.hws[(size_t)f * b.hl_total + b.hl_floor] : 0.0;
     for (int t = 0; t < NW_TRY; ++t) {
         const double *gt = b.gt + ((size_t)a * NW_TRY + t) * D;
+        const double *xs_t = trial + ((size_t)a * NW_TRY + t) * D;
         const double lpn = lp_t[a * NW_TRY + t];
         int fin = isfinite(lpn) ? 1 : 0;
         double gi = 0.0;
-        for (int j = tid; j < D; j += 256) { const double v = gt[j]; if (!isfinite(v)) fin = 0; gi = fmax(gi, fabs(v)); }
+        for (int j = tid; j < D; j += 256) {
+            double v = gt[j];
+            if (!isfinite(v)) fin = 0;
+            // a coefficient on the linear scale that sits at its floor passes |g_y| = x |g_x| < tol whatever g_x is: there the test is
+            // the bound's own condition, g_x <= 0 (a positive g_x, scaled by the largest coefficient, counts as gradient)
+            if (lin && j >= b.o_x && j < b.o_x + b.Kx) {
+                const double xj = exp(xs_t[j]);
+                if (xj <= 4.0 * floor_x && v > 0.0) v = v / xj * (1e14 * floor_x);
+            }
+            gi = fmax(gi, fabs(v));
+        }
         fin = __syncthreads_and(fin);
         red[tid] = gi;
         __syncthreads();
