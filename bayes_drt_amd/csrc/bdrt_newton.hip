@@ -674,6 +674,7 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
     // fits that are done; a fit that keeps its Hessian after a rejected trial skips the probe writes and ignores the probe
     // gradients), so several rounds are enqueued back to back and the host reads the status records once per group.
     const char *rp_env = getenv("BDRT_NEWTON_ROUNDS");
+    const char *trace_env = getenv("BDRT_NEWTON_TRACE");      // 1: the status records of the first eight fits at every host synchronisation, on stderr
     const int rounds_per_sync = std::max(1, rp_env ? atoi(rp_env) : 4);
     const long long max_rounds = (long long)max_iter * 40 + 100;
     for (long long round = 0; round < max_rounds; round += rounds_per_sync) {
@@ -681,6 +682,10 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
         NW_HIP(hipStreamSynchronize(st));
         int n_active = 0;
         for (int i = 0; i < n_fits; ++i) if (!hst[i].done) hact[n_active++] = i;
+        if (trace_env && trace_env[0] == '1')
+            for (int i = 0; i < n_fits && i < 8; ++i)
+                fprintf(stderr, "[bdrt newton trace] round %lld fit %d spec %d: lp %.12g lam %.3g |g| %.3g iters %d done %d rc %d lin %d\n", round, i, hspec[i],
+                        hst[i].lp, hst[i].lam, hst[i].grad_inf, hst[i].iters, hst[i].done, hst[i].rc, hst[i].lin);
         if (n_active == 0) break;
         NW_HIP(hipMemcpyAsync(d_active, hact.data(), (size_t)n_active * sizeof(int), hipMemcpyHostToDevice, st));
         if (!b.analytic) hspecp.resize((size_t)n_active * 2 * D);
