@@ -38,9 +38,10 @@ struct WaveGeom {
     int nb;                   // blocks (distributions) of the model: a generator table each
     int XL;                   // halo-padded K-row
     int DSS;                  // row stride of the D-vectors (as bdrt_solo.h)
-    int o_xs, o_us, o_w, o_gen, o_zp, o_gz, o_state, o_hot, total0;      // LDS offsets (doubles); total0: without hot rows
+    int o_xs, o_us, o_w, o_gen, o_zp, o_gz, o_tc, o_state, o_hot, total0;      // LDS offsets (doubles); total0: without hot rows
 };
 
+constexpr int WV_TCL = 3 * 16 + 8;            // doubles of one block's band-coefficient table in LDS (one batch of over-read behind it)
 constexpr int WV_MAXPARTS = 8;            // m-parts of the forward product at most
 
 __host__ __device__ inline WaveGeom wave_geometry(int nf, int K, int D, int nb = 1)
@@ -60,7 +61,7 @@ __host__ __device__ inline WaveGeom wave_geometry(int nf, int K, int D, int nb =
     g.S = mx + 16;
     const int nmax = g.R4 > g.NLP + 16 ? g.R4 : g.NLP + 16;
     g.GQ = (g.S + nmax + 8) / 4 + 2;
-    g.KZ = g.NP * g.ML + 4;
+    g.KZ = g.NP * g.ML + 8;                                  // (the pipelined products request one iteration -- eight steps -- beyond the end)
     const int kmax = K > g.KZ ? K : g.KZ;
     g.XL = (2 * MAXBW + kmax + 8) & ~1;
     g.DSS = (D + 7) & ~7;
@@ -71,7 +72,8 @@ __host__ __device__ inline WaveGeom wave_geometry(int nf, int K, int D, int nb =
     g.o_gen = o; o += nb * 2 * 4 * g.GQ;
     const int zp = g.NP * 2 * g.R4, gk = 2 * g.KP;
     g.o_zp = o; o += ((zp > gk ? zp : gk) + 1) & ~1;
-    g.o_gz = o; o += 2 * g.NLP + 8;
+    g.o_gz = o; o += 2 * g.NLP + 16;
+    g.o_tc = o; o += nb * WV_TCL;          // band coefficients of L0, L1, L2, rows of 16 (taps 13..15 zero): the one-wave-per-SIMD instantiations read them here
     g.o_state = o; o += (int)((sizeof(ChainState) + 15) / 16) * 2 + 2;
     g.o_hot = o;
     g.total0 = o;
@@ -237,6 +239,117 @@ __device__ __forceinline__ void wave_toep_bwd(const double *gen, int GQ, int E, 
 #undef BDRT_WV_BWD_BLOCK
 }
 
+// ---- the same products for ONE wave per SIMD (the OCC = 1 instantiations of wave_eval / nuts_wave_kernel) ------------------------------------------
+// With a second wave on the SIMD the LDS latency of a block's operands is the other wave's issue time; alone, the loop above exposes it
+// once per iteration (the scheduler batches the twelve reads at the top and the first FMA waits for them: ~230 of ~500 cycles).  Here
+// the operands of a whole iteration (eight steps) are requested one iteration ahead into a second register set; the loop is unrolled by
+// two so that the sets swap roles without moves.
+struct ToepFwdOps { double2 xa, xb, ya, yb; double n[4], m[4], p[4], q[4]; };
+// the generator elements of the first iteration and the initial windows: they do not depend on the point, so the evaluator requests them
+// before it computes the constrained parameters (their latency runs under the exponentials)
+struct ToepFwdPre { ToepPtr A, Bq; double a[4], b[4]; ToepFwdOps w; };
+__device__ __forceinline__ void toep_fwd_load_gen(const ToepPtr &A, const ToepPtr &Bq, ToepFwdOps &w, int t)
+{
+    const int o = -(t >> 2);
+    w.n[0] = BDRT_TE(A, -1, o); w.n[1] = BDRT_TE(A, -2, o); w.n[2] = BDRT_TE(A, -3, o); w.n[3] = BDRT_TE(A, -4, o);
+    w.m[0] = BDRT_TE(Bq, -1, o); w.m[1] = BDRT_TE(Bq, -2, o); w.m[2] = BDRT_TE(Bq, -3, o); w.m[3] = BDRT_TE(Bq, -4, o);
+    w.p[0] = BDRT_TE(A, -1, o - 1); w.p[1] = BDRT_TE(A, -2, o - 1); w.p[2] = BDRT_TE(A, -3, o - 1); w.p[3] = BDRT_TE(A, -4, o - 1);
+    w.q[0] = BDRT_TE(Bq, -1, o - 1); w.q[1] = BDRT_TE(Bq, -2, o - 1); w.q[2] = BDRT_TE(Bq, -3, o - 1); w.q[3] = BDRT_TE(Bq, -4, o - 1);
+}
+__device__ __forceinline__ ToepFwdPre wave_toep_fwd_pre(const double *genA, int GQ, int E)
+{
+    ToepFwdPre r;
+    r.A = toep_ptrs(genA, GQ, E); r.Bq = toep_ptrs(genA + 4 * GQ, GQ, E);
+    r.a[0] = BDRT_TE(r.A, 0, 0); r.a[1] = BDRT_TE(r.A, 1, 0); r.a[2] = BDRT_TE(r.A, 2, 0); r.a[3] = BDRT_TE(r.A, 3, 0);
+    r.b[0] = BDRT_TE(r.Bq, 0, 0); r.b[1] = BDRT_TE(r.Bq, 1, 0); r.b[2] = BDRT_TE(r.Bq, 2, 0); r.b[3] = BDRT_TE(r.Bq, 3, 0);
+    toep_fwd_load_gen(r.A, r.Bq, r.w, 0);
+    return r;
+}
+__device__ __forceinline__ void wave_toep_fwd_pipe(const ToepFwdPre &pre, const double *v, int len, double (&ar)[4], double (&ai)[4])
+{
+    const ToepPtr &A = pre.A, &Bq = pre.Bq;
+    double a0 = pre.a[0], a1 = pre.a[1], a2 = pre.a[2], a3 = pre.a[3];
+    double b0 = pre.b[0], b1 = pre.b[1], b2 = pre.b[2], b3 = pre.b[3];
+    auto loadx = [&](ToepFwdOps &w, int t) {
+        w.xa = *reinterpret_cast<const double2 *>(v + t); w.xb = *reinterpret_cast<const double2 *>(v + t + 2);
+        w.ya = *reinterpret_cast<const double2 *>(v + t + 4); w.yb = *reinterpret_cast<const double2 *>(v + t + 6);
+    };
+    auto load = [&](ToepFwdOps &w, int t) { loadx(w, t); toep_fwd_load_gen(A, Bq, w, t); };
+    auto block = [&](const double2 &xa, const double2 &xb, const double (&n)[4], const double (&m)[4]) {
+        ar[0] = fma(a0, xa.x, ar[0]); ar[1] = fma(a1, xa.x, ar[1]); ar[2] = fma(a2, xa.x, ar[2]); ar[3] = fma(a3, xa.x, ar[3]);
+        ai[0] = fma(b0, xa.x, ai[0]); ai[1] = fma(b1, xa.x, ai[1]); ai[2] = fma(b2, xa.x, ai[2]); ai[3] = fma(b3, xa.x, ai[3]);
+        ar[0] = fma(n[0], xa.y, ar[0]); ar[1] = fma(a0, xa.y, ar[1]); ar[2] = fma(a1, xa.y, ar[2]); ar[3] = fma(a2, xa.y, ar[3]);
+        ai[0] = fma(m[0], xa.y, ai[0]); ai[1] = fma(b0, xa.y, ai[1]); ai[2] = fma(b1, xa.y, ai[2]); ai[3] = fma(b2, xa.y, ai[3]);
+        ar[0] = fma(n[1], xb.x, ar[0]); ar[1] = fma(n[0], xb.x, ar[1]); ar[2] = fma(a0, xb.x, ar[2]); ar[3] = fma(a1, xb.x, ar[3]);
+        ai[0] = fma(m[1], xb.x, ai[0]); ai[1] = fma(m[0], xb.x, ai[1]); ai[2] = fma(b0, xb.x, ai[2]); ai[3] = fma(b1, xb.x, ai[3]);
+        ar[0] = fma(n[2], xb.y, ar[0]); ar[1] = fma(n[1], xb.y, ar[1]); ar[2] = fma(n[0], xb.y, ar[2]); ar[3] = fma(a0, xb.y, ar[3]);
+        ai[0] = fma(m[2], xb.y, ai[0]); ai[1] = fma(m[1], xb.y, ai[1]); ai[2] = fma(m[0], xb.y, ai[2]); ai[3] = fma(b0, xb.y, ai[3]);
+        a3 = n[0]; a2 = n[1]; a1 = n[2]; a0 = n[3];
+        b3 = m[0]; b2 = m[1]; b1 = m[2]; b0 = m[3];
+    };
+    auto compute = [&](const ToepFwdOps &w) { block(w.xa, w.xb, w.n, w.m); block(w.ya, w.yb, w.p, w.q); };
+    ToepFwdOps w0 = pre.w, w1;
+    loadx(w0, 0);
+    int t = 0;
+#pragma unroll 1
+    for (; t + 16 <= len; t += 16) {
+        load(w1, t + 8);
+        compute(w0);
+        load(w0, t + 16);
+        compute(w1);
+    }
+    if (t < len) compute(w0);
+}
+struct ToepBwdOps { double2 xa, xb, ya, yb; double n[4], p[4]; };
+struct ToepBwdPre { ToepPtr A; double w[6]; ToepBwdOps q; };
+__device__ __forceinline__ void toep_bwd_load_gen(const ToepPtr &A, ToepBwdOps &w, int t)
+{
+    const int o = t >> 2;
+    w.n[0] = BDRT_TE(A, 1, o); w.n[1] = BDRT_TE(A, 2, o); w.n[2] = BDRT_TE(A, 3, o); w.n[3] = BDRT_TE(A, 4, o);
+    w.p[0] = BDRT_TE(A, 1, o + 1); w.p[1] = BDRT_TE(A, 2, o + 1); w.p[2] = BDRT_TE(A, 3, o + 1); w.p[3] = BDRT_TE(A, 4, o + 1);
+}
+__device__ __forceinline__ ToepBwdPre wave_toep_bwd_pre(const double *gen, int GQ, int E)
+{
+    ToepBwdPre r;
+    r.A = toep_ptrs(gen, GQ, E);
+    r.w[0] = BDRT_TE(r.A, 0, 0); r.w[1] = BDRT_TE(r.A, -1, 0); r.w[2] = BDRT_TE(r.A, -2, 0); r.w[3] = BDRT_TE(r.A, -3, 0); r.w[4] = BDRT_TE(r.A, -4, 0); r.w[5] = BDRT_TE(r.A, -5, 0);
+    toep_bwd_load_gen(r.A, r.q, 0);
+    return r;
+}
+__device__ __forceinline__ void wave_toep_bwd_pipe(const ToepBwdPre &pre, const double *v, int len, double (&acc)[6])
+{
+    const ToepPtr &A = pre.A;
+    double w0 = pre.w[0], w1 = pre.w[1], w2 = pre.w[2], w3 = pre.w[3], w4 = pre.w[4], w5 = pre.w[5];
+    auto loadx = [&](ToepBwdOps &w, int t) {
+        w.xa = *reinterpret_cast<const double2 *>(v + t); w.xb = *reinterpret_cast<const double2 *>(v + t + 2);
+        w.ya = *reinterpret_cast<const double2 *>(v + t + 4); w.yb = *reinterpret_cast<const double2 *>(v + t + 6);
+    };
+    auto load = [&](ToepBwdOps &w, int t) { loadx(w, t); toep_bwd_load_gen(A, w, t); };
+    auto block = [&](const double2 &xa, const double2 &xb, const double (&n)[4]) {
+        acc[0] = fma(w0, xa.x, acc[0]); acc[1] = fma(w1, xa.x, acc[1]); acc[2] = fma(w2, xa.x, acc[2]);
+        acc[3] = fma(w3, xa.x, acc[3]); acc[4] = fma(w4, xa.x, acc[4]); acc[5] = fma(w5, xa.x, acc[5]);
+        acc[0] = fma(n[0], xa.y, acc[0]); acc[1] = fma(w0, xa.y, acc[1]); acc[2] = fma(w1, xa.y, acc[2]);
+        acc[3] = fma(w2, xa.y, acc[3]); acc[4] = fma(w3, xa.y, acc[4]); acc[5] = fma(w4, xa.y, acc[5]);
+        acc[0] = fma(n[1], xb.x, acc[0]); acc[1] = fma(n[0], xb.x, acc[1]); acc[2] = fma(w0, xb.x, acc[2]);
+        acc[3] = fma(w1, xb.x, acc[3]); acc[4] = fma(w2, xb.x, acc[4]); acc[5] = fma(w3, xb.x, acc[5]);
+        acc[0] = fma(n[2], xb.y, acc[0]); acc[1] = fma(n[1], xb.y, acc[1]); acc[2] = fma(n[0], xb.y, acc[2]);
+        acc[3] = fma(w0, xb.y, acc[3]); acc[4] = fma(w1, xb.y, acc[4]); acc[5] = fma(w2, xb.y, acc[5]);
+        w5 = w1; w4 = w0; w3 = n[0]; w2 = n[1]; w1 = n[2]; w0 = n[3];
+    };
+    auto compute = [&](const ToepBwdOps &w) { block(w.xa, w.xb, w.n); block(w.ya, w.yb, w.p); };
+    ToepBwdOps q0 = pre.q, q1;
+    loadx(q0, 0);
+    int t = 0;
+#pragma unroll 1
+    for (; t + 16 <= len; t += 16) {
+        load(q1, t + 8);
+        compute(q0);
+        load(q0, t + 16);
+        compute(q1);
+    }
+    if (t < len) compute(q0);
+}
+
 // per-launch constants of the evaluator held in registers: the measured spectrum at this lane's rows, its m-part of the forward
 // product.  (Re-reading the spectrum from L2 per evaluation instead -- twelve registers less across the products -- was measured:
 // the scheduler spends the freedom on longer live ranges elsewhere, 224 instead of 198 registers for the evaluator alone.)
@@ -264,7 +377,11 @@ __device__ __forceinline__ WaveEvalRegs<NS> wave_eval_setup(const DevProblem &P,
 __device__ __forceinline__ void wave_eval_init(const DevProblem &P, const WaveGeom &g, double *lds, int lane)
 {
     for (int i = lane; i < g.o_gen; i += WV_NT) lds[i] = (i >= g.o_us && i < g.o_us + g.XL) ? 1.0 : 0.0;
-    for (int i = lane; i < 2 * g.NLP + 8; i += WV_NT) lds[g.o_gz + i] = 0.0;
+    for (int i = lane; i < 2 * g.NLP + 16; i += WV_NT) lds[g.o_gz + i] = 0.0;
+    for (int i = lane; i < g.nb * WV_TCL; i += WV_NT) {
+        const int blk = i / WV_TCL, r = i - blk * WV_TCL, row = r >> 4, d = r & 15;
+        lds[g.o_tc + i] = (row < 3 && d < 2 * MAXBW + 1) ? P.blk[blk].T[row][d] : 0.0;
+    }
     const int glen = g.nf + g.K - 1;
     for (int i = lane; i < g.nb * 2 * 4 * g.GQ; i += WV_NT) {
         const int blk = i / (2 * 4 * g.GQ), i2 = i - blk * 2 * 4 * g.GQ;
@@ -297,7 +414,10 @@ template <int KS, int NS, bool OM> constexpr int wave_slots() { return 2 * KS + 
 // log-posterior + gradient of the chain at theta (registers, slot order above) -> gradient (registers), returns lp (uniform).
 // Formulas: bdrt_solo.h / bdrt_tile_s1.h (same model code, other thread mapping).  `jac`: 1.0 with the Jacobian of the
 // lower = 0 transforms (sampling), 0.0 without (optimisation).
-template <int KS, int NS, bool OM = false>
+// OCC: waves per SIMD the instantiation is scheduled for.  2 (default): the kernel of a full CU (eight chains), bound by VALU issue.  1: at most four
+// chains on the CU -- nothing hides a wave's own LDS / scalar-load latency, so the products request their operands an iteration ahead
+// (wave_toep_*_pipe), the band coefficients come from LDS instead of scalar loads, the neighbour terms of the prior are branch-free.
+template <int KS, int NS, bool OM = false, int OCC = 2>
 __device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom &g, double *lds, const double (&th)[wave_slots<KS, NS, OM>()],
                                             double (&gr)[wave_slots<KS, NS, OM>()], const WaveEvalRegs<NS> &er, const double jac, int lane_,
                                             long long *prof = nullptr)
@@ -312,6 +432,12 @@ __device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom 
     const double *gen = lds + g.o_gen;
     double *zp = lds + g.o_zp, *gz = lds + g.o_gz;
     double lp = 0.0;                                       // this lane's share of lp
+    [[maybe_unused]] ToepFwdPre fpre;
+    if constexpr (OCC == 1) {
+        // (lanes behind the last part: the last part's addresses, loaded and not used)
+        const int fpart_c = er.fpart < g.NP ? er.fpart : g.NP - 1;
+        fpre = wave_toep_fwd_pre(gen, g.GQ, 4 * (lane - er.fpart * g.RGb) - fpart_c * g.ML + g.S);
+    }
 
     // ---- E0: constrained parameters ----------------------------------------------------------------------------------
     double x[KS], uu[KS];
@@ -343,7 +469,8 @@ __device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom 
         if (part < g.NP) {
             const int n0 = 4 * rg, m0 = part * g.ML;
             double ar[4] = {0.0, 0.0, 0.0, 0.0}, ai[4] = {0.0, 0.0, 0.0, 0.0};
-            wave_toep_fwd(gen, g.GQ, n0 - m0 + g.S, xs + MAXBW + m0, g.ML, ar, ai);
+            if constexpr (OCC == 1) wave_toep_fwd_pipe(fpre, xs + MAXBW + m0, g.ML, ar, ai);
+            else wave_toep_fwd(gen, g.GQ, n0 - m0 + g.S, xs + MAXBW + m0, g.ML, ar, ai);
             double *o = zp + (size_t)(2 * part) * g.R4 + n0;
             *reinterpret_cast<double2 *>(o) = make_double2(ar[0], ar[1]); *reinterpret_cast<double2 *>(o + 2) = make_double2(ar[2], ar[3]);
             o += g.R4;
@@ -385,6 +512,34 @@ __device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom 
                     }
                 }
             };
+            if constexpr (OCC == 1) {
+            // one wave per SIMD: the coefficients come from the LDS table with the taps' operands (a scalar load returns out of order: its
+            // s_waitcnt drains the LDS queue as well -- with no second wave to fill the gap, once per batch)
+            const double *tcl = lds + g.o_tc;
+            double ca[3][CB], cb[3][CB];
+            auto ldc = [&](double (&cv)[3][CB], int d0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < CB; ++j) cv[i][j] = tcl[16 * i + d0 + j];
+            };
+            auto macc = [&](const double (&xv)[CB][KS], const double (&cv)[3][CB]) {
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int u = 0; u < KS; ++u) {
+                        v0[u] = fma(cv[0][j], xv[j][u], v0[u]); v1[u] = fma(cv[1][j], xv[j][u], v1[u]); v2[u] = fma(cv[2][j], xv[j][u], v2[u]);
+                    }
+            };
+            ld(xa, 0); ldc(ca, 0);
+#pragma unroll 1
+            for (int d0 = 0; d0 < NT13; d0 += 2 * CB) {
+                ld(xb, d0 + CB); ldc(cb, d0 + CB);
+                macc(xa, ca);
+                ld(xa, d0 + 2 * CB); ldc(ca, d0 + 2 * CB);
+                macc(xb, cb);
+            }
+            } else {
             ld(xa, 0);
 #pragma unroll 1
             for (int d0 = 0; d0 < NT13; d0 += 2 * CB) {
@@ -393,7 +548,9 @@ __device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom 
                 ld(xa, d0 + 2 * CB);
                 mac(xb, d0 + CB);
             }
+            }
         }
+        BDRT_WV_PROF(12);
 #pragma unroll
         for (int u = 0; u < KS; ++u) {
             const int k = lane + 64 * u;
@@ -405,22 +562,39 @@ __device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom 
             const double ir = 0.15 * iu;                       // 1 / ups_raw
             double lpk = -(tu + LOG_015) - 0.5 * q2 * iu2 - (P.ups_alpha + 1.0) * tu - P.ups_beta * ir + jac * tu;
             double gu = -iu + q2 * iu2 * iu;
-            // (branch-free selects here let the lane's slots interleave -- 4.8 k -> 3.5 k cycles for this phase with one wave per
-            //  SIMD -- and cost 40 registers: with two waves per SIMD the kernel was 9 % slower.  Measured, dropped.)
-            if (k >= 1 && k + 1 < K) {                         // dups centred at k
-                const double du = 0.5 * (uk - 0.5 * (um1 + up1)) * iu;
-                lpk += -0.5 * du * du;
-                gu += -du * 0.25 * (um1 + up1) * iu2;
-            }
-            if (k >= 2 && kv[u]) {                             // k is the right neighbour of centre k-1
-                const double i0 = lean_rcp(um1);
-                const double du = 0.5 * (um1 - 0.5 * (um2 + uk)) * i0;
-                gu += du * 0.25 * i0;
-            }
-            if (k + 2 < K) {                                   // k is the left neighbour of centre k+1
-                const double i0 = lean_rcp(up1);
-                const double du = 0.5 * (up1 - 0.5 * (uk + up2)) * i0;
-                gu += du * 0.25 * i0;
+            // neighbour terms of the ups prior: centre k, and k as the right / left neighbour of the centres k - 1 / k + 1.  Every accumulation
+            // is an explicit fma of the same operands in both schedules (OCC 1 and 2 give the same bits: chains change schedule between
+            // launches when the number of live chains crosses four per CU).
+            {
+                const double s1 = um1 + up1;
+                const double duc = 0.5 * (uk - 0.5 * s1) * iu;
+                const bool cc = k >= 1 && k + 1 < K, cl = k >= 2 && kv[u], cr = k + 2 < K;
+                if constexpr (OCC == 1) {
+                    // one wave per SIMD: branch-free, so that the lane's slots interleave (4.8 k -> 3.5 k cycles for this phase; the 40
+                    // registers it costs are what made it slower with two waves per SIMD).  The rows' pads hold 1.0: every reciprocal is finite.
+                    lpk = fma(cc ? -0.5 * duc : 0.0, duc, lpk);
+                    gu = fma(cc ? -duc * 0.25 * s1 : 0.0, iu2, gu);
+                    const double il = lean_rcp(um1), ir1 = lean_rcp(up1);
+                    const double dul = 0.5 * (um1 - 0.5 * (um2 + uk)) * il;
+                    gu = fma(cl ? dul * 0.25 : 0.0, il, gu);
+                    const double dur = 0.5 * (up1 - 0.5 * (uk + up2)) * ir1;
+                    gu = fma(cr ? dur * 0.25 : 0.0, ir1, gu);
+                } else {
+                    if (cc) {
+                        lpk = fma(-0.5 * duc, duc, lpk);
+                        gu = fma(-duc * 0.25 * s1, iu2, gu);
+                    }
+                    if (cl) {
+                        const double il = lean_rcp(um1);
+                        const double dul = 0.5 * (um1 - 0.5 * (um2 + uk)) * il;
+                        gu = fma(dul * 0.25, il, gu);
+                    }
+                    if (cr) {
+                        const double ir1 = lean_rcp(up1);
+                        const double dur = 0.5 * (up1 - 0.5 * (uk + up2)) * ir1;
+                        gu = fma(dur * 0.25, ir1, gu);
+                    }
+                }
             }
             lp += kv[u] ? lpk : 0.0;
             sv0 += kv[u] ? v0[u] * v0[u] * iu2 : 0.0; sv1 += kv[u] ? v1[u] * v1[u] * iu2 : 0.0; sv2 += kv[u] ? v2[u] * v2[u] * iu2 : 0.0;
@@ -500,12 +674,20 @@ __device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom 
                 sHzr2 += (h_re + h_im) * zr * zr; sHzi2 += (h_re + h_im) * zi * zi;
             }
         }
+        BDRT_WV_PROF(6);
         // the six sums and lp in one butterfly: lane j of each half-wave ends with sum j
         const double q[8] = {sR, sL, sH, sHz2, sHzr2, sHzi2, lp, 0.0};
         double t = sum32_by_lane<8>(q, lane);
         t += wv_xor32(t);
 #pragma unroll
         for (int i = 0; i < 7; ++i) T[i] = wv_bcast(t, i);
+        BDRT_WV_PROF(7);
+    }
+    [[maybe_unused]] ToepBwdPre bpre;
+    if constexpr (OCC == 1) {
+        // the backward product's first generator elements: requested here, used behind the backward convolutions
+        const int bmg_c = (lane & 31) < g.MG ? (lane & 31) : g.MG - 1;
+        bpre = wave_toep_bwd_pre(gen + (lane >> 5) * 4 * g.GQ, g.GQ, g.S - 6 * bmg_c);
     }
     double gl[KS];
     {
@@ -530,9 +712,15 @@ __device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom 
             for (int j = 0; j < CBB; ++j)
 #pragma unroll
                 for (int u = 0; u < KS; ++u) wb[j][u] = wl[ko[u] - (CA + j)];
+            [[maybe_unused]] double cr[16];           // OCC 1: the row's coefficients from the LDS table (see the forward convolutions)
+            if constexpr (OCC == 1) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) cr[j] = (lds + g.o_tc)[16 * i + j];
+            }
 #pragma unroll
             for (int j = 0; j < CA; ++j) {
-                const double c = Tc[i * NT13 + j];
+                double c;
+                if constexpr (OCC == 1) c = cr[j]; else c = Tc[i * NT13 + j];
 #pragma unroll
                 for (int u = 0; u < KS; ++u) gl[u] = fma(c, wa[j][u], gl[u]);
             }
@@ -543,7 +731,8 @@ __device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom 
                 for (int u = 0; u < KS; ++u) wa[j][u] = wl[ko[u] - j];
 #pragma unroll
             for (int j = 0; j < CBB; ++j) {
-                const double c = Tc[i * NT13 + CA + j];
+                double c;
+                if constexpr (OCC == 1) c = cr[CA + j]; else c = Tc[i * NT13 + CA + j];
 #pragma unroll
                 for (int u = 0; u < KS; ++u) gl[u] = fma(c, wb[j][u], gl[u]);
             }
@@ -558,7 +747,8 @@ __device__ __forceinline__ double wave_eval(const DevProblem &P, const WaveGeom 
         const int b = lane >> 5, mg = lane & 31;
         if (mg < g.MG) {
             double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            wave_toep_bwd(gen + b * 4 * g.GQ, g.GQ, g.S - 6 * mg, gz + b * g.NLP, g.NLP, acc);
+            if constexpr (OCC == 1) wave_toep_bwd_pipe(bpre, gz + b * g.NLP, g.NLP, acc);
+            else wave_toep_bwd(gen + b * 4 * g.GQ, g.GQ, g.S - 6 * mg, gz + b * g.NLP, g.NLP, acc);
             double *o = gk + b * g.KP + 6 * mg;
             *reinterpret_cast<double2 *>(o) = make_double2(acc[0], acc[1]);
             *reinterpret_cast<double2 *>(o + 2) = make_double2(acc[2], acc[3]);

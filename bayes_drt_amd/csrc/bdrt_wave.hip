@@ -34,7 +34,10 @@ static hipError_t wave_set_lds_limit(size_t bytes)
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nuts_wave_kernel<KS_, NS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nuts_wave_kernel<KS_, NS_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)wave_eval_kernel<KS_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)wave_eval_kernel<KS_, NS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)wave_eval_kernel<KS_, NS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nuts_wave_kernel<KS_, NS_, false, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nuts_wave_kernel<KS_, NS_, true, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)wave_eval_kernel<KS_, NS_, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         BDRT_WV_ATTR(1, 1) BDRT_WV_ATTR(1, 2) BDRT_WV_ATTR(2, 1) BDRT_WV_ATTR(2, 2) BDRT_WV_ATTR(3, 1) BDRT_WV_ATTR(3, 2)
 #undef BDRT_WV_ATTR
         return e;
@@ -63,20 +66,36 @@ size_t wave_lds_request(const WaveGeom &g, int n_wg, int n_cu, int *nhot, int ma
     return share;
 }
 
+// Which schedule of the headline family's kernels a launch takes: the one for ONE wave per SIMD (OCC = 1 instantiations, bdrt_wave.h) when
+// the LDS share of a chain leaves room for at most four chains on a CU -- wave_lds_request hands out such shares exactly when the launch
+// has at most four chains per CU.  BDRT_WAVE_OCC=1 / 2 forces one (tests, A/B runs).
+static bool wave_one_per_simd(size_t lds)
+{
+    if (const char *e = getenv("BDRT_WAVE_OCC")) { if (e[0] == '1') return true; if (e[0] == '2') return false; }
+    return lds * 5 > (size_t)160 * 1024;
+}
+
 int launch_wave_nuts(const DevProblem *dp, const NutsParams &np, const NutsArgs &args, const WaveGeom &g, int nhot, int n_wg, size_t lds,
                      hipStream_t stream, int outlier_model)
 {
     if (g.nb > 1) return launch_wave_nuts_nb(dp, np, args, g, nhot, n_wg, lds, stream, outlier_model);     // (bdrt_wave_nb.hip)
     BDRT_HIP(wave_set_lds_limit(lds));
+    const bool one = wave_one_per_simd(lds);
+#define BDRT_WV_CALL1(KS_, NS_) hipLaunchKernelGGL((nuts_wave_kernel<KS_, NS_, false, false, 1, 1>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, np, args, g, nhot)
+#define BDRT_WV_CALL1_PROF(KS_, NS_) hipLaunchKernelGGL((nuts_wave_kernel<KS_, NS_, true, false, 1, 1>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, np, args, g, nhot)
 #define BDRT_WV_CALL(KS_, NS_) hipLaunchKernelGGL((nuts_wave_kernel<KS_, NS_>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, np, args, g, nhot)
 #define BDRT_WV_CALL_PROF(KS_, NS_) hipLaunchKernelGGL((nuts_wave_kernel<KS_, NS_, true>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, np, args, g, nhot)
 #define BDRT_WV_CALL_OM(KS_, NS_) hipLaunchKernelGGL((nuts_wave_kernel<KS_, NS_, false, true>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, np, args, g, nhot)
     if (outlier_model) BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL_OM);     // (no profiling instantiation of the outlier variant)
+    else if (args.prof && one) BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL1_PROF);
     else if (args.prof) BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL_PROF);
+    else if (one) BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL1);
     else BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL);
 #undef BDRT_WV_CALL
 #undef BDRT_WV_CALL_PROF
 #undef BDRT_WV_CALL_OM
+#undef BDRT_WV_CALL1
+#undef BDRT_WV_CALL1_PROF
     BDRT_HIP(hipGetLastError());
     return 0;
 }
@@ -88,10 +107,14 @@ int launch_wave_eval(const DevProblem *dp, const WaveGeom &g, const double *d_th
     BDRT_HIP(wave_set_lds_limit(lds));
 #define BDRT_WV_CALL(KS_, NS_) hipLaunchKernelGGL((wave_eval_kernel<KS_, NS_>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, g, d_theta, d_spec, B, jacobian, d_lp, d_grad)
 #define BDRT_WV_CALL_OM(KS_, NS_) hipLaunchKernelGGL((wave_eval_kernel<KS_, NS_, true>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, g, d_theta, d_spec, B, jacobian, d_lp, d_grad)
+#define BDRT_WV_CALL1(KS_, NS_) hipLaunchKernelGGL((wave_eval_kernel<KS_, NS_, false, 1, 1>), dim3(n_wg), dim3(WV_NT), lds, stream, dp, g, d_theta, d_spec, B, jacobian, d_lp, d_grad)
+    const char *occ_env = getenv("BDRT_WAVE_OCC");                 // (the evaluator on its own runs a grid-stride loop on a full machine: the default schedule unless forced)
     if (outlier_model) BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL_OM);
+    else if (occ_env && occ_env[0] == '1') BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL1);
     else BDRT_WAVE_DISPATCH(g.KS, g.NS, BDRT_WV_CALL);
 #undef BDRT_WV_CALL
 #undef BDRT_WV_CALL_OM
+#undef BDRT_WV_CALL1
     BDRT_HIP(hipGetLastError());
     return 0;
 }

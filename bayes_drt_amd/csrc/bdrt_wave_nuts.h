@@ -13,8 +13,9 @@ typedef __attribute__((address_space(1))) double wv_glb_d;
 // PROF: the instantiation that fills the phase profile (a kernel of its own: see nuts_kernel, bdrt_nuts16.h)
 // OM: the outlier error model's parameters (two per frequency) are slots of the lanes too; one wave per SIMD then (512 registers)
 // NB: distributions of the model (wave_eval_nb from two on)
-template <int KS, int NS, bool PROF = false, bool OM = false, int NB = 1>
-__global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : 2) void nuts_wave_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, WaveGeom g, int nhot)
+// OCC: waves per SIMD the instantiation is scheduled for (wave_eval, bdrt_wave.h): 1 is launched when a CU gets at most four chains
+template <int KS, int NS, bool PROF = false, bool OM = false, int NB = 1, int OCC = 2>
+__global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : OCC) void nuts_wave_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, WaveGeom g, int nhot)
 {
     constexpr int NJ = wave_slots_nb<KS, NS, OM, NB>();
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : 2) void nuts_wave_kerne
             uvec = rng_uniform(rng, (uint32_t)(64 * u_blk + lane), RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
         }
         double lp;
-        if constexpr (NB == 1) lp = wave_eval<KS, NS, OM>(P, g, smem, th, gq, er, 1.0, lane, prof);
+        if constexpr (NB == 1) lp = wave_eval<KS, NS, OM, OCC>(P, g, smem, th, gq, er, 1.0, lane, prof);
         else lp = wave_eval_nb<KS, NS, OM, NB>(P, g, smem, th, gq, er, 1.0, lane);
         {
             // the slot indices from a lane number the optimiser cannot see through: otherwise every row's per-slot address
@@ -400,8 +401,8 @@ __global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : 2) void nuts_wave_kerne
 }
 
 // evaluator of the one-chain-per-wave path on its own (parity tests; few-point batches): a wave per point, grid-stride
-template <int KS, int NS, bool OM = false, int NB = 1>
-__global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : 2) void wave_eval_kernel(const DevProblem *__restrict__ Pp, WaveGeom g, const double *theta,
+template <int KS, int NS, bool OM = false, int NB = 1, int OCC = 2>
+__global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : OCC) void wave_eval_kernel(const DevProblem *__restrict__ Pp, WaveGeom g, const double *theta,
                                                              const int *spec, int B, int jacobian, double *lp, double *grad)
 {
     constexpr int NJ = wave_slots_nb<KS, NS, OM, NB>();
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : 2) void wave_eval_kerne
         for (int u = 0; u < NJ; ++u) { const double t = theta[(size_t)b * g.D + jx[u]]; th[u] = ok[u] ? t : 0.0; }
         const WaveEvalRegs<NS> er = wave_eval_setup<NS>(P, g, spec ? spec[b] : 0, lane);
         double v;
-        if constexpr (NB == 1) v = wave_eval<KS, NS, OM>(P, g, smem, th, gr, er, jacobian ? 1.0 : 0.0, lane);
+        if constexpr (NB == 1) v = wave_eval<KS, NS, OM, OCC>(P, g, smem, th, gr, er, jacobian ? 1.0 : 0.0, lane);
         else v = wave_eval_nb<KS, NS, OM, NB>(P, g, smem, th, gr, er, jacobian ? 1.0 : 0.0, lane);
         if (grad) {
 #pragma unroll
