@@ -107,6 +107,34 @@ def test_wave_nuts_matches_oracle_and_the_other_kernels(tag):
     prob.close()
 
 
+@pytest.mark.parametrize('tag', ['K161', 'K81', 'K101'])
+def test_wave_schedules_for_one_and_two_waves_per_simd_give_the_same_bits(tag):
+    """A launch with at most four chains per CU takes the instantiations scheduled for ONE wave per SIMD (operands of the Toeplitz
+    products requested an iteration ahead, band coefficients from LDS, branch-free neighbour terms: bdrt_wave.h, OCC = 1), a fuller one
+    the default ones; a chain changes schedule between launches as the other chains finish.  Same operations in the same order:
+    evaluator and sampler agree bit for bit (BDRT_WAVE_OCC forces a schedule), and both match the oracle."""
+    from bayes_drt_amd.engine import sample_units
+    prob, om = _problem(tag)
+    rng = np.random.default_rng(11)
+    theta = rng.uniform(-2, 2, (40, prob.D))
+    out = {}
+    for occ in ('1', '2'):
+        with _env(BDRT_WAVE_OCC=occ):
+            out[occ] = _wave_logp_grad(prob, theta, True)
+    assert np.array_equal(out['1'][0], out['2'][0]) and np.array_equal(out['1'][1], out['2'][1])
+    lp_ref, g_ref = om.logp_grad(theta[5], True)
+    assert abs(out['1'][0][5] - lp_ref) <= 1e-10 * max(1.0, abs(lp_ref))
+    assert np.max(np.abs(out['1'][1][5] - g_ref)) <= 1e-10 * max(1.0, np.max(np.abs(g_ref)))
+    ctrl = _ctrl(prob._lib, max_treedepth=6)
+    runs = {}
+    for occ in ('1', '2'):
+        with _env(BDRT_WAVE='1', BDRT_WAVE_OCC=occ):
+            runs[occ] = sample_units(prob, 5, 30, 10, 21, ctrl)
+    assert np.array_equal(runs['1'][0], runs['2'][0]) and np.array_equal(runs['1'][1], runs['2'][1])
+    assert [d['n_leapfrog'] for d in runs['1'][2]] == [d['n_leapfrog'] for d in runs['2'][2]]
+    prob.close()
+
+
 @pytest.mark.parametrize('hot', [None, '0', '3'])
 def test_wave_is_independent_of_launch_slicing_packing_and_resident_rows(hot):
     """The chain state survives the register / LDS <-> HBM round trip at every launch boundary bit for bit, whatever the number
