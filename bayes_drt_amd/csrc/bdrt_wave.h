@@ -864,7 +864,7 @@ __device__ __forceinline__ double wave_eval_nb(const DevProblem &P, const WaveGe
             if (part < g.NP) {
                 const int n0 = 4 * rg, m0 = part * g.ML;
                 double ar[4] = {0.0, 0.0, 0.0, 0.0}, ai[4] = {0.0, 0.0, 0.0, 0.0};
-                wave_toep_fwd(gen, g.GQ, n0 - m0 + g.S, xs + MAXBW + m0, g.ML, ar, ai);
+                wave_toep_fwd_pipe(wave_toep_fwd_pre(gen, g.GQ, n0 - m0 + g.S), xs + MAXBW + m0, g.ML, ar, ai);      // (one wave per SIMD: see wave_eval, OCC = 1)
                 double *o = zp + (size_t)(2 * part) * g.R4 + n0;
                 *reinterpret_cast<double2 *>(o) = make_double2(ar[0], ar[1]); *reinterpret_cast<double2 *>(o + 2) = make_double2(ar[2], ar[3]);
                 o += g.R4;
@@ -890,25 +890,32 @@ __device__ __forceinline__ double wave_eval_nb(const DevProblem &P, const WaveGe
 #pragma unroll
                         for (int u = 0; u < KS; ++u) xv[j][u] = xl[(kv[u] ? 64 * u : 0) + dd0 + j];
                 };
-                auto mac = [&](const double (&xv)[CB][KS], int dd0) {
+                // (the band coefficients from the block's LDS table, rows of 16 with zeros behind tap 12: a scalar load's s_waitcnt would drain
+                //  the LDS queue once per batch -- see wave_eval, OCC = 1)
+                (void)Tc;
+                const double *tcl = lds + g.o_tc + b * WV_TCL;
+                double ca[3][CB], cb[3][CB];
+                auto ldc = [&](double (&cv)[3][CB], int dd0) {
 #pragma unroll
-                    for (int j = 0; j < CB; ++j) {
-                        const int d = dd0 + j, dd = d < NT13 ? d : NT13 - 1;
-                        const bool in = d < NT13;
-                        const double t0 = in ? Tc[dd] : 0.0, t1 = in ? Tc[NT13 + dd] : 0.0, t2 = in ? Tc[2 * NT13 + dd] : 0.0;
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < CB; ++j) cv[i][j] = tcl[16 * i + dd0 + j];
+                };
+                auto mac = [&](const double (&xv)[CB][KS], const double (&cv)[3][CB]) {
+#pragma unroll
+                    for (int j = 0; j < CB; ++j)
 #pragma unroll
                         for (int u = 0; u < KS; ++u) {
-                            v0[u] = fma(t0, xv[j][u], v0[u]); v1[u] = fma(t1, xv[j][u], v1[u]); v2[u] = fma(t2, xv[j][u], v2[u]);
+                            v0[u] = fma(cv[0][j], xv[j][u], v0[u]); v1[u] = fma(cv[1][j], xv[j][u], v1[u]); v2[u] = fma(cv[2][j], xv[j][u], v2[u]);
                         }
-                    }
                 };
-                ld(xa, 0);
+                ld(xa, 0); ldc(ca, 0);
 #pragma unroll 1
                 for (int dd0 = 0; dd0 < NT13; dd0 += 2 * CB) {
-                    ld(xb, dd0 + CB);
-                    mac(xa, dd0);
-                    ld(xa, dd0 + 2 * CB);
-                    mac(xb, dd0 + CB);
+                    ld(xb, dd0 + CB); ldc(cb, dd0 + CB);
+                    mac(xa, ca);
+                    ld(xa, dd0 + 2 * CB); ldc(ca, dd0 + 2 * CB);
+                    mac(xb, cb);
                 }
             }
 #pragma unroll
@@ -967,14 +974,16 @@ __device__ __forceinline__ double wave_eval_nb(const DevProblem &P, const WaveGe
 #pragma unroll
             for (int u = 0; u < KS; ++u) gl[b][u] = 0.0;
             constexpr int NT13 = 2 * MAXBW + 1;
-            wv_cptr Tc = (wv_cptr)&B.T[0][0];
-            __asm__ volatile("" : "+s"(Tc));
+            const double *tcl = lds + g.o_tc + b * WV_TCL;
 #pragma unroll 1
             for (int i = 0; i < 3; ++i) {
                 const double *wl = wr + i * g.XL + 2 * MAXBW;
+                double cr[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) cr[j] = tcl[16 * i + j];
 #pragma unroll
                 for (int j = 0; j < NT13; ++j) {
-                    const double c = Tc[i * NT13 + j];
+                    const double c = cr[j];
 #pragma unroll
                     for (int u = 0; u < KS; ++u) gl[b][u] = fma(c, wl[(kv[u] ? lane + 64 * u : 0) - j], gl[b][u]);
                 }
@@ -1086,7 +1095,7 @@ __device__ __forceinline__ double wave_eval_nb(const DevProblem &P, const WaveGe
             const int h = lane >> 5, mg = lane & 31;
             if (mg < g.MG) {
                 double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                wave_toep_bwd(gen + h * 4 * g.GQ, g.GQ, g.S - 6 * mg, gz + h * g.NLP, g.NLP, acc);
+                wave_toep_bwd_pipe(wave_toep_bwd_pre(gen + h * 4 * g.GQ, g.GQ, g.S - 6 * mg), gz + h * g.NLP, g.NLP, acc);
                 double *o = gk + h * g.KP + 6 * mg;
                 *reinterpret_cast<double2 *>(o) = make_double2(acc[0], acc[1]);
                 *reinterpret_cast<double2 *>(o + 2) = make_double2(acc[2], acc[3]);

@@ -14,6 +14,9 @@ typedef __attribute__((address_space(1))) double wv_glb_d;
 // OM: the outlier error model's parameters (two per frequency) are slots of the lanes too; one wave per SIMD then (512 registers)
 // NB: distributions of the model (wave_eval_nb from two on)
 // OCC: waves per SIMD the instantiation is scheduled for (wave_eval, bdrt_wave.h): 1 is launched when a CU gets at most four chains
+#ifndef BDRT_WAVE_OM_OCC1
+#define BDRT_WAVE_OM_OCC1 1          // the outlier-model instantiations (one wave per SIMD by construction) take the OCC = 1 schedule of the evaluator
+#endif
 template <int KS, int NS, bool PROF = false, bool OM = false, int NB = 1, int OCC = 2>
 __global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : OCC) void nuts_wave_kernel(const DevProblem *__restrict__ Pp, NutsParams np, NutsArgs a, WaveGeom g, int nhot)
 {
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(WV_NT, (OM || NB > 1) ? 1 : OCC) void nuts_wave_ker
             uvec = rng_uniform(rng, (uint32_t)(64 * u_blk + lane), RNG_LEAF, (uint32_t)s.depth, 0, (uint32_t)s.iter);
         }
         double lp;
-        if constexpr (NB == 1) lp = wave_eval<KS, NS, OM, OCC>(P, g, smem, th, gq, er, 1.0, lane, prof);
+        if constexpr (NB == 1) lp = wave_eval<KS, NS, OM, (OM && BDRT_WAVE_OM_OCC1) ? 1 : OCC>(P, g, smem, th, gq, er, 1.0, lane, prof);
         else lp = wave_eval_nb<KS, NS, OM, NB>(P, g, smem, th, gq, er, 1.0, lane);
         {
             // the slot indices from a lane number the optimiser cannot see through: otherwise every row's per-slot address
