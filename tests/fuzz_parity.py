@@ -261,7 +261,18 @@ def run_case(n, verbose=False):
     conv = rep[0]['return_code'] == 0 and rep[0]['grad_inf'] < 1e-8
     if conv and not (np.max(np.abs(gr)) < 1e-6 and abs(lr - rep[0]['lp']) <= 1e-9 * max(1.0, abs(lr))):
         fails.append('MAP: reported |g| %.3g lp %.12g, oracle |g| %.3g lp %.12g' % (rep[0]['grad_inf'], rep[0]['lp'], np.max(np.abs(gr)), lr))
-    if not np.isfinite(lr) or lr < oms[0].logp_grad(th0[0], False)[0]:
+    boundary = False
+    if not np.isfinite(lr) and case['kw'].get('use_x_sum') and np.isfinite(rep[0]['lp']):
+        # The mixed models reject x_sum_raw < 0 (real<lower=0> x_sum_raw): with a series block without sign constraint the optimum can lie
+        # ON that boundary.  There the device's iterate is feasible by its own summation order and infeasible by the oracle's (the sum is
+        # zero to rounding), the iteration stalls against the wall and says so (return code 2): reported, not a parity failure.
+        lay = prob.layout()
+        terms = np.concatenate([np.exp(out[0][o:o + blk['A'].shape[1]]) if blk.get('nonneg') else out[0][o:o + blk['A'].shape[1]]
+                                for o, blk in zip(lay['x'], case['blocks'])])
+        boundary = abs(terms.sum()) <= 1e-9 * np.abs(terms).sum() and rep[0]['return_code'] != 0
+    if boundary:
+        note += ' [MAP stalled on the boundary x_sum_raw = 0 of the support (return code %d)]' % rep[0]['return_code']
+    elif not np.isfinite(lr) or lr < oms[0].logp_grad(th0[0], False)[0]:
         fails.append('MAP: lp at the answer %.6g below lp at the start' % lr)
     prob.close()
     text += note + ' D=%d evaluator=%d kernel=%d warm=%d map=%s' % (prob.D, evaluator, kind, warm, 'converged/%d' % rep[0]['newton_iterations'] if conv else
