@@ -59,7 +59,7 @@ struct NewtonProf {
     __device__ NewtonProf(long long *p_) : p(blockIdx.x == 0 && threadIdx.x == 0 ? p_ : nullptr), t(0) { if (p) t = clock64(); }
     __device__ void mark(int k) { if (p) { const long long n = clock64(); p[k] += n - t; t = n; } }
 };
-enum { NP_HESS = 0, NP_BUILD, NP_DIAG, NP_PANEL, NP_TRAIL, NP_SOLVE, NP_PRED, NP_WALL, NP_CALLS, NP_PREP0 = 16 /* .. 24: stages of hess_prep */, NP_FILL0 = 32 /* .. 34: stages of hess_fill */, NP_COUNT = 40 };
+enum { NP_HESS = 0, NP_BUILD, NP_DIAG, NP_PANEL, NP_TRAIL, NP_SOLVE, NP_PRED, NP_WALL, NP_CALLS, NP_ATTEMPTS /* factorisations started */, NP_PREP0 = 16 /* .. 24: stages of hess_prep */, NP_FILL0 = 32 /* .. 34: stages of hess_fill */, NP_COUNT = 40 };
 
 __global__ void newton_probe_kernel(NewtonBufs b, const int *active, int n_active)
 {
@@ -411,13 +411,26 @@ __global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const
     double lam = S.lam;
     bool ok = false, rebuilt = true;
     while (lam <= 1e12) {
-        if (!rebuilt) {                                            // more damping after a failed factorisation: M again from H
-            for (int i = tid >> 6; i < Dp; i += NW_NT / 64)
-                for (int k = tid & 63; k < Dp; k += 64) {
-                    double m = i == k ? 1.0 : 0.0;                 // identity on the padding
-                    if (i < D && k < D) m = -H[(size_t)i * Dp + k] + (i == k ? lam : 0.0);
-                    M[(size_t)i * Dp + k] = m;
+        if (!rebuilt) {
+            // more damping after a failed factorisation: M again from H -- the lower block triangle only (what chol_blocked reads:
+            // diagonal tiles in full), four rows of a wave's column slice in flight at a time (one dependent load per row was 160 k
+            // cycles per rebuild, four in ten launches at K = 161)
+            const int wv = tid >> 6, ln = tid & 63;
+            for (int i0 = 4 * wv; i0 < Dp; i0 += 4 * (NW_NT / 64)) {
+                const int kend = ((i0 + 3) | 15) + 1;               // columns up to the end of the rows' diagonal tile
+                for (int k = ln; k < kend; k += 64) {
+                    double h[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const int i = i0 + r; h[r] = (i < D && k < D) ? H[(size_t)i * Dp + k] : 0.0; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = i0 + r;
+                        double m = i == k ? 1.0 : 0.0;             // identity on the padding
+                        if (i < D && k < D) m = -h[r] + (i == k ? lam : 0.0);
+                        M[(size_t)i * Dp + k] = m;
+                    }
                 }
+            }
             __syncthreads();
         }
         rebuilt = false;
@@ -429,6 +442,7 @@ __global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const
             v[i] = gi;
         }
         __syncthreads();
+        if (pf.p) pf.p[NP_ATTEMPTS] += 1;
         if (chol_blocked(M, Dp, cl, pf, v)) {
             chol_blocked_solve(M, Dp, v, cl);
             pf.mark(NP_SOLVE);
@@ -732,6 +746,7 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
                 "chol diag %.0f / panel %.0f / trailing %.0f, solve %.0f, pred %.0f; wall %.1f us per launch\n", D, hp[NP_CALLS],
                 hp[NP_HESS] / n, hp[NP_BUILD] / n, hp[NP_DIAG] / n, hp[NP_PANEL] / n, hp[NP_TRAIL] / n, hp[NP_SOLVE] / n, hp[NP_PRED] / n,
                 hp[NP_WALL] / n / 100.0);
+        fprintf(stderr, "[bdrt newton prof] factorisations started per launch: %.2f\n", hp[NP_ATTEMPTS] / n);
         fprintf(stderr, "[bdrt newton prof] closed-form Hessian, cycles per launch: prep");
         for (int k = NP_PREP0; k <= NP_PREP0 + 8; ++k) fprintf(stderr, " %.0f", hp[k] / n);
         fprintf(stderr, "; fill (row tile 8): stage %.0f, dense product %.0f, entries + stores %.0f\n", hp[NP_FILL0] / n, hp[NP_FILL0 + 1] / n, hp[NP_FILL0 + 2] / n);
