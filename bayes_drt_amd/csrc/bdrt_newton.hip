@@ -28,6 +28,7 @@
 namespace bdrt {
 
 constexpr int NW_NT = 512;
+constexpr int NW_ATT = 6;           // dampings lam, 4 lam, ... 4^5 lam factored side by side when the machine has room (newton_solve_kernel)
 constexpr int NW_TRY = 4;           // step lengths tried per factorisation: s, s/2, s/4, s/8 -- one batched evaluation
 
 struct NewtonState {            // one per fit, in device memory
@@ -37,10 +38,16 @@ struct NewtonState {            // one per fit, in device memory
     double tol;
 };
 
+// what one factorisation attempt of a launch leaves for the gather kernel (up to NW_ATT attempts per fit when the launch speculates, see newton_solve_kernel)
+struct NewtonAttempt { double pred, gs, ss, lam; int ok, pad; };
+
 struct NewtonBufs {
     int D, Dp;                  // Dp = D rounded up to 16
-    double *x, *g, *s, *xt, *gt, *hstep;   // [n_fits][D]
+    double *x, *g, *gt, *hstep;            // [n_fits][D]
+    double *s, *xt;             // [n_fits][NW_ATT][D]: step and trial point of each attempt
     double *H, *M;              // [n_fits][Dp][Dp]
+    double *M2;                 // [n_fits][NW_ATT - 1][Dp][Dp]: the speculative attempts' matrices (nullptr: never more than one attempt)
+    NewtonAttempt *att;         // [n_fits][NW_ATT]
     double *probes, *pgrad;     // [n_fits][2 D][D]
     double *plp;                // [n_fits][2 D]
     NewtonState *st;            // [n_fits]
@@ -56,7 +63,7 @@ struct NewtonBufs {
 // phase counters: thread 0 of workgroup 0 adds the core-clock cycles since the previous mark to slot k
 struct NewtonProf {
     long long *p, t;
-    __device__ NewtonProf(long long *p_) : p(blockIdx.x == 0 && threadIdx.x == 0 ? p_ : nullptr), t(0) { if (p) t = clock64(); }
+    __device__ NewtonProf(long long *p_) : p(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 ? p_ : nullptr), t(0) { if (p) t = clock64(); }
     __device__ void mark(int k) { if (p) { const long long n = clock64(); p[k] += n - t; t = n; } }
 };
 enum { NP_HESS = 0, NP_BUILD, NP_DIAG, NP_PANEL, NP_TRAIL, NP_SOLVE, NP_PRED, NP_WALL, NP_CALLS, NP_ATTEMPTS /* factorisations started */, NP_PREP0 = 16 /* .. 24: stages of hess_prep */, NP_FILL0 = 32 /* .. 34: stages of hess_fill */, NP_COUNT = 40 };
@@ -356,7 +363,9 @@ __global__ __launch_bounds__(HP_NT) void newton_hess_prep_kernel(NewtonBufs b, c
     __syncthreads();
     if (threadIdx.x == 0) S.lin = lin;
     HessArgs ha{b.dP, b.x, b.g, b.fspec, b.hws, b.H, b.M, b.D, b.Dp, lin, b.prof};
+    const long long w0 = (b.prof && blockIdx.x == 0 && threadIdx.x == 0) ? wall_clock64() : 0;
     hess_prep(ha, f, sh);
+    if (b.prof && blockIdx.x == 0 && threadIdx.x == 0) b.prof[NP_PREP0 + 9] += wall_clock64() - w0;
 }
 __global__ __launch_bounds__(HP_NT) void newton_hess_fill_kernel(NewtonBufs b, const int *active, int n_active)
 {
@@ -382,17 +391,26 @@ __global__ __launch_bounds__(HP_NT) void newton_hess_fill_kernel(NewtonBufs b, c
     }
 }
 
-// One Levenberg-Marquardt step per active fit: (optionally) H from the probe gradients, then the damped solve and the trial point.
-__global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const int *active, int n_active)
+// One Levenberg-Marquardt step per active fit: the damped solve and the trial point.
+// natt > 1 (natt workgroups per fit, blockIdx.y = attempt): four factorisations in ten at K = 161 find -H + lam I indefinite, and the
+// next one with 4 lam is another 250 us on the one workgroup -- up to five in a row where the damping has to grow by orders of magnitude
+// (the longest launches took 1.4 ms).  When the machine has room (natt workgroups per active fit <= CUs) attempt j factors
+// -H + 4^j lam I at the same time on a CU of its own (its matrix built from H; the last attempt goes on to higher dampings by itself if
+// it must), each once; the gather kernel takes the first attempt that succeeded: the same sequence of dampings and the same numbers as
+// the one-workgroup loop, the failed factorisations off the critical path.  With natt = 1 attempt 0 runs the whole loop.
+// The kernel only reads the fit's state; the gather kernel commits the chosen attempt.
+__global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const int *active, int n_active, int natt)
 {
     extern __shared__ __attribute__((aligned(16))) double sh[];
-    const int a = blockIdx.x, tid = threadIdx.x;
+    const int a = blockIdx.x, att = blockIdx.y, tid = threadIdx.x;
     const int f = active[a], D = b.D, Dp = b.Dp;
-    NewtonState &S = b.st[f];
+    const NewtonState &S = b.st[f];
     if (S.done) return;
-    double *H = b.H + (size_t)f * Dp * Dp, *M = b.M + (size_t)f * Dp * Dp;
+    NewtonAttempt &A = b.att[NW_ATT * f + att];
+    const double *H = b.H + (size_t)f * Dp * Dp;
+    double *M = att ? b.M2 + ((size_t)f * (NW_ATT - 1) + (att - 1)) * Dp * Dp : b.M + (size_t)f * Dp * Dp;
     const double *x = b.x + (size_t)f * D, *g = b.g + (size_t)f * D;
-    double *s = b.s + (size_t)f * D, *xt = b.xt + (size_t)f * D;
+    double *s = b.s + ((size_t)f * NW_ATT + att) * D, *xt = b.xt + ((size_t)f * NW_ATT + att) * D;
     const bool lin = b.analytic && S.lin;
     const double *hw = b.analytic ? b.hws + (size_t)f * b.hl_total : nullptr;
     double *v = sh;                               // [Dp] right-hand side / solution
@@ -401,20 +419,17 @@ __global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const
     __shared__ int s_fin;
     NewtonProf pf(b.prof);
     const long long wall0 = b.prof ? wall_clock64() : 0;
-    // H (when new probe gradients arrived) and M = -H + lam I were written by newton_build_kernel
-    if (S.need_hess) {
-        if (S.hbad) { if (tid == 0) { S.rc = 2; S.done = 1; } return; }
-        __syncthreads();
-        if (tid == 0) { S.need_hess = 0; S.n_evals += b.analytic ? 0 : 2 * D; }
-    }
+    // H (when new probe gradients arrived) and M = -H + lam I were written by the build / fill kernel
+    if (S.need_hess && S.hbad) { if (tid == 0) { A.ok = 0; A.lam = S.lam; } return; }       // (the gather kernel reports it)
     pf.mark(NP_HESS);
     double lam = S.lam;
     bool ok = false, rebuilt = true;
+    if (att) { lam *= ldexp(1.0, 2 * att); rebuilt = false; }
     while (lam <= 1e12) {
         if (!rebuilt) {
-            // more damping after a failed factorisation: M again from H -- the lower block triangle only (what chol_blocked reads:
-            // diagonal tiles in full), four rows of a wave's column slice in flight at a time (one dependent load per row was 160 k
-            // cycles per rebuild, four in ten launches at K = 161)
+            // more damping after a failed factorisation (or the speculative attempt's first matrix): M again from H -- the lower block
+            // triangle only (what chol_blocked reads: diagonal tiles in full), four rows of a wave's column slice in flight at a time
+            // (one dependent load per row was 160 k cycles per rebuild)
             const int wv = tid >> 6, ln = tid & 63;
             for (int i0 = 4 * wv; i0 < Dp; i0 += 4 * (NW_NT / 64)) {
                 const int kend = ((i0 + 3) | 15) + 1;               // columns up to the end of the rows' diagonal tile
@@ -457,10 +472,11 @@ __global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const
             __syncthreads();
             if (s_fin) { ok = true; break; }
         }
+        if (att + 1 < natt) break;                         // (the next damping is another workgroup's)
         lam *= 4.0;
         __syncthreads();
     }
-    if (!ok) { if (tid == 0) { S.rc = 2; S.done = 1; S.lam = lam; } return; }
+    if (!ok) { if (tid == 0) { A.ok = 0; A.lam = lam; } return; }
     // trial point and the model's predicted increase g.s + 1/2 s^T H s.  With (-H + lam I) s = g this is
     // 1/2 (g.s + lam s.s): no product with H is needed (the difference is the residual of the backward-stable solve).
     double gs = 0.0, ss = 0.0;
@@ -481,8 +497,8 @@ __global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const
     if (tid == 0) {
         double p = 0.0, q = 0.0;
         for (int w = 0; w < NW_NT / 64; ++w) { p += red[w]; q += red[NW_NT / 64 + w]; }
-        S.pred = 0.5 * (p + lam * q); S.lam = lam;
-        S.gs = p; S.ss = q;
+        A.pred = 0.5 * (p + lam * q); A.lam = lam;
+        A.gs = p; A.ss = q; A.ok = 1;
     }
     pf.mark(NP_PRED);
     if (pf.p) { pf.p[NP_WALL] += wall_clock64() - wall0; pf.p[NP_CALLS] += 1; }
@@ -492,14 +508,13 @@ __global__ __launch_bounds__(NW_NT) void newton_solve_kernel(NewtonBufs b, const
 // passes the sufficient-increase test is accepted (bdrt_newton.h NewtonFit::consume, NEED_TRIAL, is the t = 0 case; the
 // shorter steps along the same Levenberg-Marquardt direction cost one batched evaluation instead of a re-factorisation
 // with more damping -- 40 % of the solves at K = 161 were such re-factorisations)
-__global__ __launch_bounds__(256) void newton_accept_kernel(NewtonBufs b, const int *active, int n_active, const double *lp_t,
-                                                            const double *trial)
+template <int NT>
+__device__ __forceinline__ void newton_accept_body(const NewtonBufs &b, int f, int a, const double *lp_t, const double *trial)
 {
-    const int a = blockIdx.x, tid = threadIdx.x;
-    const int f = active[a], D = b.D;
+    const int tid = threadIdx.x;
+    const int D = b.D;
     NewtonState &S = b.st[f];
-    if (S.done) return;
-    __shared__ double red[256];
+    __shared__ double red[NT];
     __shared__ int s_acc, s_t;
     double *x = b.x + (size_t)f * D, *g = b.g + (size_t)f * D;
     if (tid == 0) { s_acc = 0; s_t = 0; S.n_evals += NW_TRY; }
@@ -512,7 +527,7 @@ __global__ __launch_bounds__(256) void newton_accept_kernel(NewtonBufs b, const 
         const double lpn = lp_t[a * NW_TRY + t];
         int fin = isfinite(lpn) ? 1 : 0;
         double gi = 0.0;
-        for (int j = tid; j < D; j += 256) {
+        for (int j = tid; j < D; j += NT) {
             double v = gt[j];
             if (!isfinite(v)) fin = 0;
             // a coefficient on the linear scale that sits at its floor passes |g_y| = x |g_x| < tol whatever g_x is: there the test is
@@ -526,7 +541,7 @@ __global__ __launch_bounds__(256) void newton_accept_kernel(NewtonBufs b, const 
         fin = __syncthreads_and(fin);
         red[tid] = gi;
         __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] = fmax(red[tid], red[tid + w]); __syncthreads(); }
+        for (int w = NT / 2; w > 0; w >>= 1) { if (tid < w) red[tid] = fmax(red[tid], red[tid + w]); __syncthreads(); }
         const double ginf = red[0];
         if (tid == 0) {
             const double lp = S.lp, sc = ldexp(1.0, -t);
@@ -561,18 +576,65 @@ __global__ __launch_bounds__(256) void newton_accept_kernel(NewtonBufs b, const 
     }
     if (s_acc) {
         const double *xs = trial + ((size_t)a * NW_TRY + s_t) * D, *gt = b.gt + ((size_t)a * NW_TRY + s_t) * D;
-        for (int j = tid; j < D; j += 256) { x[j] = xs[j]; g[j] = gt[j]; }
+        for (int j = tid; j < D; j += NT) { x[j] = xs[j]; g[j] = gt[j]; }
     } else if (tid == 0) {
         S.lam *= 16.0;                                            // none of the lengths: same Hessian, much more damping
     }
 }
 
+__global__ __launch_bounds__(256) void newton_accept_kernel(NewtonBufs b, const int *active, int n_active, const double *lp_t,
+                                                            const double *trial)
+{
+    const int f = active[blockIdx.x];
+    if (b.st[f].done) return;
+    newton_accept_body<256>(b, f, blockIdx.x, lp_t, trial);
+}
+
+// closed-form Hessian: the verdict on the trial points and, for a fit that goes on with a new point, the forward quantities of the NEXT
+// round's Hessian (newton_hess_prep_kernel) in one launch: as a launch of its own -- one or two workgroups between two short kernels --
+// the prep kernel took 48 us of which 25 us are its work (kernel timeline of a K = 161 fit, profiles/r06/newton_timeline.txt).
+__global__ __launch_bounds__(HP_NT) void newton_accept_prep_kernel(NewtonBufs b, const int *active, int n_active, const double *lp_t,
+                                                                const double *trial)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    const long long w0 = (b.prof && blockIdx.x == 0 && threadIdx.x == 0) ? wall_clock64() : 0;
+    const int f = active[blockIdx.x];
+    NewtonState &S = b.st[f];
+    if (S.done) return;
+    newton_accept_body<HP_NT>(b, f, blockIdx.x, lp_t, trial);
+    __syncthreads();                                       // the verdict (thread 0) and the new point are visible to the workgroup
+    if (S.done || !S.need_hess) return;
+    const int lin = (b.lin_ok && (S.lin || S.lam <= 1e-4)) ? 1 : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) S.lin = lin;
+    HessArgs ha{b.dP, b.x, b.g, b.fspec, b.hws, b.H, b.M, b.D, b.Dp, lin, b.prof};
+    hess_prep(ha, f, sh);
+    if (b.prof && blockIdx.x == 0 && threadIdx.x == 0) b.prof[NP_PREP0 + 9] += wall_clock64() - w0;
+}
+
 // dense batch of the active fits' trial points: rows NW_TRY a + t <- x + 2^-t s of fit active[a]
-__global__ void newton_gather_kernel(NewtonBufs b, const int *active, int n_active, double *dst)
+// (and the commit of the launch's solve: attempt 0 when it succeeded, else the speculative attempt 1 -- newton_solve_kernel)
+__global__ void newton_gather_kernel(NewtonBufs b, const int *active, int n_active, double *dst, int natt)
 {
     const int a = blockIdx.x, t = blockIdx.y;
     const int f = active[a];
-    const double *x = b.x + (size_t)f * b.D, *sv = b.s + (size_t)f * b.D, *xt = b.xt + (size_t)f * b.D;
+    int c = 0;
+    while (c + 1 < natt && !b.att[NW_ATT * f + c].ok) ++c;            // the first attempt that succeeded (the last one if none did)
+    const double *x = b.x + (size_t)f * b.D, *sv = b.s + ((size_t)f * NW_ATT + c) * b.D, *xt = b.xt + ((size_t)f * NW_ATT + c) * b.D;
+    if (t == 0 && threadIdx.x == 0) {
+        NewtonState &S = b.st[f];
+        if (!S.done) {
+            const NewtonAttempt &A = b.att[NW_ATT * f + c];
+            if (S.need_hess) {
+                if (S.hbad) { S.rc = 2; S.done = 1; }
+                else { S.need_hess = 0; S.n_evals += b.analytic ? 0 : 2 * b.D; }
+            }
+            if (!S.done) {
+                if (A.ok) { S.pred = A.pred; S.lam = A.lam; S.gs = A.gs; S.ss = A.ss; }
+                else { S.rc = 2; S.done = 1; S.lam = A.lam; }
+            }
+        }
+    }
     const double sc = ldexp(1.0, -t);
     double *d = dst + ((size_t)a * NW_TRY + t) * b.D;
     const bool lin = b.analytic && b.st[f].lin;
@@ -625,10 +687,20 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
     NewtonBufs b;
     b.D = D; b.Dp = Dp;
     const size_t nD = (size_t)n_fits * D * sizeof(double);
-    NW_HIP(alloc(nD, (void **)&b.x)); NW_HIP(alloc(nD, (void **)&b.g)); NW_HIP(alloc(nD, (void **)&b.s));
-    NW_HIP(alloc(nD, (void **)&b.xt)); NW_HIP(alloc(nD * NW_TRY, (void **)&b.gt)); NW_HIP(alloc(nD, (void **)&b.hstep));
+    NW_HIP(alloc(nD, (void **)&b.x)); NW_HIP(alloc(nD, (void **)&b.g)); NW_HIP(alloc(NW_ATT * nD, (void **)&b.s));
+    NW_HIP(alloc(NW_ATT * nD, (void **)&b.xt)); NW_HIP(alloc(nD * NW_TRY, (void **)&b.gt)); NW_HIP(alloc(nD, (void **)&b.hstep));
+    NW_HIP(alloc((size_t)n_fits * NW_ATT * sizeof(NewtonAttempt), (void **)&b.att));
+    NW_HIP(hipMemsetAsync(b.att, 0, (size_t)n_fits * NW_ATT * sizeof(NewtonAttempt), P.stream));
     NW_HIP(alloc((size_t)n_fits * Dp * Dp * sizeof(double), (void **)&b.H));
     NW_HIP(alloc((size_t)n_fits * Dp * Dp * sizeof(double), (void **)&b.M));
+    // the speculative factorisations (newton_solve_kernel) need matrices of their own: allocated while they stay below 2 GB (a 512-spectrum batch with them -- 2.3 GB of hipMalloc -- was 0.31 -> 0.38 s), used in the
+    // launches that have the workgroups to spare (BDRT_NEWTON_SPEC=0: never)
+    b.M2 = nullptr;
+    int n_cu = 0;
+    NW_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, P.device));
+    const char *spec_env = getenv("BDRT_NEWTON_SPEC");
+    if (!(spec_env && spec_env[0] == '0') && (size_t)n_fits * (NW_ATT - 1) * Dp * Dp * sizeof(double) <= ((size_t)2 << 30))
+        NW_HIP(alloc((size_t)n_fits * (NW_ATT - 1) * Dp * Dp * sizeof(double), (void **)&b.M2));
     // closed-form Hessian where the model has one (BDRT_NEWTON_FD=1: central differences of the gradient as in rounds 1-5)
     const char *fd_env = getenv("BDRT_NEWTON_FD");
     b.analytic = (hess_analytic_ok(P.dev) && !(fd_env && fd_env[0] == '1')) ? 1 : 0;
@@ -677,6 +749,7 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
     const size_t lds_prep = hess_prep_lds_doubles(P.dev.nf, P.dev.blk[0].K) * sizeof(double), lds_fill = hess_fill_lds_doubles(P.dev.nf, P.dev.blk[0].K) * sizeof(double);
     if (b.analytic) {
         NW_HIP(hipFuncSetAttribute((const void *)newton_hess_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
+        NW_HIP(hipFuncSetAttribute((const void *)newton_accept_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
         NW_HIP(hipFuncSetAttribute((const void *)newton_hess_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fill));
     }
     int rc;
@@ -709,22 +782,30 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
         }
         if (!b.analytic) NW_HIP(hipMemcpyAsync(d_specp, hspecp.data(), hspecp.size() * sizeof(int), hipMemcpyHostToDevice, st));
         NW_HIP(hipMemcpyAsync(d_spec1, sp1.data(), (size_t)n_active * NW_TRY * sizeof(int), hipMemcpyHostToDevice, st));
+        const int natt = b.M2 ? std::max(1, std::min(NW_ATT, n_cu / n_active)) : 1;
         for (int r = 0; r < rounds_per_sync; ++r) {
             // probes of the fits that ask for a fresh Hessian (probe slot a = position in the active list) and their gradients
             if (b.analytic) {
-                hipLaunchKernelGGL(newton_hess_prep_kernel, dim3(n_active), dim3(HP_NT), lds_prep, st, b, (const int *)d_active, n_active);
+                // (the forward quantities of this round's Hessian: left by the previous round's accept + prep kernel, by a launch of
+                //  their own in the first round)
+                if (round == 0 && r == 0)
+                    hipLaunchKernelGGL(newton_hess_prep_kernel, dim3(n_active), dim3(HP_NT), lds_prep, st, b, (const int *)d_active, n_active);
                 hipLaunchKernelGGL(newton_hess_fill_kernel, dim3(Dp / 16, n_active), dim3(HP_NT), lds_fill, st, b, (const int *)d_active, n_active);
             } else {
                 hipLaunchKernelGGL(newton_probe_kernel, dim3(2 * D, n_active), dim3(128), 0, st, b, (const int *)d_active, n_active);
                 if ((rc = launch_logp_grad(&P, b.probes, d_specp, n_active * 2 * D, 0, b.plp, b.pgrad, nullptr, nullptr, nullptr, st))) { cleanup(); return rc; }
                 hipLaunchKernelGGL(newton_build_kernel, dim3(Dp / 16, n_active), dim3(256), 0, st, b, (const int *)d_active, n_active);
             }
-            hipLaunchKernelGGL(newton_solve_kernel, dim3(n_active), dim3(NW_NT), lds_solve, st, b, (const int *)d_active, n_active);
+            hipLaunchKernelGGL(newton_solve_kernel, dim3(n_active, natt), dim3(NW_NT), lds_solve, st, b, (const int *)d_active, n_active, natt);
             // trial points (NW_TRY step lengths per fit) as a dense batch for the evaluator, then the verdict
-            hipLaunchKernelGGL(newton_gather_kernel, dim3(n_active, NW_TRY), dim3(128), 0, st, b, (const int *)d_active, n_active, b.probes);
+            hipLaunchKernelGGL(newton_gather_kernel, dim3(n_active, NW_TRY), dim3(128), 0, st, b, (const int *)d_active, n_active, b.probes, natt);
             if ((rc = launch_logp_grad(&P, b.probes, d_spec1, n_active * NW_TRY, 0, d_lpt, b.gt, nullptr, nullptr, nullptr, st))) { cleanup(); return rc; }
-            hipLaunchKernelGGL(newton_accept_kernel, dim3(n_active), dim3(256), 0, st, b, (const int *)d_active, n_active, (const double *)d_lpt,
-                               (const double *)b.probes);
+            if (b.analytic)
+                hipLaunchKernelGGL(newton_accept_prep_kernel, dim3(n_active), dim3(HP_NT), lds_prep, st, b, (const int *)d_active, n_active,
+                                   (const double *)d_lpt, (const double *)b.probes);
+            else
+                hipLaunchKernelGGL(newton_accept_kernel, dim3(n_active), dim3(256), 0, st, b, (const int *)d_active, n_active, (const double *)d_lpt,
+                                   (const double *)b.probes);
         }
         NW_HIP(hipGetLastError());
     }
@@ -749,7 +830,7 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
         fprintf(stderr, "[bdrt newton prof] factorisations started per launch: %.2f\n", hp[NP_ATTEMPTS] / n);
         fprintf(stderr, "[bdrt newton prof] closed-form Hessian, cycles per launch: prep");
         for (int k = NP_PREP0; k <= NP_PREP0 + 8; ++k) fprintf(stderr, " %.0f", hp[k] / n);
-        fprintf(stderr, "; fill (row tile 8): stage %.0f, dense product %.0f, entries + stores %.0f\n", hp[NP_FILL0] / n, hp[NP_FILL0 + 1] / n, hp[NP_FILL0 + 2] / n);
+        fprintf(stderr, "; fill (row tile 8): stage %.0f, dense product %.0f, entries + stores %.0f; prep wall %.1f us\n", hp[NP_FILL0] / n, hp[NP_FILL0 + 1] / n, hp[NP_FILL0 + 2] / n, hp[NP_PREP0 + 9] / n / 100.0);
     }
 #undef NW_HIP
     const auto t_host2 = std::chrono::steady_clock::now();

@@ -1111,8 +1111,9 @@ class Inverter:
             # Bayesian fit would not touch: put them back
             saved = {k: getattr(self, k) for k in self._RIDGE_SIDE_EFFECTS if hasattr(self, k)}
             try:
-                # (three hyper-lambda iterations, not the twenty of a ridge fit in its own right: this is a starting point, and
-                #  the full ridge solve -- 19 ms at K = 81, 57 ms at K = 161, one workgroup -- was 40 % of the whole MAP fit)
+                # (two hyper-lambda iterations, not the twenty of a ridge fit in its own right: this is a starting point, and
+                #  the full ridge solve -- 19 ms at K = 81, 57 ms at K = 161, one workgroup -- was 40 % of the whole MAP fit; with two
+                #  the start is as good as with three -- 49 against 54 Newton rounds at K = 161 --, with one it is not: 136)
                 with warnings.catch_warnings():
                     warnings.simplefilter('ignore')
                     if defer_ridge_start and not ridge_kw and not outliers and \
@@ -1123,11 +1124,11 @@ class Inverter:
                         self.distribution_fits = {}
                         st = self._ridge_setup(frequencies, np.asarray(Z), 'both', 'integral', 2, 0, True, True, 'modulus', False)
                         extra.append(_DeferredRidgeStart(st, self._Z_scale, frequencies, Z, nonneg, inductance_scale,
-                                                         int(os.environ.get('BDRT_RIDGE_START_ITER', 3))))
+                                                         int(os.environ.get('BDRT_RIDGE_START_ITER', 2))))
                     else:
                       extra.append(self._get_init_from_ridge(frequencies, Z, 'optimize', nonneg=nonneg, outliers=outliers,
                                                            inductance_scale=inductance_scale,
-                                                           ridge_kw=dict({'max_iter': int(os.environ.get('BDRT_RIDGE_START_ITER', 3))}, **ridge_kw)))
+                                                           ridge_kw=dict({'max_iter': int(os.environ.get('BDRT_RIDGE_START_ITER', 2))}, **ridge_kw)))
             except Exception as e:                       # the ridge candidate is optional: the random start remains
                 warnings.warn('ridge starting point not available (%s): MAP from the random start only' % e)
             finally:
