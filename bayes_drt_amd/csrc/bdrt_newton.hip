@@ -764,26 +764,36 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
     const char *trace_env = getenv("BDRT_NEWTON_TRACE");      // 1: the status records of the first eight fits at every host synchronisation, on stderr
     const int rounds_per_sync = std::max(1, rp_env ? atoi(rp_env) : 4);
     const long long max_rounds = (long long)max_iter * 40 + 100;
-    for (long long round = 0; round < max_rounds; round += rounds_per_sync) {
+    // A host synchronisation costs ~90 us (status records down, the active list and its spectrum ids up): the lists go up only when they
+    // changed, and while some active fit is far from its stationary point (|g| > 0.01: at least three more rounds) a group is twice as long
+    std::vector<int> hact_prev;
+    int group = rounds_per_sync;
+    for (long long round = 0; round < max_rounds; round += group) {
         NW_HIP(hipMemcpyAsync(hst.data(), b.st, hst.size() * sizeof(NewtonState), hipMemcpyDeviceToHost, st));
         NW_HIP(hipStreamSynchronize(st));
         int n_active = 0;
-        for (int i = 0; i < n_fits; ++i) if (!hst[i].done) hact[n_active++] = i;
+        double g_far = 0.0;                                    // (the fit that will finish last decides how long the iteration runs)
+        for (int i = 0; i < n_fits; ++i) if (!hst[i].done) { hact[n_active++] = i; g_far = std::max(g_far, hst[i].grad_inf); }
+        // (small batches only: a fit that finishes inside a group keeps its rows in the evaluator's batch until the next synchronisation)
+        group = (rp_env || !(g_far > 1e-2) || n_active > 32) ? rounds_per_sync : 2 * rounds_per_sync;
         if (trace_env && trace_env[0] == '1')
             for (int i = 0; i < n_fits && i < 8; ++i)
                 fprintf(stderr, "[bdrt newton trace] round %lld fit %d spec %d: lp %.12g lam %.3g |g| %.3g iters %d done %d rc %d lin %d\n", round, i, hspec[i],
                         hst[i].lp, hst[i].lam, hst[i].grad_inf, hst[i].iters, hst[i].done, hst[i].rc, hst[i].lin);
         if (n_active == 0) break;
-        NW_HIP(hipMemcpyAsync(d_active, hact.data(), (size_t)n_active * sizeof(int), hipMemcpyHostToDevice, st));
-        if (!b.analytic) hspecp.resize((size_t)n_active * 2 * D);
-        for (int a = 0; a < n_active; ++a) {
-            if (!b.analytic) std::fill(hspecp.begin() + (size_t)a * 2 * D, hspecp.begin() + (size_t)(a + 1) * 2 * D, hspec[hact[a]]);
-            for (int t = 0; t < NW_TRY; ++t) sp1[(size_t)a * NW_TRY + t] = hspec[hact[a]];
+        if ((int)hact_prev.size() != n_active || !std::equal(hact_prev.begin(), hact_prev.end(), hact.begin())) {
+            hact_prev.assign(hact.begin(), hact.begin() + n_active);
+            NW_HIP(hipMemcpyAsync(d_active, hact.data(), (size_t)n_active * sizeof(int), hipMemcpyHostToDevice, st));
+            if (!b.analytic) hspecp.resize((size_t)n_active * 2 * D);
+            for (int a = 0; a < n_active; ++a) {
+                if (!b.analytic) std::fill(hspecp.begin() + (size_t)a * 2 * D, hspecp.begin() + (size_t)(a + 1) * 2 * D, hspec[hact[a]]);
+                for (int t = 0; t < NW_TRY; ++t) sp1[(size_t)a * NW_TRY + t] = hspec[hact[a]];
+            }
+            if (!b.analytic) NW_HIP(hipMemcpyAsync(d_specp, hspecp.data(), hspecp.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            NW_HIP(hipMemcpyAsync(d_spec1, sp1.data(), (size_t)n_active * NW_TRY * sizeof(int), hipMemcpyHostToDevice, st));
         }
-        if (!b.analytic) NW_HIP(hipMemcpyAsync(d_specp, hspecp.data(), hspecp.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        NW_HIP(hipMemcpyAsync(d_spec1, sp1.data(), (size_t)n_active * NW_TRY * sizeof(int), hipMemcpyHostToDevice, st));
         const int natt = b.M2 ? std::max(1, std::min(NW_ATT, n_cu / n_active)) : 1;
-        for (int r = 0; r < rounds_per_sync; ++r) {
+        for (int r = 0; r < group; ++r) {
             // probes of the fits that ask for a fresh Hessian (probe slot a = position in the active list) and their gradients
             if (b.analytic) {
                 // (the forward quantities of this round's Hessian: left by the previous round's accept + prep kernel, by a launch of
