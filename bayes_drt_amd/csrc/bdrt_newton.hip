@@ -609,6 +609,7 @@ __global__ __launch_bounds__(HP_NT) void newton_accept_prep_kernel(NewtonBufs b,
     if (threadIdx.x == 0) S.lin = lin;
     HessArgs ha{b.dP, b.x, b.g, b.fspec, b.hws, b.H, b.M, b.D, b.Dp, lin, b.prof};
     hess_prep(ha, f, sh);
+    if (b.prof) __syncthreads();                           // (profiling runs: the wall time of the whole workgroup, not of thread 0's wave)
     if (b.prof && blockIdx.x == 0 && threadIdx.x == 0) b.prof[NP_PREP0 + 9] += wall_clock64() - w0;
 }
 

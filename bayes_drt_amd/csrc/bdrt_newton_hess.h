@@ -381,20 +381,23 @@ __device__ inline void hess_prep(const HessArgs &a, int f, double *lds)
         W[(q == 0 ? L.bR : (q == 1 ? L.bI : L.bS + (q - 2) * K)) + m] = s0 + s1;
     }
     HP_STAMP(23);
-    if (tid >= HP_NT - 11) {                    // (the last threads: the first K are busy with the vectors above)
-        const int q = tid - (HP_NT - 11);
-        double t = 0.0;
-        for (int n = 0; n < nf; ++n) {
-            const double wn = wfs[n];
-            double v;
-            if (q == 0) v = cfs[n];
-            else if (q == 1) v = cfs[nf + n] * wn;
-            else if (q == 2) v = cfs[2 * nf + n] * wn * wn;
-            else if (q < 7) v = hzs[(q - 3) * nf + n];
-            else v = wn * hzs[(4 + q - 7) * nf + n];
-            t += v;
+    // the eleven border scalars: sums over the frequencies of cf_0, w cf_1, w^2 cf_2, hz_0..3, w hz_4..7 -- a segment of 32 lanes per sum,
+    // strided terms and a butterfly.  (One thread per sum, eleven lanes of one wave each on its own branch of the selection, was the tail of
+    // the kernel: 20 of its 49 us, invisible in the stamps of thread 0.)
+    {
+        const int q = tid >> 5, l = tid & 31;
+        if (q < 11) {
+            const double *src = q < 3 ? cfs + (size_t)q * nf : hzs + (size_t)(q - 3) * nf;
+            const int pw = q < 3 ? q : (q < 7 ? 0 : 1);
+            double t = 0.0;
+            for (int n = l; n < nf; n += 32) {
+                const double wn = wfs[n], v = src[n];
+                t += pw == 0 ? v : (pw == 1 ? v * wn : v * wn * wn);
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o);
+            if (l == 0) W[L.h0 + q] = t;
         }
-        W[L.h0 + q] = t;
     }
     HP_STAMP(24);
 #undef HP_STAMP
