@@ -95,7 +95,7 @@ int launch_logp_grad(Problem *p, const double *d_theta, const int *d_spec, int B
 // when the problem / batch does not take that path (nothing launched), 0 when launched, < 0 on error.  Same formulas, other
 // summation order: results agree with the tile evaluator to ~1e-13 relative, not bit for bit.
 int launch_logp_grad_few(Problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp, double *d_grad,
-                         hipStream_t stream);
+                         hipStream_t stream, int any_b = 0);
 
 // the Stan-style L-BFGS of n fits as one launch (bdrt_lbfgs_dev.h; defined in bdrt_nuts.hip); 1: not applicable to this problem
 int lbfgs_device(Problem &P, const double *x0, const int *spec, int n, const bdrt_opt_options &o, double *x_out, double *g_out,

@@ -761,6 +761,8 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
     // The sequence of launches of one Levenberg-Marquardt round does not depend on what the round decides (kernels skip the
     // fits that are done; a fit that keeps its Hessian after a rejected trial skips the probe writes and ignores the probe
     // gradients), so several rounds are enqueued back to back and the host reads the status records once per group.
+    const char *tf_env = getenv("BDRT_NEWTON_TRIAL_FEW");      // 0: the trial points through the tile evaluator (as before round 6)
+    const bool trial_few = !(tf_env && tf_env[0] == '0');
     const char *rp_env = getenv("BDRT_NEWTON_ROUNDS");
     const char *trace_env = getenv("BDRT_NEWTON_TRACE");      // 1: the status records of the first eight fits at every host synchronisation, on stderr
     const int rounds_per_sync = std::max(1, rp_env ? atoi(rp_env) : 4);
@@ -810,7 +812,11 @@ int newton_polish_device(Problem &P, const double *x0, const int *spec, int n_fi
             hipLaunchKernelGGL(newton_solve_kernel, dim3(n_active, natt), dim3(NW_NT), lds_solve, st, b, (const int *)d_active, n_active, natt);
             // trial points (NW_TRY step lengths per fit) as a dense batch for the evaluator, then the verdict
             hipLaunchKernelGGL(newton_gather_kernel, dim3(n_active, NW_TRY), dim3(128), 0, st, b, (const int *)d_active, n_active, b.probes, natt);
-            if ((rc = launch_logp_grad(&P, b.probes, d_spec1, n_active * NW_TRY, 0, d_lpt, b.gt, nullptr, nullptr, nullptr, st))) { cleanup(); return rc; }
+            // (the one-workgroup-per-point evaluator where the family has one: 8 us against the tile evaluator's 24 for the eight points of
+            //  a two-start fit; the same evaluator for every batch size -- a fit's numbers do not depend on its batch)
+            rc = trial_few ? launch_logp_grad_few(&P, b.probes, d_spec1, n_active * NW_TRY, 0, d_lpt, b.gt, st, 1) : 1;
+            if (rc < 0) { cleanup(); return rc; }
+            if (rc == 1 && (rc = launch_logp_grad(&P, b.probes, d_spec1, n_active * NW_TRY, 0, d_lpt, b.gt, nullptr, nullptr, nullptr, st))) { cleanup(); return rc; }
             if (b.analytic)
                 hipLaunchKernelGGL(newton_accept_prep_kernel, dim3(n_active), dim3(HP_NT), lds_prep, st, b, (const int *)d_active, n_active,
                                    (const double *)d_lpt, (const double *)b.probes);

@@ -772,8 +772,11 @@ static size_t nuts_lds_bytes(const DevProblem &P, bool s1)
     return tile * sizeof(double) + NUTS16_SCALAR_LDS;
 }
 
+// any_b: the caller wants ONE evaluator whatever the batch size (the Newton iteration's trial points: a fit's numbers must not depend on
+// how many other fits share its batch) -- the headline family's one-workgroup-per-point evaluator then takes any B (grid-stride), every
+// other family answers 1 (the caller's tile evaluator, also for every B)
 int launch_logp_grad_few(Problem *p, const double *d_theta, const int *d_spec, int B, int jacobian, double *d_lp, double *d_grad,
-                         hipStream_t stream)
+                         hipStream_t stream, int any_b)
 {
     Problem &P = *p;
     const char *sw = getenv("BDRT_FEW_POINTS");                     // diagnostics / tests: 0 = the tile evaluator whatever B is
@@ -791,7 +794,7 @@ int launch_logp_grad_few(Problem *p, const double *d_theta, const int *d_spec, i
     // a few points per CU: beyond that the 16-column tiles win (26 us up to 16 points per CU).  BDRT_FEW_POINTS=n: n points per CU
     // at most (default 5 for the LDS-light evaluator of the headline family, three workgroups of which share a CU; 1 otherwise)
     const int per_cu = sw ? atoi(sw) : (solo ? 5 : 1);
-    if (B > per_cu * ncu) return 1;
+    if (any_b ? !solo : B > per_cu * ncu) return 1;
     static LdsAttrCache attr_solo, attr_w1;
     if (solo) {
         const SoloGeom g = solo_geometry(P.dev.nf, P.dev.blk[0].K, P.dev.D);
